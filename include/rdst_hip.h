@@ -1,0 +1,135 @@
+/* rdst_hip.h — C ABI of librdst_hip.so, the MI355X (gfx950) implementation of the RDST hot path.
+ *
+ * The reference (GinZhu/RDST) is pure Python/PyTorch and has no FFI of its own: its hot path is
+ * sequences of stock torch ops inside nn.Module.forward.  Each entry point below
+ * replaces one such sequence; the comment on it cites the reference lines (relative to the
+ * reference root).  The Python host side (rdst_amd/ops.py) binds these with ctypes; see
+ * INTEGRATION.md for the binding a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to caller-allocated memory; nothing is allocated, freed or
+ *     synchronised inside; work is enqueued on `stream` (a hipStream_t passed as void*), so the
+ *     calls are graph-capturable and re-entrant across streams;
+ *   - activations are token-major rows: element (row, c) lives at base[row*ld + c], `ld` in
+ *     ELEMENTS (this is how the dense concat buffer of an RDSTB is addressed in place);
+ *   - `dtype` selects the activation element type: RDST_F32 (parity mode, fp32 I/O and math) or
+ *     RDST_BF16 (throughput mode: bf16 I/O, fp32 accumulation).  Parameters and parameter
+ *     gradients are ALWAYS fp32;
+ *   - return value: 0 on success, a negative hipError_t from the launch, or RDST_EINVAL /
+ *     RDST_ENOTSUP for bad or unsupported arguments.  Never throws.  rdst_last_error() returns a
+ *     thread-local message for the last non-zero return.
+ */
+#ifndef RDST_HIP_H
+#define RDST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDST_F32 0
+#define RDST_BF16 1
+
+#define RDST_EINVAL (-10001)
+#define RDST_ENOTSUP (-10002)
+
+#define RDST_ACT_NONE 0
+#define RDST_ACT_GELU 1       /* exact erf GELU (nn.GELU default), swin_transformer_sr.py:14,19 */
+#define RDST_ACT_LEAKY02 2    /* LeakyReLU(0.2), rdst_variations.py:425 ('3conv' variant) */
+
+int rdst_abi_version(void);
+const char* rdst_last_error(void);
+
+/* ---- K1: fused window attention forward -------------------------------------------------------
+ * Replaces torch.roll (swin_transformer_sr.py:244-247) -> window_partition (:32-43, :250-251) ->
+ * per-head split of qkv (:117-118) -> q*scale (:120) -> q@k^T (:121) -> + relative_position_bias
+ * gather (:123-126) -> + shifted-window mask (:128-131; mask itself :211-232, computed
+ * analytically here, the (nW,N,N) buffer is never read) -> softmax (:132/:134) -> attn@v (:138) ->
+ * head merge (:138) -> window_reverse (:46-59, :260-261) -> torch.roll back (:264-267).
+ *   qkv   : (B*H*W, 3C) rows, inner order [3][heads][C/heads]   (output of the qkv Linear :117)
+ *   table : (2*ws-1)^2 x heads fp32  (relative_position_bias_table, :85-86)
+ *   out   : (B*H*W, C) rows          (input of the proj Linear :139)
+ * H and W must be multiples of ws; 0 <= shift < ws.
+ */
+int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out,
+                   int B, int H, int W, int C, int heads, int ws, int shift, float scale,
+                   int dtype, void* stream);
+
+/* ---- K2: fused window attention backward (autograd of the sequence above) ----------------------
+ * Recomputes the softmax from qkv (nothing but qkv is saved by the forward).
+ *   dout   : (B*H*W, C) gradient of `out`
+ *   dqkv   : (B*H*W, 3C) gradient of `qkv` (overwritten)
+ *   dtable : (2*ws-1)^2 x heads fp32 gradient of `table` (overwritten; deterministic two-pass sum)
+ *   workspace : >= rdst_wattn_bwd_workspace(...) bytes of scratch
+ */
+size_t rdst_wattn_bwd_workspace(int B, int H, int W, int C, int heads, int ws);
+int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const void* dout,
+                   int64_t ld_dout, void* dqkv, int64_t ld_dqkv, float* dtable, void* workspace,
+                   size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift,
+                   float scale, int dtype, void* stream);
+
+/* ---- K3: (LayerNorm ->) Linear (-> activation) (-> + residual), forward and backward -----------
+ * Y[M,N] = act( LN(X)[M,K] @ Wt[N,K]^T + bias ) * out_scale + R
+ * Replaces: norm1 + qkv Linear (swin_transformer_sr.py:240, :117); proj + shortcut add (:139,
+ * :271); norm2 + fc1 + GELU (:272, :24-25); fc2 + residual (:27, :272); DenseSTLayer tail
+ * LN + Linear written straight into its slot of the dense buffer, times dense_scale
+ * (rdst_variations.py:310-313, :339-340: the torch.cat disappears); the final norm (:1337) and
+ * patch_embed.norm (swin_transformer_sr.py:517-518) with W == NULL (LayerNorm only).
+ *   ln_w/ln_b : fp32 (K) or NULL for no LayerNorm (eps 1e-5, biased variance)
+ *   Wt, bias  : fp32 (N,K) row-major as nn.Linear stores it / (N); Wt NULL => Y = LN(X) (N == K)
+ *   R         : optional residual rows (may alias Y), ld_r elements
+ *   stats     : optional fp32 (M,2) {mean, rstd} written by the forward for the backward
+ */
+int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b,
+                       const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y,
+                       int64_t ld_y, float* stats, int64_t M, int K, int N, int act, float out_scale,
+                       int dtype, void* stream);
+
+/* Backward of rdst_ln_linear_fwd.  dY (M,N) -> dX (M,K) [overwritten, or accumulated when
+ * accumulate_dx != 0], dW (N,K), dbias (N), dln_w/dln_b (K) [all overwritten].  The residual's
+ * gradient is dY itself and is the caller's business.  `Hpre` is the pre-activation (M,N) saved by
+ * the caller when act != NONE (NULL otherwise).  workspace as sized by the query below. */
+size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N);
+int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b,
+                       const float* stats, const float* Wt, const void* Hpre, int64_t ld_h,
+                       const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx,
+                       float* dW, float* dbias, float* dln_w, float* dln_b, void* workspace,
+                       size_t workspace_bytes, int64_t M, int K, int N, int act, float out_scale,
+                       int dtype, void* stream);
+
+/* ---- K4/K5/K6: 3x3 convolution on token-major (NHWC) rows ---------------------------------------
+ * Y[b,y,x,:] = act( sum_{ky,kx} X[b,y+ky-1,x+kx-1,:] @ Wc[:, :, ky, kx]^T + bias ) * out_scale + R
+ * with zero padding 1 and an optional PixelShuffle(r) folded into the store
+ * (out channel c*r*r + i*r + j of pixel (y,x) -> channel c of pixel (y*r+i, x*r+j)).
+ * Replaces: PatchUnEmbed transpose (swin_transformer_sr.py:552-555) -> nn.Conv2d(150,60,3,1,1)
+ * (rdst_variations.py:420-421) -> PatchEmbed transpose (:515-516) -> .mul(residual_scale) +
+ * shortcut (:444-445); conv_after_body (:1285,:1348-1350); head (:1229,:1344); UpSampler conv +
+ * nn.PixelShuffle(2) (common.py:125-136) and the last conv (:1303).  ksize 1 covers the 1x1 conv of
+ * the '3conv' variant (:426) and MeanShift (common.py:151-167).
+ *   Wc : fp32 (Cout, Cin, k, k) as nn.Conv2d stores it.
+ */
+int rdst_conv_fwd(const void* X, int64_t ld_x, const float* Wc, const float* bias, const void* R,
+                  int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin, int Cout,
+                  int ksize, int act, float out_scale, int shuffle_r, int dtype, void* stream);
+
+size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize);
+int rdst_conv_bwd(const void* X, int64_t ld_x, const float* Wc, const void* Ypre, int64_t ld_yp,
+                  const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx,
+                  float* dW, float* dbias, void* workspace, size_t workspace_bytes, int B, int H,
+                  int W, int Cin, int Cout, int ksize, int act, float out_scale, int shuffle_r,
+                  int dtype, void* stream);
+
+/* ---- layout helpers at the NCHW boundary of the module ------------------------------------------
+ * nchw (B,C,H,W) fp32 <-> token rows (B*H*W, C) of `dtype`.  The caller-facing tensors of
+ * RDSTSR.forward are fp32 NCHW (rdst_variations.py:1342-1360). */
+int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int B, int C, int H, int W,
+                      int dtype, void* stream);
+int rdst_rows_to_nchw(const void* rows, int64_t ld, float* nchw, int B, int C, int H, int W,
+                      int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDST_HIP_H */

@@ -1,0 +1,63 @@
+"""ctypes binding of librdst_hip.so (the C ABI of include/rdst_hip.h).  Fails loudly: there is no
+fallback when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librdst_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
+
+_p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/rdst_hip.h declares
+SIGNATURES = {
+    "rdst_abi_version": (_i, []),
+    "rdst_last_error": (C.c_char_p, []),
+    "rdst_wattn_fwd": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rdst_wattn_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
+    "rdst_wattn_bwd": (_i, [_p, _l, _p, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _i, _i, _i, _f, _i, _p]),
+    "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
+    "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _p, _p, _z,
+                                _l, _i, _i, _i, _f, _i, _p]),
+    "rdst_conv_fwd": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
+    "rdst_conv_bwd": (_i, [_p, _l, _p, _p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i,
+                           _f, _i, _i, _p]),
+    "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise: the product path never runs without it."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"rdst_amd: {LIB_PATH} is missing. Build it with `python -m rdst_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().rdst_last_error().decode(errors="replace")
+        raise HipError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,38 @@
+// Window geometry shared by the window-attention kernels (K1/K2).
+#pragma once
+#include "common.h"
+
+struct WinGeom {
+  int B, H, W, C, heads, ws, shift;
+  int nWh, nWw;  // windows per column / row
+  int N;         // tokens per window = ws*ws
+  int T;         // relative-position table rows = (2ws-1)^2
+};
+
+// Row (token) index in the (B*H*W) activation of token t of window (wr,wc) of image b.
+// The cyclic shift of networks/swin_transformer_sr.py:244-247 / :264-267 is folded in here:
+// shifted[r][c] = x[(r+shift)%H][(c+shift)%W], and the result goes back to the same place.
+__device__ __forceinline__ int64_t win_token(int b, int wr, int wc, int t, const WinGeom& g) {
+  const int y = t / g.ws, x = t - y * g.ws;
+  int r = wr * g.ws + y + g.shift;
+  if (r >= g.H) r -= g.H;
+  int c = wc * g.ws + x + g.shift;
+  if (c >= g.W) c -= g.W;
+  return ((int64_t)b * g.H + r) * g.W + c;
+}
+
+// Region id (0..8) of a token of the SHIFTED image: networks/swin_transformer_sr.py:215-225.
+// Tokens of one window with different ids are masked with -100 (:227-230).
+__device__ __forceinline__ int win_region(int wr, int wc, int t, const WinGeom& g) {
+  if (g.shift == 0) return 0;
+  const int y = t / g.ws, x = t - y * g.ws;
+  const int r = wr * g.ws + y, c = wc * g.ws + x;
+  const int rr = r < g.H - g.ws ? 0 : (r < g.H - g.shift ? 1 : 2);
+  const int cr = c < g.W - g.ws ? 0 : (c < g.W - g.shift ? 1 : 2);
+  return rr * 3 + cr;
+}
+
+int wattn_fwd_generic(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
+                      float scale, int dtype, hipStream_t st);
+int wattn_bwd_generic(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
+                      int64_t ldq, float* slab, const WinGeom& g, float scale, int dtype, hipStream_t st);

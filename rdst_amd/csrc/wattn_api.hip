@@ -1,0 +1,85 @@
+// C-ABI entry points of the window-attention path (K1/K2) + the deterministic d(table) reduction.
+#include "common.h"
+#include "wattn.h"
+
+thread_local char g_rdst_err[256] = {0};
+
+extern "C" int rdst_abi_version(void) { return 1; }
+extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
+
+namespace {
+
+int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shift, const char* who) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || ws <= 0)
+    return rdst_fail(RDST_EINVAL, "%s: non-positive dimension", who);
+  if (C % heads) return rdst_fail(RDST_EINVAL, "%s: C=%d not divisible by heads=%d", who, C, heads);
+  if (H % ws || W % ws) return rdst_fail(RDST_EINVAL, "%s: H=%d, W=%d must be multiples of the window size %d", who, H, W, ws);
+  if (shift < 0 || shift >= ws) return rdst_fail(RDST_EINVAL, "%s: shift=%d must be in [0, ws=%d)", who, shift, ws);
+  if ((int64_t)B * H * W >= (1ll << 31)) return rdst_fail(RDST_EINVAL, "%s: more than 2^31 tokens", who);
+  g.B = B; g.H = H; g.W = W; g.C = C; g.heads = heads; g.ws = ws; g.shift = shift;
+  g.nWh = H / ws; g.nWw = W / ws; g.N = ws * ws; g.T = (2 * ws - 1) * (2 * ws - 1);
+  return 0;
+}
+
+// dtable[t*heads + h] = sum over windows of slab[(win*heads + h)*T + t]; fixed summation order.
+__global__ void __launch_bounds__(1024)
+dtable_reduce(const float* __restrict__ slab, float* __restrict__ dtable, int nwin, int heads, int T) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int chunks = (T + 63) / 64;
+  const int h = blockIdx.x / chunks, t = (blockIdx.x % chunks) * 64 + lane;
+  float s = 0.f;
+  if (t < T)
+    for (int w = grp; w < nwin; w += 16) s += slab[((int64_t)w * heads + h) * T + t];
+  part[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && t < T) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += part[k][lane];
+    dtable[t * heads + h] = a;
+  }
+}
+
+}  // namespace
+
+extern "C" int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out,
+                              int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype,
+                              void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, "rdst_wattn_fwd")) return rc;
+  if (!qkv || !table || !out) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: null pointer");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: bad dtype %d", dtype);
+  if (ld_qkv < 3 * C || ld_out < C) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: leading dimension too small");
+  return wattn_fwd_generic(qkv, ld_qkv, table, out, ld_out, g, scale, dtype, (hipStream_t)stream);
+}
+
+extern "C" size_t rdst_wattn_bwd_workspace(int B, int H, int W, int C, int heads, int ws) {
+  if (B <= 0 || H <= 0 || W <= 0 || ws <= 0 || heads <= 0) return 0;
+  const size_t nwin = (size_t)B * (H / ws) * (W / ws);
+  const size_t T = (size_t)(2 * ws - 1) * (2 * ws - 1);
+  (void)C;
+  return nwin * heads * T * sizeof(float);
+}
+
+extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const void* dout, int64_t ld_dout,
+                              void* dqkv, int64_t ld_dqkv, float* dtable, void* workspace, size_t workspace_bytes,
+                              int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype,
+                              void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, "rdst_wattn_bwd")) return rc;
+  if (!qkv || !table || !dout || !dqkv || !dtable || !workspace)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: null pointer");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: bad dtype %d", dtype);
+  if (ld_qkv < 3 * C || ld_dqkv < 3 * C || ld_dout < C)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: leading dimension too small");
+  if (workspace_bytes < rdst_wattn_bwd_workspace(B, H, W, C, heads, ws))
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)workspace;
+  if (int rc = wattn_bwd_generic(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, g, scale, dtype, st)) return rc;
+  const int nwin = B * g.nWh * g.nWw;
+  const int chunks = (g.T + 63) / 64;
+  hipLaunchKernelGGL(dtable_reduce, dim3(heads * chunks), dim3(1024), 0, st, slab, dtable, nwin, heads, g.T);
+  return rdst_launch_status("dtable_reduce");
+}

@@ -1,0 +1,104 @@
+"""K1/K2 parity: the HIP window-attention kernels (through the C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdst_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32))
+
+
+CASES = [
+    # B, H, W, C, heads, ws, shift
+    (2, 16, 16, 60, 6, 8, 0),
+    (2, 16, 16, 60, 6, 8, 4),
+    (1, 16, 24, 90, 6, 8, 4),     # non-square, head dim 15
+    (1, 24, 16, 120, 6, 8, 4),    # head dim 20
+    (1, 32, 32, 60, 6, 16, 8),    # window 16 (N = 256)
+    (1, 32, 48, 48, 6, 16, 0),
+    (3, 8, 8, 48, 6, 8, 0),       # one window per image
+    (2, 8, 8, 60, 6, 8, 4),       # shifted, single window: every region in one window
+    (2, 8, 12, 72, 6, 4, 2),      # window 4 (RDSTSR ctor default), head dim 12
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,ws,shift", CASES)
+def test_wattn_fwd_bwd_fp32(B, H, W, C, heads, ws, shift):
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    scale = (C // heads) ** -0.5
+    qkv = _rand((B, H, W, 3 * C), 1)
+    table = _rand(((2 * ws - 1) ** 2, heads), 2, 0.5)
+    gout = _rand((B, H, W, C), 3)
+
+    q_ref = qkv.clone().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout)
+
+    q = qkv.to(dev).requires_grad_(True)
+    t = table.to(dev).requires_grad_(True)
+    o = ops.window_attention(q, t, H, W, heads, ws, shift, scale)
+    o.backward(gout.to(dev))
+    torch.cuda.synchronize()
+
+    # fp32 tolerance: |d| <= 2e-5 abs on O(1) outputs (different summation order, expf vs Sleef exp)
+    assert (o.cpu() - o_ref).abs().max().item() <= 2e-5
+    assert (q.grad.cpu() - q_ref.grad).abs().max().item() <= 5e-5
+    rel = (t.grad.cpu() - t_ref.grad).norm().item() / t_ref.grad.norm().item()
+    assert rel <= 1e-5, rel
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,ws,shift", CASES[:5])
+def test_wattn_fwd_bwd_bf16(B, H, W, C, heads, ws, shift):
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    scale = (C // heads) ** -0.5
+    qkv = _rand((B, H, W, 3 * C), 1).bfloat16()
+    table = _rand(((2 * ws - 1) ** 2, heads), 2, 0.5)
+    gout = _rand((B, H, W, C), 3).bfloat16()
+
+    q_ref = qkv.float().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout.float())
+
+    q = qkv.to(dev).requires_grad_(True)
+    t = table.to(dev).requires_grad_(True)
+    o = ops.window_attention(q, t, H, W, heads, ws, shift, scale)
+    o.backward(gout.to(dev))
+    torch.cuda.synchronize()
+    # bf16 I/O (8 mantissa bits): outputs are rounded once, inputs identical
+    assert (o.float().cpu() - o_ref).abs().max().item() <= 2e-2
+    assert (q.grad.float().cpu() - q_ref.grad).abs().max().item() <= 6e-2
+    rel = (t.grad.cpu() - t_ref.grad).norm().item() / t_ref.grad.norm().item()
+    assert rel <= 2e-2, rel
+
+
+def test_wattn_strided_rows():
+    """qkv living inside a wider buffer (ld > 3C) gives the same result."""
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, W, C, heads, ws, shift = 1, 16, 16, 60, 6, 8, 4
+    scale = 10 ** -0.5
+    big = _rand((B, H, W, 3 * C + 20), 5).to(dev)
+    table = _rand((225, heads), 6, 0.5).to(dev)
+    a = ops.window_attention(big[..., 4:4 + 3 * C], table, H, W, heads, ws, shift, scale)
+    b = ops.window_attention(big[..., 4:4 + 3 * C].contiguous(), table, H, W, heads, ws, shift, scale)
+    assert torch.equal(a, b)
+
+
+def test_wattn_bad_args():
+    from rdst_amd import ops, _lib
+    dev = torch.device("cuda:0")
+    qkv = torch.zeros(1, 12, 16, 180, device=dev)
+    table = torch.zeros(225, 6, device=dev)
+    with pytest.raises(_lib.HipError):
+        ops.window_attention(qkv, table, 12, 16, 6, 8, 0, 1.0)   # H not a multiple of ws
+    with pytest.raises(RuntimeError):
+        ops.window_attention(qkv.cpu(), table.cpu(), 16, 16, 6, 8, 0, 1.0)  # CPU tensors: no fallback
