@@ -51,11 +51,14 @@ const char* rdst_last_error(void);
  *   qkv   : (B*H*W, 3C) rows, inner order [3][heads][C/heads]   (output of the qkv Linear :117)
  *   table : (2*ws-1)^2 x heads fp32  (relative_position_bias_table, :85-86)
  *   out   : (B*H*W, C) rows          (input of the proj Linear :139)
+ *   mask  : NULL (the shifted-window mask is derived from `shift`), or an explicit additive fp32
+ *           mask (mask_nw, N, N) applied to window (w % mask_nw) — the `mask` argument of the
+ *           reference's standalone WindowAttention.forward(x, mask) (:110-131).
  * H and W must be multiples of ws; 0 <= shift < ws.
  */
-int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out,
-                   int B, int H, int W, int C, int heads, int ws, int shift, float scale,
-                   int dtype, void* stream);
+int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, const float* mask,
+                   int mask_nw, void* out, int64_t ld_out, int B, int H, int W, int C, int heads,
+                   int ws, int shift, float scale, int dtype, void* stream);
 
 /* ---- K2: fused window attention backward (autograd of the sequence above) ----------------------
  * Recomputes the softmax from qkv (nothing but qkv is saved by the forward).
@@ -65,61 +68,65 @@ int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, void* ou
  *   workspace : >= rdst_wattn_bwd_workspace(...) bytes of scratch
  */
 size_t rdst_wattn_bwd_workspace(int B, int H, int W, int C, int heads, int ws);
-int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const void* dout,
-                   int64_t ld_dout, void* dqkv, int64_t ld_dqkv, float* dtable, void* workspace,
+int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const float* mask,
+                   int mask_nw, const void* dout, int64_t ld_dout, void* dqkv, int64_t ld_dqkv,
+                   float* dtable, void* workspace,
                    size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift,
                    float scale, int dtype, void* stream);
 
-/* ---- K3: (LayerNorm ->) Linear (-> activation) (-> + residual), forward and backward -----------
- * Y[M,N] = act( LN(X)[M,K] @ Wt[N,K]^T + bias ) * out_scale + R
+/* ---- K3: (LayerNorm | activation ->) Linear (-> *scale + residual), forward and backward ---------
+ * Y[M,N] = ( f(X)[M,K] @ Wt[N,K]^T + bias ) * out_scale + R
+ * with f = LayerNorm (ln_w != NULL), or the activation `in_act` applied to X on the fly, or identity.
+ * Putting the activation on the INPUT side means the GELU output of the reference's Mlp is never
+ * materialised: fc1 writes its pre-activation, fc2 reads it through GELU.
  * Replaces: norm1 + qkv Linear (swin_transformer_sr.py:240, :117); proj + shortcut add (:139,
- * :271); norm2 + fc1 + GELU (:272, :24-25); fc2 + residual (:27, :272); DenseSTLayer tail
- * LN + Linear written straight into its slot of the dense buffer, times dense_scale
+ * :271); norm2 + fc1 (:272, :24); GELU + fc2 + residual (:25-27, :272); DenseSTLayer tail LN +
+ * Linear written straight into its slot of the dense buffer, times dense_scale
  * (rdst_variations.py:310-313, :339-340: the torch.cat disappears); the final norm (:1337) and
- * patch_embed.norm (swin_transformer_sr.py:517-518) with W == NULL (LayerNorm only).
+ * patch_embed.norm (swin_transformer_sr.py:517-518) with Wt == NULL (LayerNorm only, N == K).
  *   ln_w/ln_b : fp32 (K) or NULL for no LayerNorm (eps 1e-5, biased variance)
- *   Wt, bias  : fp32 (N,K) row-major as nn.Linear stores it / (N); Wt NULL => Y = LN(X) (N == K)
+ *   Wt, bias  : fp32 (N,K) row-major as nn.Linear stores it / (N) or NULL
  *   R         : optional residual rows (may alias Y), ld_r elements
- *   stats     : optional fp32 (M,2) {mean, rstd} written by the forward for the backward
+ *   stats     : fp32 (M,2) {mean, rstd} written by the forward when ln_w != NULL (kept for bwd)
  */
-int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b,
+int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
                        const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y,
-                       int64_t ld_y, float* stats, int64_t M, int K, int N, int act, float out_scale,
+                       int64_t ld_y, float* stats, int64_t M, int K, int N, float out_scale,
                        int dtype, void* stream);
 
 /* Backward of rdst_ln_linear_fwd.  dY (M,N) -> dX (M,K) [overwritten, or accumulated when
- * accumulate_dx != 0], dW (N,K), dbias (N), dln_w/dln_b (K) [all overwritten].  The residual's
- * gradient is dY itself and is the caller's business.  `Hpre` is the pre-activation (M,N) saved by
- * the caller when act != NONE (NULL otherwise).  workspace as sized by the query below. */
+ * accumulate_dx != 0], dW (N,K), dbias (N), dln_w/dln_b (K) [overwritten; any of them may be NULL
+ * to skip].  The residual's gradient is dY itself and is the caller's business. */
 size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N);
 int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b,
-                       const float* stats, const float* Wt, const void* Hpre, int64_t ld_h,
-                       const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx,
-                       float* dW, float* dbias, float* dln_w, float* dln_b, void* workspace,
-                       size_t workspace_bytes, int64_t M, int K, int N, int act, float out_scale,
-                       int dtype, void* stream);
+                       const float* stats, int in_act, const float* Wt, const void* dY,
+                       int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx, float* dW,
+                       float* dbias, float* dln_w, float* dln_b, void* workspace,
+                       size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
+                       void* stream);
 
-/* ---- K4/K5/K6: 3x3 convolution on token-major (NHWC) rows ---------------------------------------
- * Y[b,y,x,:] = act( sum_{ky,kx} X[b,y+ky-1,x+kx-1,:] @ Wc[:, :, ky, kx]^T + bias ) * out_scale + R
- * with zero padding 1 and an optional PixelShuffle(r) folded into the store
- * (out channel c*r*r + i*r + j of pixel (y,x) -> channel c of pixel (y*r+i, x*r+j)).
+/* ---- K4/K5/K6: k x k convolution (k = 1 or 3, stride 1, zero padding k/2) on token-major rows ----
+ * Y[b,y,x,:] = ( sum_{ky,kx} in_act(X)[b,y+ky-p,x+kx-p,:] @ Wc[:, :, ky, kx]^T + bias ) * out_scale + R
+ * with an optional PixelShuffle(r) folded into the store: out channel c*r*r + i*r + j of pixel (y,x)
+ * lands in channel c of pixel (y*r+i, x*r+j) of a (B, H*r, W*r, Cout/r^2) image.
  * Replaces: PatchUnEmbed transpose (swin_transformer_sr.py:552-555) -> nn.Conv2d(150,60,3,1,1)
  * (rdst_variations.py:420-421) -> PatchEmbed transpose (:515-516) -> .mul(residual_scale) +
- * shortcut (:444-445); conv_after_body (:1285,:1348-1350); head (:1229,:1344); UpSampler conv +
- * nn.PixelShuffle(2) (common.py:125-136) and the last conv (:1303).  ksize 1 covers the 1x1 conv of
- * the '3conv' variant (:426) and MeanShift (common.py:151-167).
- *   Wc : fp32 (Cout, Cin, k, k) as nn.Conv2d stores it.
+ * shortcut (:444-445); the LeakyReLU(0.2) of the '3conv' variant (:425,:427) as `in_act` of the next
+ * conv; conv_after_body (:1285,:1348-1350); head (:1229,:1344); UpSampler conv + nn.PixelShuffle
+ * (common.py:125-136) and the last conv (rdst_variations.py:1303); MeanShift (common.py:151-167).
+ *   Wc : fp32 (Cout, Cin, k, k) as nn.Conv2d stores it.   R/Y rows are in the OUTPUT geometry.
  */
-int rdst_conv_fwd(const void* X, int64_t ld_x, const float* Wc, const float* bias, const void* R,
-                  int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin, int Cout,
-                  int ksize, int act, float out_scale, int shuffle_r, int dtype, void* stream);
+int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const float* bias,
+                  const void* R, int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin,
+                  int Cout, int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
+/* Backward: dY (output geometry) -> dX (B*H*W, Cin) [overwrite / accumulate], dW (Cout,Cin,k,k),
+ * dbias (Cout) [overwritten; may be NULL]. */
 size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize);
-int rdst_conv_bwd(const void* X, int64_t ld_x, const float* Wc, const void* Ypre, int64_t ld_yp,
-                  const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx,
-                  float* dW, float* dbias, void* workspace, size_t workspace_bytes, int B, int H,
-                  int W, int Cin, int Cout, int ksize, int act, float out_scale, int shuffle_r,
-                  int dtype, void* stream);
+int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY,
+                  int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx, float* dW, float* dbias,
+                  void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                  int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
 /* ---- layout helpers at the NCHW boundary of the module ------------------------------------------
  * nchw (B,C,H,W) fp32 <-> token rows (B*H*W, C) of `dtype`.  The caller-facing tensors of

@@ -17,16 +17,16 @@ _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "rdst_abi_version": (_i, []),
     "rdst_last_error": (C.c_char_p, []),
-    "rdst_wattn_fwd": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rdst_wattn_fwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rdst_wattn_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
-    "rdst_wattn_bwd": (_i, [_p, _l, _p, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _i, _i, _i, _f, _i, _p]),
+    "rdst_wattn_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _l, _p, _l, _p, _l, _i, _i, _f, _i, _p]),
     "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
-    "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _p, _p, _z,
-                                _l, _i, _i, _i, _f, _i, _p]),
-    "rdst_conv_fwd": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
+    "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _i, _p, _p, _p, _p, _p, _z,
+                                _l, _i, _i, _f, _i, _p]),
+    "rdst_conv_fwd": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
-    "rdst_conv_bwd": (_i, [_p, _l, _p, _p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i,
+    "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _i, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,
                            _f, _i, _i, _p]),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
@@ -46,11 +46,20 @@ def load() -> C.CDLL:
             "(hipcc --offload-arch=gfx950); there is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn = getattr(lib, name, None)
+        if fn is None:  # a declared symbol the .so does not export: calling it raises
+            setattr(lib, name, _missing(name))
+            continue
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _missing(name):
+    def raiser(*_a, **_k):
+        raise RuntimeError(f"rdst_amd: {LIB_PATH} does not export {name}; rebuild with `python -m rdst_amd.build --force`")
+    return raiser
 
 
 class HipError(RuntimeError):

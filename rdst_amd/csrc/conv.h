@@ -1,0 +1,42 @@
+// Convolution geometry + hooks for the MFMA fast paths (conv_mfma.hip); a hook returns RDST_ENOTSUP
+// when it does not cover the shape and conv.hip falls back to the generic functor GEMM.
+#pragma once
+#include "common.h"
+
+struct ConvGeom {
+  int B, H, W;    // input pixel grid (the conv runs at this resolution)
+  int Cin, Cout;  // Cout counts channels BEFORE the pixel shuffle
+  int ks, pad;
+  int r;          // PixelShuffle factor folded into the output addressing (1 = none)
+  __host__ __device__ __forceinline__ int64_t pixels() const { return (int64_t)B * H * W; }
+  __device__ __forceinline__ void decode(int64_t p, int& b, int& y, int& x) const {
+    const int hw = H * W;
+    b = (int)(p / hw);
+    const int q = (int)(p - (int64_t)b * hw);
+    y = q / W;
+    x = q - y * W;
+  }
+  // output row / channel of conv output channel `co` at input pixel (b,y,x):
+  // nn.PixelShuffle(r): channel c*r*r + i*r + j -> channel c at (y*r+i, x*r+j)   (networks/common.py:132)
+  __device__ __forceinline__ void out_rc(int b, int y, int x, int co, int64_t& row, int& c) const {
+    if (r == 1) {
+      row = ((int64_t)b * H + y) * W + x;
+      c = co;
+      return;
+    }
+    const int r2 = r * r;
+    c = co / r2;
+    const int rem = co - c * r2, i = rem / r, j = rem - i * r;
+    row = ((int64_t)b * (H * r) + y * r + i) * (int64_t)(W * r) + x * r + j;
+  }
+};
+
+template <typename T>
+int conv_fwd_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr,
+                  T* Y, int64_t ldy, const ConvGeom& g, float s, hipStream_t st);
+template <typename T>
+int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int64_t lddy, T* dX,
+                    int64_t lddx, int accumulate, const ConvGeom& g, float s, hipStream_t st);
+template <typename T>
+int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dY, int64_t lddy, float* dW, float* slab,
+                    const ConvGeom& g, float s, hipStream_t st);

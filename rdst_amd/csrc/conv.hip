@@ -1,0 +1,263 @@
+// K4/K5/K6: k x k convolution (k = 1, 3) on token-major (NHWC) rows with the activation on the input
+// side, scale + residual epilogue and PixelShuffle folded into the store; forward, dgrad, wgrad.
+// Reference sequences replaced: see include/rdst_hip.h (rdst_conv_fwd / _bwd).
+// Shape-generic implementation on gemm_valu.h (implicit GEMM through addressing functors); the MFMA
+// fast paths for the 150->60, 60->60 and 60->240 convs live in conv_mfma.hip.
+#include "common.h"
+#include "gemm_valu.h"
+#include "conv.h"
+
+namespace {
+
+template <typename T>
+struct ConvA {  // fwd: A(p, k = tap*Cin + ci) = in_act(X)[p + tap][ci]
+  static constexpr bool kFast = true;
+  const T* X; int64_t ldx; ConvGeom g; int act;
+  __device__ __forceinline__ float operator()(int64_t p, int64_t k) const {
+    const int tap = (int)(k / g.Cin), ci = (int)(k - (int64_t)tap * g.Cin);
+    const int ky = tap / g.ks, kx = tap - ky * g.ks;
+    int b, y, x;
+    g.decode(p, b, y, x);
+    const int yy = y + ky - g.pad, xx = x + kx - g.pad;
+    if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) return 0.f;
+    return apply_act(to_f32<T>(X[(((int64_t)b * g.H + yy) * g.W + xx) * ldx + ci]), act);
+  }
+};
+template <typename T>
+struct ConvAT {  // wgrad B operand: B(p, n = tap*Cin + ci)
+  static constexpr bool kFast = false;
+  ConvA<T> a;
+  __device__ __forceinline__ float operator()(int64_t p, int n) const { return a(p, n); }
+};
+struct ConvB {  // fwd: B(k = tap*Cin + ci, co) = Wc[co][ci][tap]
+  static constexpr bool kFast = true;
+  const float* Wc; ConvGeom g;
+  __device__ __forceinline__ float operator()(int64_t k, int co) const {
+    const int tap = (int)(k / g.Cin), ci = (int)(k - (int64_t)tap * g.Cin);
+    return Wc[((int64_t)co * g.Cin + ci) * g.ks * g.ks + tap];
+  }
+};
+struct ConvBd {  // dgrad: B(k' = tap*Cout + co, ci) = Wc[co][ci][tap]
+  static constexpr bool kFast = false;
+  const float* Wc; ConvGeom g;
+  __device__ __forceinline__ float operator()(int64_t k, int ci) const {
+    const int tap = (int)(k / g.Cout), co = (int)(k - (int64_t)tap * g.Cout);
+    return Wc[((int64_t)co * g.Cin + ci) * g.ks * g.ks + tap];
+  }
+};
+template <typename T>
+struct ConvDyA {  // dgrad: A(p, k' = tap*Cout + co) = s * dY[p - tap][co]
+  static constexpr bool kFast = true;
+  const T* dY; int64_t ld; ConvGeom g; float s;
+  __device__ __forceinline__ float operator()(int64_t p, int64_t k) const {
+    const int tap = (int)(k / g.Cout), co = (int)(k - (int64_t)tap * g.Cout);
+    const int ky = tap / g.ks, kx = tap - ky * g.ks;
+    int b, y, x;
+    g.decode(p, b, y, x);
+    const int yy = y - ky + g.pad, xx = x - kx + g.pad;
+    if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) return 0.f;
+    int64_t row; int c;
+    g.out_rc(b, yy, xx, co, row, c);
+    return to_f32<T>(dY[row * ld + c]) * s;
+  }
+};
+template <typename T>
+struct ConvDyAT {  // wgrad: A(co, p) = s * dY[p][co]
+  static constexpr bool kFast = false;
+  const T* dY; int64_t ld; ConvGeom g; float s;
+  __device__ __forceinline__ float operator()(int64_t co, int64_t p) const {
+    int b, y, x;
+    g.decode(p, b, y, x);
+    int64_t row; int c;
+    g.out_rc(b, y, x, (int)co, row, c);
+    return to_f32<T>(dY[row * ld + c]) * s;
+  }
+};
+template <typename T>
+struct ConvDyCol {
+  const T* dY; int64_t ld; ConvGeom g; float s;
+  __device__ __forceinline__ float operator()(int64_t p, int co) const {
+    int b, y, x;
+    g.decode(p, b, y, x);
+    int64_t row; int c;
+    g.out_rc(b, y, x, co, row, c);
+    return to_f32<T>(dY[row * ld + c]) * s;
+  }
+};
+template <typename T>
+struct ConvFwdEp {
+  const float* bias; const T* R; int64_t ldr; T* Y; int64_t ldy; ConvGeom g; float s;
+  __device__ __forceinline__ void operator()(int64_t p, int co, float acc, int) const {
+    int b, y, x;
+    g.decode(p, b, y, x);
+    int64_t row; int c;
+    g.out_rc(b, y, x, co, row, c);
+    float v = (acc + (bias ? bias[co] : 0.f)) * s;
+    if (R) v += to_f32<T>(R[row * ldr + c]);
+    Y[row * ldy + c] = from_f32<T>(v);
+  }
+};
+template <typename T>
+struct ConvDxEp {
+  const T* X; int64_t ldx; T* dX; int64_t lddx; int act; int accumulate;
+  __device__ __forceinline__ void operator()(int64_t p, int ci, float acc, int) const {
+    float v = acc;
+    if (act) v *= act_grad(to_f32<T>(X[p * ldx + ci]), act);
+    if (accumulate) v += to_f32<T>(dX[p * lddx + ci]);
+    dX[p * lddx + ci] = from_f32<T>(v);
+  }
+};
+struct ConvSlabEp {  // wgrad split-K partials, already in nn.Conv2d weight order [co][ci][tap]
+  float* slab; ConvGeom g;
+  __device__ __forceinline__ void operator()(int64_t co, int n, float acc, int z) const {
+    const int tap = n / g.Cin, ci = n - tap * g.Cin;
+    const int64_t total = (int64_t)g.Cout * g.Cin * g.ks * g.ks;
+    slab[(int64_t)z * total + (co * g.Cin + ci) * g.ks * g.ks + tap] = acc;
+  }
+};
+
+constexpr int kSmallBlocks = 512;
+constexpr int kMaxSplits = 128;
+
+int wgrad_splits(const ConvGeom& g) {
+  const int tiles = ((g.Cout + 63) / 64) * ((g.ks * g.ks * g.Cin + 63) / 64);
+  int s = 1024 / tiles;
+  if (s < 1) s = 1;
+  if (s > kMaxSplits) s = kMaxSplits;
+  return s;
+}
+
+template <typename T>
+int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr, T* Y,
+          int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
+  if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+  ConvA<T> la{X, ldx, g, in_act};
+  ConvB lb{Wc, g};
+  ConvFwdEp<T> ep{bias, R, ldr, Y, ldy, g, s};
+  return gemm_valu_launch(la, lb, ep, g.pixels(), g.Cout, (int64_t)g.ks * g.ks * g.Cin, 1, st, "conv_fwd");
+}
+
+template <typename T>
+int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int64_t lddy, T* dX, int64_t lddx,
+          int accumulate, float* dW, float* dbias, float* wsp, const ConvGeom& g, float s, hipStream_t st) {
+  const int64_t wtotal = (int64_t)g.Cout * g.Cin * g.ks * g.ks;
+  float* slab = wsp;
+  float* small = slab + (int64_t)kMaxSplits * wtotal;
+  if (dbias) {
+    ConvDyCol<T> f{dY, lddy, g, s};
+    if (int rc = colsum_launch(f, g.pixels(), g.Cout, small, kSmallBlocks, dbias, st, "conv_dbias")) return rc;
+  }
+  if (dW) {
+    int rc = conv_wgrad_mfma<T>(X, ldx, in_act, dY, lddy, dW, slab, g, s, st);
+    if (rc == RDST_ENOTSUP) {
+      ConvDyAT<T> la{dY, lddy, g, s};
+      ConvAT<T> lb{ConvA<T>{X, ldx, g, in_act}};
+      ConvSlabEp ep{slab, g};
+      const int splits = wgrad_splits(g);
+      const int z = gemm_valu_splits(g.pixels(), splits);
+      rc = gemm_valu_launch(la, lb, ep, g.Cout, g.ks * g.ks * g.Cin, g.pixels(), splits, st, "conv_wgrad");
+      if (!rc) rc = slab_reduce(slab, dW, z, wtotal, st);
+    }
+    if (rc) return rc;
+  }
+  if (dX) {
+    int rc = conv_dgrad_mfma<T>(X, ldx, in_act, Wc, dY, lddy, dX, lddx, accumulate, g, s, st);
+    if (rc == RDST_ENOTSUP) {
+      ConvDyA<T> la{dY, lddy, g, s};
+      ConvBd lb{Wc, g};
+      ConvDxEp<T> ep{X, ldx, dX, lddx, in_act, accumulate};
+      rc = gemm_valu_launch(la, lb, ep, g.pixels(), g.Cin, (int64_t)g.ks * g.ks * g.Cout, 1, st, "conv_dgrad");
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int make_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ks, int r, const char* who) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return rdst_fail(RDST_EINVAL, "%s: non-positive dimension", who);
+  if (ks != 1 && ks != 3) return rdst_fail(RDST_ENOTSUP, "%s: kernel size %d (1 or 3)", who, ks);
+  if (r < 1 || Cout % (r * r)) return rdst_fail(RDST_EINVAL, "%s: Cout=%d not divisible by shuffle^2=%d", who, Cout, r * r);
+  if ((int64_t)B * H * W * r * r >= (1ll << 31)) return rdst_fail(RDST_EINVAL, "%s: more than 2^31 output pixels", who);
+  g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ks = ks; g.pad = ks / 2; g.r = r;
+  return 0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_rows_kernel(const float* __restrict__ src, T* __restrict__ rows, int64_t ld,
+                                                           int B, int C, int64_t HW) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B*HW*C, c fastest
+  if (i >= (int64_t)B * HW * C) return;
+  const int c = (int)(i % C);
+  const int64_t bp = i / C, b = bp / HW, p = bp - b * HW;
+  rows[bp * ld + c] = from_f32<T>(src[(b * C + c) * HW + p]);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) rows_to_nchw_kernel(const T* __restrict__ rows, int64_t ld, float* __restrict__ dst,
+                                                           int B, int C, int64_t HW) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over B*C*HW, p fastest
+  if (i >= (int64_t)B * HW * C) return;
+  const int64_t p = i % HW, bc = i / HW, b = bc / C;
+  const int c = (int)(bc - b * C);
+  dst[i] = to_f32<T>(rows[(b * HW + p) * ld + c]);
+}
+
+}  // namespace
+
+extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const float* bias, const void* R,
+                             int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin, int Cout, int ksize,
+                             float out_scale, int shuffle_r, int dtype, void* stream) {
+  ConvGeom g;
+  if (int rc = make_geom(g, B, H, W, Cin, Cout, ksize, shuffle_r, "rdst_conv_fwd")) return rc;
+  if (!X || !Wc || !Y) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: null pointer");
+  const int cy = Cout / (shuffle_r * shuffle_r);
+  if (ld_x < Cin || ld_y < cy || (R && ld_r < cy)) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: leading dimension too small");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RDST_F32)
+    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, st);
+  return fwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, g, out_scale, st);
+}
+
+extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
+  return sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64);
+}
+
+extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY, int64_t ld_dy,
+                             void* dX, int64_t ld_dx, int accumulate_dx, float* dW, float* dbias, void* workspace,
+                             size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int ksize, float out_scale,
+                             int shuffle_r, int dtype, void* stream) {
+  ConvGeom g;
+  if (int rc = make_geom(g, B, H, W, Cin, Cout, ksize, shuffle_r, "rdst_conv_bwd")) return rc;
+  if (!X || !Wc || !dY || !workspace) return rdst_fail(RDST_EINVAL, "rdst_conv_bwd: null pointer");
+  const int cy = Cout / (shuffle_r * shuffle_r);
+  if (ld_x < Cin || ld_dy < cy || (dX && ld_dx < Cin)) return rdst_fail(RDST_EINVAL, "rdst_conv_bwd: leading dimension too small");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_conv_bwd: bad dtype %d", dtype);
+  if (workspace_bytes < rdst_conv_bwd_workspace(B, H, W, Cin, Cout, ksize)) return rdst_fail(RDST_EINVAL, "rdst_conv_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RDST_F32)
+    return bwd_t<float>((const float*)X, ld_x, in_act, Wc, (const float*)dY, ld_dy, (float*)dX, ld_dx, accumulate_dx, dW, dbias, (float*)workspace, g, out_scale, st);
+  return bwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, accumulate_dx, dW, dbias, (float*)workspace, g, out_scale, st);
+}
+
+extern "C" int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int B, int C, int H, int W, int dtype, void* stream) {
+  if (!nchw || !rows || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return rdst_fail(RDST_EINVAL, "rdst_nchw_to_rows: bad arguments");
+  const int64_t n = (int64_t)B * C * H * W;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RDST_F32) hipLaunchKernelGGL((nchw_to_rows_kernel<float>), grid, dim3(256), 0, st, nchw, (float*)rows, ld, B, C, (int64_t)H * W);
+  else if (dtype == RDST_BF16) hipLaunchKernelGGL((nchw_to_rows_kernel<bf16>), grid, dim3(256), 0, st, nchw, (bf16*)rows, ld, B, C, (int64_t)H * W);
+  else return rdst_fail(RDST_EINVAL, "rdst_nchw_to_rows: bad dtype %d", dtype);
+  return rdst_launch_status("nchw_to_rows");
+}
+
+extern "C" int rdst_rows_to_nchw(const void* rows, int64_t ld, float* nchw, int B, int C, int H, int W, int dtype, void* stream) {
+  if (!nchw || !rows || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return rdst_fail(RDST_EINVAL, "rdst_rows_to_nchw: bad arguments");
+  const int64_t n = (int64_t)B * C * H * W;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RDST_F32) hipLaunchKernelGGL((rows_to_nchw_kernel<float>), grid, dim3(256), 0, st, (const float*)rows, ld, nchw, B, C, (int64_t)H * W);
+  else if (dtype == RDST_BF16) hipLaunchKernelGGL((rows_to_nchw_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)rows, ld, nchw, B, C, (int64_t)H * W);
+  else return rdst_fail(RDST_EINVAL, "rdst_rows_to_nchw: bad dtype %d", dtype);
+  return rdst_launch_status("rows_to_nchw");
+}

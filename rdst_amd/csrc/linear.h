@@ -1,0 +1,18 @@
+// Hooks for the MFMA fast paths of K3 (linear_mfma.hip).  Each returns RDST_ENOTSUP when the shape
+// or dtype is not covered, in which case linear.hip falls back to the generic functor GEMM.
+#pragma once
+#include "common.h"
+
+template <typename T>
+int linear_fwd_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt,
+                    const float* bias, const T* R, int64_t ldr, T* Y, int64_t ldy, float* stats, int64_t M, int K,
+                    int N, float s, hipStream_t st);
+// dA[M][K] = s * dY[M][N] @ Wt[N][K]; has_ln: write fp32 dA, else dX = dA*act'(X) (+dX)
+template <typename T>
+int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const float* Wt, const T* dY, int64_t lddy,
+                      T* dX, int64_t lddx, int accumulate, float* dA, int64_t M, int K, int N, float s, hipStream_t st);
+// dW[N][K] = s * dY^T f(X)
+template <typename T>
+int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
+                      const T* dY, int64_t lddy, float* dW, float* slab, int64_t M, int K, int N, float s,
+                      hipStream_t st);

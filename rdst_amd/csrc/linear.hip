@@ -1,0 +1,381 @@
+// K3: (LayerNorm | activation ->) Linear (-> *scale + residual), forward and backward.
+// Reference sequences replaced: see include/rdst_hip.h (rdst_ln_linear_fwd / _bwd).
+// This file holds the shape-generic fp32-math implementation built on gemm_valu.h plus the row-wise
+// LayerNorm kernels; the MFMA fast paths for the shapes of the shipped configs live in
+// linear_mfma.hip and are dispatched from here.
+#include "common.h"
+#include "gemm_valu.h"
+#include "linear.h"
+
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                          int S, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += slab[(int64_t)s * n + i];
+  out[i] = a;
+}
+
+int slab_reduce(const float* slab, float* out, int S, int64_t n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, out, S, n);
+  return rdst_launch_status("slab_reduce");
+}
+
+namespace {
+
+constexpr float kLnEps = 1e-5f;  // nn.LayerNorm default
+
+// ---- LayerNorm row statistics: one wave per row ------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) row_stats_kernel(const T* __restrict__ X, int64_t ldx, float* __restrict__ stats,
+                                                        int64_t M, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* x = X + row * ldx;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += to_f32<T>(x[k]);
+  const float mean = wave_sum(s) / (float)K;
+  float v = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float d = to_f32<T>(x[k]) - mean;
+    v = fmaf(d, d, v);
+  }
+  const float var = wave_sum(v) / (float)K;
+  if (lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = 1.0f / sqrtf(var + kLnEps);
+  }
+}
+
+// ---- LayerNorm only: Y = LN(X)*s + R -------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ln_apply_kernel(const T* __restrict__ X, int64_t ldx, const float* __restrict__ stats,
+                                                       const float* __restrict__ g, const float* __restrict__ b,
+                                                       const T* R, int64_t ldr, T* Y, int64_t ldy, int64_t M, int K,
+                                                       float s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * K) return;
+  const int64_t m = i / K;
+  const int k = (int)(i - m * K);
+  float v = (to_f32<T>(X[m * ldx + k]) - stats[2 * m]) * stats[2 * m + 1] * g[k] + b[k];
+  v *= s;
+  if (R) v += to_f32<T>(R[m * ldr + k]);
+  Y[m * ldy + k] = from_f32<T>(v);
+}
+
+// ---- functors -------------------------------------------------------------------------------------
+template <typename T>
+struct LinIn {  // f(X)[m][k]
+  static constexpr bool kFast = true;
+  const T* X; int64_t ldx; const float* stats; const float* g; const float* b; int act;
+  __device__ __forceinline__ float operator()(int64_t m, int64_t k) const {
+    float v = to_f32<T>(X[m * ldx + k]);
+    if (g) return (v - stats[2 * m]) * stats[2 * m + 1] * g[k] + b[k];
+    return apply_act(v, act);
+  }
+};
+template <typename T>
+struct LinInT {  // same matrix as B operand of the wgrad GEMM: B(k = m_row, n = k_col)
+  static constexpr bool kFast = false;
+  LinIn<T> f;
+  __device__ __forceinline__ float operator()(int64_t m, int k) const { return f(m, k); }
+};
+struct WtB {  // B(k, n) = Wt[n][k]
+  static constexpr bool kFast = true;
+  const float* Wt; int K;
+  __device__ __forceinline__ float operator()(int64_t k, int n) const { return Wt[(int64_t)n * K + k]; }
+};
+struct WtBT {  // B(n_idx as k, k_idx as n) = Wt[n_idx][k_idx]
+  static constexpr bool kFast = false;
+  const float* Wt; int K;
+  __device__ __forceinline__ float operator()(int64_t n_idx, int k_idx) const { return Wt[n_idx * K + k_idx]; }
+};
+template <typename T>
+struct DyA {  // A(m, n) = dY[m][n] * s
+  static constexpr bool kFast = true;
+  const T* dY; int64_t ld; float s;
+  __device__ __forceinline__ float operator()(int64_t m, int64_t n) const { return to_f32<T>(dY[m * ld + n]) * s; }
+};
+template <typename T>
+struct DyAT {  // A(n, m) = dY[m][n] * s   (wgrad: rows of the output are n)
+  static constexpr bool kFast = false;
+  const T* dY; int64_t ld; float s;
+  __device__ __forceinline__ float operator()(int64_t n, int64_t m) const { return to_f32<T>(dY[m * ld + n]) * s; }
+};
+template <typename T>
+struct DyCol {  // colsum functor
+  const T* dY; int64_t ld; float s;
+  __device__ __forceinline__ float operator()(int64_t m, int n) const { return to_f32<T>(dY[m * ld + n]) * s; }
+};
+
+template <typename T>
+struct FwdEp {
+  const float* bias; const T* R; int64_t ldr; T* Y; int64_t ldy; float s;
+  __device__ __forceinline__ void operator()(int64_t m, int n, float acc, int) const {
+    float v = acc + (bias ? bias[n] : 0.f);
+    v *= s;
+    if (R) v += to_f32<T>(R[m * ldr + n]);
+    Y[m * ldy + n] = from_f32<T>(v);
+  }
+};
+struct SlabEp {  // split-K partials of an (rows x cols) matrix
+  float* slab; int64_t n_total; int cols;
+  __device__ __forceinline__ void operator()(int64_t r, int c, float acc, int z) const {
+    slab[(int64_t)z * n_total + r * cols + c] = acc;
+  }
+};
+struct DaEp {  // LN case: keep d(LN output) in fp32 for the row-wise LN backward
+  float* dA; int K;
+  __device__ __forceinline__ void operator()(int64_t m, int k, float acc, int) const { dA[m * K + k] = acc; }
+};
+template <typename T>
+struct DxEp {  // no LN: dX = dA * act'(X) (+ existing dX)
+  const T* X; int64_t ldx; T* dX; int64_t lddx; int act; int accumulate;
+  __device__ __forceinline__ void operator()(int64_t m, int k, float acc, int) const {
+    float v = acc;
+    if (act) v *= act_grad(to_f32<T>(X[m * ldx + k]), act);
+    if (accumulate) v += to_f32<T>(dX[m * lddx + k]);
+    dX[m * lddx + k] = from_f32<T>(v);
+  }
+};
+
+// ---- LayerNorm backward, one wave per row, K <= 64*KC --------------------------------------------
+// dX = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dA * gamma;  partial dgamma/dbeta per block.
+template <typename T, int KC>
+__global__ void __launch_bounds__(256)
+ln_bwd_rows_kernel(const float* __restrict__ dA, const T* __restrict__ X, int64_t ldx, const float* __restrict__ stats,
+                   const float* __restrict__ gamma, T* dX, int64_t lddx, int accumulate, float* __restrict__ slab,
+                   int64_t M, int K) {
+  __shared__ float red[4][2][64 * KC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dg[KC], db[KC], gm[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    dg[c] = 0.f;
+    db[c] = 0.f;
+    const int k = lane + 64 * c;
+    gm[c] = k < K ? gamma[k] : 0.f;
+  }
+  const float invK = 1.0f / (float)K;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[KC], g[KC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = lane + 64 * c;
+      if (k < K) {
+        const float da = dA[row * K + k];
+        xh[c] = (to_f32<T>(X[row * ldx + k]) - mean) * rstd;
+        g[c] = da * gm[c];
+        s1 += g[c];
+        s2 = fmaf(g[c], xh[c], s2);
+        dg[c] = fmaf(da, xh[c], dg[c]);
+        db[c] += da;
+      } else {
+        xh[c] = 0.f;
+        g[c] = 0.f;
+      }
+    }
+    s1 = wave_sum(s1) * invK;
+    s2 = wave_sum(s2) * invK;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = lane + 64 * c;
+      if (k < K) {
+        float v = rstd * (g[c] - s1 - xh[c] * s2);
+        if (dX) {
+          if (accumulate) v += to_f32<T>(dX[row * lddx + k]);
+          dX[row * lddx + k] = from_f32<T>(v);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    red[wave][0][lane + 64 * c] = dg[c];
+    red[wave][1][lane + 64 * c] = db[c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * K; i += 256) {
+    const int which = i / K, k = i - which * K;
+    const float a = red[0][which][k] + red[1][which][k] + red[2][which][k] + red[3][which][k];
+    slab[(int64_t)blockIdx.x * 2 * K + i] = a;  // [block][2][K]
+  }
+}
+
+constexpr int kWgradSplits = 96;
+constexpr int kSmallBlocks = 512;
+
+template <typename T>
+int fwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt, const float* bias,
+          const T* R, int64_t ldr, T* Y, int64_t ldy, float* stats, int64_t M, int K, int N, float s, hipStream_t st) {
+  if (ln_w) {
+    hipLaunchKernelGGL((row_stats_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, X, ldx, stats, M, K);
+    if (int rc = rdst_launch_status("row_stats")) return rc;
+  }
+  if (!Wt) {
+    const int64_t n = M * K;
+    hipLaunchKernelGGL((ln_apply_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, stats, ln_w,
+                       ln_b, R, ldr, Y, ldy, M, K, s);
+    return rdst_launch_status("ln_apply");
+  }
+  if (int rc = linear_fwd_mfma<T>(X, ldx, ln_w, ln_b, in_act, Wt, bias, R, ldr, Y, ldy, stats, M, K, N, s, st);
+      rc != RDST_ENOTSUP)
+    return rc;
+  LinIn<T> la{X, ldx, stats, ln_w, ln_b, in_act};
+  WtB lb{Wt, K};
+  FwdEp<T> ep{bias, R, ldr, Y, ldy, s};
+  return gemm_valu_launch(la, lb, ep, M, N, K, 1, st, "linear_fwd");
+}
+
+template <typename T>
+int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act, const float* Wt,
+          const T* dY, int64_t lddy, T* dX, int64_t lddx, int accumulate, float* dW, float* dbias, float* dln_w,
+          float* dln_b, float* wsp, int64_t M, int K, int N, float s, hipStream_t st) {
+  // workspace carve: [dA: M*K] [slabW: splits*N*K] [small: kSmallBlocks * max(N, 2K)]
+  float* dA = wsp;
+  float* slabW = dA + (ln_w ? M * K : 0);
+  float* small = slabW + (int64_t)kWgradSplits * N * K;
+  LinIn<T> fin{X, ldx, stats, ln_w, ln_b, in_act};
+  if (Wt) {
+    if (dbias) {
+      DyCol<T> f{dY, lddy, s};
+      if (int rc = colsum_launch(f, M, N, small, kSmallBlocks, dbias, st, "linear_dbias")) return rc;
+    }
+    if (dW) {
+      if (int rc = linear_wgrad_mfma<T>(X, ldx, ln_w, ln_b, stats, in_act, dY, lddy, dW, slabW, M, K, N, s, st);
+          rc != 0) {
+        if (rc != RDST_ENOTSUP) return rc;
+        DyAT<T> la{dY, lddy, s};
+        LinInT<T> lb{fin};
+        SlabEp ep{slabW, (int64_t)N * K, K};
+        const int z = gemm_valu_splits(M, kWgradSplits);
+        if (int rc2 = gemm_valu_launch(la, lb, ep, N, K, M, kWgradSplits, st, "linear_wgrad")) return rc2;
+        if (int rc2 = slab_reduce(slabW, dW, z, (int64_t)N * K, st)) return rc2;
+      }
+    }
+    if (dX) {
+      int rc = linear_dgrad_mfma<T>(X, ldx, ln_w != nullptr, in_act, Wt, dY, lddy, dX, lddx, accumulate, dA, M, K, N, s, st);
+      if (rc == RDST_ENOTSUP) {
+        DyA<T> la{dY, lddy, s};
+        WtBT lb{Wt, K};
+        if (ln_w) {
+          DaEp ep{dA, K};
+          rc = gemm_valu_launch(la, lb, ep, M, K, N, 1, st, "linear_dgrad");
+        } else {
+          DxEp<T> ep{X, ldx, dX, lddx, in_act, accumulate};
+          rc = gemm_valu_launch(la, lb, ep, M, K, N, 1, st, "linear_dgrad");
+        }
+      }
+      if (rc) return rc;
+    }
+  }
+  if (ln_w) {
+    const float* dAsrc = dA;
+    if (!dX && !dln_w && !dln_b) return 0;
+    if (K > 512) return rdst_fail(RDST_ENOTSUP, "rdst_ln_linear_bwd: LayerNorm width %d > 512", K);
+    const int blocks = (int)((M + 3) / 4 < kSmallBlocks ? (M + 3) / 4 : kSmallBlocks);
+    const int kc = (K + 63) / 64;
+#define RDST_LNB(KC)                                                                                              \
+  hipLaunchKernelGGL((ln_bwd_rows_kernel<T, KC>), dim3(blocks), dim3(256), 0, st, dAsrc, X, ldx, stats, ln_w, dX, \
+                     lddx, accumulate, small, M, K)
+    if (kc <= 1) RDST_LNB(1); else if (kc <= 2) RDST_LNB(2); else if (kc <= 4) RDST_LNB(4); else RDST_LNB(8);
+#undef RDST_LNB
+    if (int rc = rdst_launch_status("ln_bwd_rows")) return rc;
+    // slab is [blocks][2][K] -> reduce to a [2][K] scratch then copy out
+    float* out2 = small + (int64_t)kSmallBlocks * 2 * K;
+    if (int rc = slab_reduce(small, out2, blocks, 2 * K, st)) return rc;
+    if (dln_w) (void)hipMemcpyAsync(dln_w, out2, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+    if (dln_b) (void)hipMemcpyAsync(dln_b, out2 + K, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+  }
+  return 0;
+}
+
+// LN-only (Wt == NULL) backward: dA = dY*s in fp32, then the row kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) scale_to_f32_kernel(const T* __restrict__ dY, int64_t ld, float* __restrict__ dA,
+                                                           int64_t M, int K, float s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * K) return;
+  const int64_t m = i / K;
+  dA[i] = to_f32<T>(dY[m * ld + (i - m * K)]) * s;
+}
+
+template <typename T>
+int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, const T* dY, int64_t lddy, T* dX,
+                int64_t lddx, int accumulate, float* dln_w, float* dln_b, float* wsp, int64_t M, int K, float s,
+                hipStream_t st) {
+  float* dA = wsp;
+  float* small = dA + M * K;
+  const int64_t n = M * K;
+  hipLaunchKernelGGL((scale_to_f32_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dY, lddy, dA, M, K, s);
+  if (int rc = rdst_launch_status("scale_to_f32")) return rc;
+  if (K > 512) return rdst_fail(RDST_ENOTSUP, "rdst_ln_linear_bwd: LayerNorm width %d > 512", K);
+  const int blocks = (int)((M + 3) / 4 < kSmallBlocks ? (M + 3) / 4 : kSmallBlocks);
+  const int kc = (K + 63) / 64;
+#define RDST_LNB(KC)                                                                                           \
+  hipLaunchKernelGGL((ln_bwd_rows_kernel<T, KC>), dim3(blocks), dim3(256), 0, st, dA, X, ldx, stats, ln_w, dX, \
+                     lddx, accumulate, small, M, K)
+  if (kc <= 1) RDST_LNB(1); else if (kc <= 2) RDST_LNB(2); else if (kc <= 4) RDST_LNB(4); else RDST_LNB(8);
+#undef RDST_LNB
+  if (int rc = rdst_launch_status("ln_bwd_rows")) return rc;
+  float* out2 = small + (int64_t)kSmallBlocks * 2 * K;
+  if (int rc = slab_reduce(small, out2, blocks, 2 * K, st)) return rc;
+  if (dln_w) (void)hipMemcpyAsync(dln_w, out2, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+  if (dln_b) (void)hipMemcpyAsync(dln_b, out2 + K, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
+                                  const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y, int64_t ld_y,
+                                  float* stats, int64_t M, int K, int N, float out_scale, int dtype, void* stream) {
+  if (!X || !Y) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: null pointer");
+  if (M < 0 || K <= 0 || N <= 0) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: bad dimensions");
+  if ((ln_w == nullptr) != (ln_b == nullptr)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: ln_w/ln_b must come together");
+  if (ln_w && !stats) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: LayerNorm needs a stats buffer");
+  if (ln_w && in_act) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: LayerNorm and in_act are exclusive");
+  if (!Wt && (!ln_w || N != K)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: Wt == NULL means LayerNorm only (N == K)");
+  if (ld_x < K || ld_y < N || (R && ld_r < N)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: leading dimension too small");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: bad dtype %d", dtype);
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RDST_F32)
+    return fwd_t<float>((const float*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const float*)R, ld_r, (float*)Y, ld_y, stats, M, K, N, out_scale, st);
+  return fwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, stats, M, K, N, out_scale, st);
+}
+
+extern "C" size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const size_t mx = (size_t)(N > 2 * K ? N : 2 * K);
+  return sizeof(float) * ((size_t)M * K + (size_t)kWgradSplits * N * K + (size_t)kSmallBlocks * mx + 2 * (size_t)K + 64);
+}
+
+extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
+                                  int in_act, const float* Wt, const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx,
+                                  int accumulate_dx, float* dW, float* dbias, float* dln_w, float* dln_b, void* workspace,
+                                  size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
+                                  void* stream) {
+  if (!X || !dY || !workspace) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: null pointer");
+  if (M < 0 || K <= 0 || N <= 0) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: bad dimensions");
+  if (ln_w && !stats) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: LayerNorm needs the forward's stats");
+  if (!Wt && (!ln_w || N != K)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: Wt == NULL means LayerNorm only (N == K)");
+  if (ld_x < K || ld_dy < N || (dX && ld_dx < K)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: leading dimension too small");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: bad dtype %d", dtype);
+  if (workspace_bytes < rdst_ln_linear_bwd_workspace(M, K, N)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: workspace too small");
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  float* wsp = (float*)workspace;
+  if (!Wt) {
+    if (dtype == RDST_F32)
+      return ln_only_bwd<float>((const float*)X, ld_x, ln_w, stats, (const float*)dY, ld_dy, (float*)dX, ld_dx, accumulate_dx, dln_w, dln_b, wsp, M, K, out_scale, st);
+    return ln_only_bwd<bf16>((const bf16*)X, ld_x, ln_w, stats, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, accumulate_dx, dln_w, dln_b, wsp, M, K, out_scale, st);
+  }
+  if (dtype == RDST_F32)
+    return bwd_t<float>((const float*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const float*)dY, ld_dy, (float*)dX, ld_dx, accumulate_dx, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
+  return bwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, accumulate_dx, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
+}

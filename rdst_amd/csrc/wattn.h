@@ -7,6 +7,8 @@ struct WinGeom {
   int nWh, nWw;  // windows per column / row
   int N;         // tokens per window = ws*ws
   int T;         // relative-position table rows = (2ws-1)^2
+  const float* mask;  // optional explicit additive mask (mask_nw, N, N), else NULL
+  int mask_nw;
 };
 
 // Row (token) index in the (B*H*W) activation of token t of window (wr,wc) of image b.

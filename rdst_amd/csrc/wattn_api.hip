@@ -9,7 +9,8 @@ extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {
 
-int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shift, const char* who) {
+int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shift, const float* mask, int mask_nw,
+              const char* who) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || ws <= 0)
     return rdst_fail(RDST_EINVAL, "%s: non-positive dimension", who);
   if (C % heads) return rdst_fail(RDST_EINVAL, "%s: C=%d not divisible by heads=%d", who, C, heads);
@@ -18,6 +19,8 @@ int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shi
   if ((int64_t)B * H * W >= (1ll << 31)) return rdst_fail(RDST_EINVAL, "%s: more than 2^31 tokens", who);
   g.B = B; g.H = H; g.W = W; g.C = C; g.heads = heads; g.ws = ws; g.shift = shift;
   g.nWh = H / ws; g.nWw = W / ws; g.N = ws * ws; g.T = (2 * ws - 1) * (2 * ws - 1);
+  if (mask && mask_nw <= 0) return rdst_fail(RDST_EINVAL, "%s: mask given with mask_nw=%d", who, mask_nw);
+  g.mask = mask; g.mask_nw = mask ? mask_nw : 1;
   return 0;
 }
 
@@ -43,11 +46,11 @@ dtable_reduce(const float* __restrict__ slab, float* __restrict__ dtable, int nw
 
 }  // namespace
 
-extern "C" int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out,
-                              int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype,
-                              void* stream) {
+extern "C" int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
+                              void* out, int64_t ld_out, int B, int H, int W, int C, int heads, int ws, int shift,
+                              float scale, int dtype, void* stream) {
   WinGeom g;
-  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, "rdst_wattn_fwd")) return rc;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_fwd")) return rc;
   if (!qkv || !table || !out) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: null pointer");
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: bad dtype %d", dtype);
   if (ld_qkv < 3 * C || ld_out < C) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: leading dimension too small");
@@ -62,12 +65,12 @@ extern "C" size_t rdst_wattn_bwd_workspace(int B, int H, int W, int C, int heads
   return nwin * heads * T * sizeof(float);
 }
 
-extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const void* dout, int64_t ld_dout,
-                              void* dqkv, int64_t ld_dqkv, float* dtable, void* workspace, size_t workspace_bytes,
-                              int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype,
-                              void* stream) {
+extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
+                              const void* dout, int64_t ld_dout, void* dqkv, int64_t ld_dqkv, float* dtable,
+                              void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
+                              int shift, float scale, int dtype, void* stream) {
   WinGeom g;
-  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, "rdst_wattn_bwd")) return rc;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_bwd")) return rc;
   if (!qkv || !table || !dout || !dqkv || !dtable || !workspace)
     return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: null pointer");
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: bad dtype %d", dtype);

@@ -50,6 +50,7 @@ wattn_fwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
     for (int e = 0; e < D; ++e) q[e] = to_f32<T>(qrow[e]) * scale;
     const int yi = i / ws, xi = i - yi * ws, ri = reg[i];
+    const float* mrow = g.mask ? g.mask + ((int64_t)(win % g.mask_nw) * N + i) * N : nullptr;
     const int base = (yi + ws - 1) * tw + xi + ws - 1;
     float m = -INFINITY;
     for (int yj = 0, j = 0; yj < ws; ++yj)
@@ -58,7 +59,7 @@ wattn_fwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
         for (int e = 0; e < D; ++e) s = fmaf(q[e], Ks[j * D + e], s);
         s += tab[base - yj * tw - xj];
-        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
+        if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         m = fmaxf(m, s);
       }
     float l = 0.f, acc[D];
@@ -70,7 +71,7 @@ wattn_fwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
         for (int e = 0; e < D; ++e) s = fmaf(q[e], Ks[j * D + e], s);
         s += tab[base - yj * tw - xj];
-        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
+        if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         const float p = expf(s - m);
         l += p;
 #pragma unroll
@@ -135,6 +136,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
     for (int e = 0; e < D; ++e) { q[e] = Qs[i * D + e]; dO[e] = dOs[i * D + e]; }
     const int yi = i / ws, xi = i - yi * ws, ri = reg[i];
+    const float* mrow = g.mask ? g.mask + ((int64_t)(win % g.mask_nw) * N + i) * N : nullptr;
     const int base = (yi + ws - 1) * tw + xi + ws - 1;
     float m = -INFINITY;
     for (int yj = 0, j = 0; yj < ws; ++yj)
@@ -143,7 +145,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
         for (int e = 0; e < D; ++e) s = fmaf(q[e], Ks[j * D + e], s);
         s += tab[base - yj * tw - xj];
-        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
+        if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         m = fmaxf(m, s);
       }
     float l = 0.f, acc[D];
@@ -155,7 +157,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
         for (int e = 0; e < D; ++e) s = fmaf(q[e], Ks[j * D + e], s);
         s += tab[base - yj * tw - xj];
-        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
+        if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         const float p = expf(s - m);
         l += p;
 #pragma unroll
@@ -181,7 +183,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
         }
         const int ti = base - yj * tw - xj;
         s += tab[ti];
-        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
+        if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         const float p = expf(s - ls);
         const float ds = p * (dp - dl);
 #pragma unroll
@@ -199,6 +201,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
 #pragma unroll
     for (int e = 0; e < D; ++e) { k[e] = Ks[j * D + e]; v[e] = Vs[j * D + e]; dk[e] = 0.f; dv[e] = 0.f; }
     const int yj = j / ws, xj = j - yj * ws, rj = reg[j];
+    const float* mcol = g.mask ? g.mask + (int64_t)(win % g.mask_nw) * N * N + j : nullptr;
     const int base = (ws - 1 - yj) * tw + ws - 1 - xj;
     for (int yi = 0, i = 0; yi < ws; ++yi)
       for (int xi = 0; xi < ws; ++xi, ++i) {
@@ -209,7 +212,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
           dp = fmaf(dOs[i * D + e], v[e], dp);
         }
         s += tab[base + yi * tw + xi];
-        if (g.shift > 0 && reg[i] != rj) s += -100.0f;
+        if (mcol) s += mcol[(int64_t)i * N]; else if (g.shift > 0 && reg[i] != rj) s += -100.0f;
         const float p = expf(s - lse[i]);
         const float ds = p * (dp - delta[i]);
 #pragma unroll

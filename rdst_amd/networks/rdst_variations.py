@@ -1,0 +1,370 @@
+"""RDST network family on HIP kernels: DenseSTLayer, RDSTB, RDSTSR, make_RDSTSR.
+
+Counterpart of the reference's ``networks/rdst_variations.py`` (identical, for these classes, to
+``networks/swinIR_variations.py`` which is what its trainer/tester import): ``DenseSTLayer``
+:246-341, ``RDSTB`` :354-445, ``RDSTSR`` :1115-1366, ``make_RDSTSR`` :1369-1457.  Constructor and
+``forward`` signatures, accepted-but-inert arguments, validation errors and parameter names follow
+the reference; ``state_dict()`` keys/shapes are identical (tests/golden/state_dict_*.json).
+
+The forward is new.  Activations stay token-major ("rows", = NHWC) from the head conv to the last
+conv, so every PatchEmbed/PatchUnEmbed transpose of the reference disappears; each op is a fused
+HIP kernel from librdst_hip.so (see include/rdst_hip.h).  ``compute_dtype`` selects fp32 (parity
+mode, default) or bf16 activations (throughput mode; parameters stay fp32).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .common import Conv2d, MeanShift, UpSampler, default_conv
+from .swin_transformer_sr import (BasicLayer, Mlp, PatchEmbed, PatchUnEmbed, SwinTransformerBlock,  # noqa: F401
+                                  WindowAttention, _ln_params, _norm_only, trunc_normal_, window_partition,
+                                  window_reverse)
+
+
+def _dim_modifier(input_dim, growth_rate, norm_layer, pre_norm):
+    """Sequential(LN(in), Linear(in, growth)) if pre_norm else Sequential(Linear, LN(growth))."""
+    if pre_norm:
+        return nn.Sequential(norm_layer(input_dim), nn.Linear(input_dim, growth_rate))
+    return nn.Sequential(nn.Linear(input_dim, growth_rate), norm_layer(growth_rate))
+
+
+def _apply_dim_modifier(seq, x, out_scale=1.0):
+    if isinstance(seq, nn.Identity):
+        return x if out_scale == 1.0 else x * out_scale
+    a, b = seq[0], seq[1]
+    if isinstance(b, nn.Linear):  # (norm, linear): one fused op
+        w, bb = _ln_params(a)
+        return ops.ln_linear(x, w, bb, b.weight, b.bias, out_scale=out_scale)
+    y = ops.ln_linear(x, None, None, a.weight, a.bias)  # (linear, norm)
+    return _norm_only(y, b, out_scale=out_scale)
+
+
+class DenseSTLayer(nn.Module):
+    """x -> cat(x, dense_scale * tail(BasicLayer(head(x)))) along channels."""
+
+    def __init__(self, input_dim, input_resolution, depth=2, num_heads=6, window_size=2,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=30., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 growth_rate=60, dense_scale=1., dim_modify_mode='tail',
+                 pre_norm=False):
+        super().__init__()
+        assert growth_rate % num_heads == 0, 'growth_rate % num_heads should be 0'
+        assert input_dim % num_heads == 0, 'token dim % num_heads should be 0'
+        if dim_modify_mode == 'head':
+            self.head = (_dim_modifier(input_dim, growth_rate, norm_layer, pre_norm)
+                         if input_dim != growth_rate else nn.Identity())
+            hidden_dim = growth_rate
+            self.tail = nn.Identity()
+        elif dim_modify_mode == 'tail':
+            self.head = nn.Identity()
+            hidden_dim = input_dim
+            self.tail = (_dim_modifier(hidden_dim, growth_rate, norm_layer, pre_norm)
+                         if hidden_dim != growth_rate else nn.Identity())
+        else:
+            raise ValueError(f"dim_modify_mode {dim_modify_mode!r} (head or tail)")
+        # the reference's own default drop_path=30. can only ever be used as "no drop path"
+        # (RDSTB always passes its own value, 0. on every shipped path)
+        self.body = BasicLayer(hidden_dim, input_resolution, depth, num_heads, window_size, mlp_ratio, qkv_bias,
+                               qk_scale, drop, attn_drop, drop_path, norm_layer, downsample, use_checkpoint)
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.input_resolution = input_resolution
+        self.dense_scale = dense_scale
+        self.growth_rate = hidden_dim
+        self.depth = depth
+        self.pre_norm = pre_norm
+
+    def new_features(self, x, x_size):
+        """dense_scale * tail(body(head(x))): the channels this layer appends."""
+        y = _apply_dim_modifier(self.head, x)
+        y = self.body(y, x_size)
+        return _apply_dim_modifier(self.tail, y, out_scale=self.dense_scale)
+
+    def forward(self, x, x_size):
+        return torch.cat((x, self.new_features(x, x_size)), 2)
+
+
+def _res_connection(resi_connection, cin, cout):
+    if resi_connection == '1conv':
+        return Conv2d(cin, cout, 3, 1, 1)
+    if resi_connection == '3conv':
+        return nn.Sequential(Conv2d(cin, cin // 4, 3, 1, 1),
+                             nn.LeakyReLU(negative_slope=0.2, inplace=True),
+                             Conv2d(cin // 4, cin // 4, 1, 1, 0),
+                             nn.LeakyReLU(negative_slope=0.2, inplace=True),
+                             Conv2d(cin // 4, cout, 3, 1, 1))
+    return None
+
+
+def _apply_res_connection(conv, x, residual=None, out_scale=1.0):
+    """conv(x) * out_scale + residual on rows; the LeakyReLUs of '3conv' ride on the next conv's load."""
+    if isinstance(conv, Conv2d):
+        return conv.forward_rows(x, residual=residual, out_scale=out_scale)
+    y = conv[0].forward_rows(x)
+    y = conv[2].forward_rows(y, in_act=ops.ACT_LEAKY02)
+    return conv[4].forward_rows(y, in_act=ops.ACT_LEAKY02, residual=residual, out_scale=out_scale)
+
+
+class RDSTB(nn.Module):
+    """Residual Dense Swin Transformer Block: num_blocks DenseSTLayers, 3x3 fusion conv, residual."""
+
+    def __init__(self, input_dim, input_resolution, layer_depth, num_heads=6, window_size=2,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 img_size=224, patch_size=4, resi_connection='1conv',
+                 growth_rate=0, dense_scale=1., dim_modify_mode='tail',
+                 num_blocks=3, residual_scale=1.,
+                 pre_norm=False):
+        super().__init__()
+        self.input_dim = input_dim
+        self.input_resolution = input_resolution
+        self.residual_scale = residual_scale
+        idim = input_dim
+        self.body = nn.ModuleList([])
+        for _ in range(int(num_blocks)):
+            self.body.append(DenseSTLayer(
+                input_dim=idim, input_resolution=input_resolution, depth=layer_depth, num_heads=num_heads,
+                window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop,
+                attn_drop=attn_drop, drop_path=drop_path, norm_layer=norm_layer, downsample=downsample,
+                use_checkpoint=use_checkpoint, growth_rate=growth_rate, dense_scale=dense_scale,
+                dim_modify_mode=dim_modify_mode, pre_norm=pre_norm))
+            idim += growth_rate
+        conv = _res_connection(resi_connection, idim, input_dim)
+        if conv is not None:
+            self.conv = conv
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=0, embed_dim=input_dim,
+                                      norm_layer=None)
+        self.patch_unembed = PatchUnEmbed(img_size=img_size, patch_size=patch_size, in_chans=0, embed_dim=idim,
+                                          norm_layer=None)
+
+    def forward(self, x, x_size):
+        B, L, C = x.shape
+        H, W = x_size
+        y = x
+        for m in self.body:
+            y = m(y, x_size)
+        out = _apply_res_connection(self.conv, y.view(B, H, W, y.shape[-1]), residual=x.view(B, H, W, C),
+                                    out_scale=self.residual_scale)
+        return out.view(B, L, C)
+
+
+class RDSTSR(nn.Module):
+    """MeanShift + head conv + n x RDSTB + LayerNorm + conv + global residual + pixel-shuffle tail."""
+
+    def __init__(self, img_size=48, patch_size=1, in_chans=1, sr_scale=2, embed_dim=60,
+                 dense_layer_depths=[2, 2, 2, 2], num_heads=[6, 6, 6, 6],
+                 window_size=[4, 4, 4, 4], rdb_depths=[3, 3, 3, 3],
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop=0., drop_path_rate=0.,
+                 norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, resi_connection='1conv',
+                 growth_rate=30, dense_scale=1., dim_modify_mode='tail',
+                 rdb_residual_scale=1.,
+                 global_res_scale=1.,
+                 mean=None, std=None,
+                 act_in_conv='leaky_relu', bn_in_conv=None,
+                 scale_free=False,
+                 scale_embedding=False,
+                 pre_norm=False,
+                 feature_last_operation=False):
+        super().__init__()
+        self.input_resolution = img_size
+        self.patch_size = patch_size
+        self.input_channel = in_chans
+        self.num_blocks = len(rdb_depths)
+        assert len(rdb_depths) == len(window_size) == len(num_heads) == len(dense_layer_depths)
+        self.n_feats = embed_dim
+        self.patch_norm = patch_norm
+        self.ape = ape
+        self.use_checkpoint = use_checkpoint      # accepted, inert (as in the reference)
+        self.drop_path_rate = drop_path_rate      # accepted, inert: never forwarded to the blocks
+        self.drop_rate = drop_rate
+        self.resi_connection = resi_connection
+        self.global_res_scale = global_res_scale
+        self.window_size = window_size
+        self.mlp_ratio = mlp_ratio
+        self.qkv_bias = qkv_bias
+        self.qk_scale = qk_scale
+        self.norm_layer = norm_layer
+        self.num_heads = num_heads
+        self.dense_layer_depths = dense_layer_depths
+        self.dense_scale = dense_scale
+        self.growth_rate = growth_rate
+        self.dim_modify_mode = dim_modify_mode
+        self.rdb_depths = rdb_depths
+        self.rdb_residual_scale = rdb_residual_scale
+
+        if act_in_conv == 'relu':
+            self.act_in_conv = nn.ReLU(True)
+        elif act_in_conv == 'leaky_relu':
+            self.act_in_conv = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        elif act_in_conv == 'prelu':
+            self.act_in_conv = nn.PReLU()
+        else:
+            raise ValueError('Invalid activation {}, should be one of [relu, leaky_relu, prelu]'.format(act_in_conv))
+        self.bn_in_conv = bn_in_conv
+        self.sr_scale = sr_scale
+        self.scale_free = scale_free
+        self.scale_embedding = scale_embedding
+        if scale_embedding:
+            self.scale_embedding = nn.Identity()
+            self.scale_embed_layer = nn.Linear(1, 1)
+        if scale_free:
+            raise NotImplementedError("rdst_amd RDSTSR: scale_free=True (MetaUpSampler) is outside the hot path; "
+                                      "every shipped config has scale_free = False")
+
+        if mean is None:
+            mean = [0. for _ in range(self.input_channel)]
+        if std is None:
+            std = [1. for _ in range(self.input_channel)]
+        if len(mean) != len(std) or len(mean) != self.input_channel:
+            raise ValueError('Dimension of mean {} / std {} should fit input channels {}'.format(
+                len(mean), len(std), self.input_channel))
+        self.mean = mean
+        self.std = std
+        self.add_mean = MeanShift(mean, std, 'add')
+        self.sub_mean = MeanShift(mean, std, 'sub')
+
+        self.head = default_conv(in_chans, embed_dim, 3)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=embed_dim,
+                                      embed_dim=embed_dim, norm_layer=norm_layer if self.patch_norm else None)
+        num_patches = self.patch_embed.num_patches
+        patches_resolution = self.patch_embed.patches_resolution
+        self.patches_resolution = patches_resolution
+        self.patch_unembed = PatchUnEmbed(img_size=img_size, patch_size=patch_size, in_chans=embed_dim,
+                                          embed_dim=embed_dim, norm_layer=norm_layer if self.patch_norm else None)
+        if self.ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
+            trunc_normal_(self.absolute_pos_embed, std=.02)
+        if drop_rate and drop_rate > 0.:
+            raise NotImplementedError("rdst_amd RDSTSR: drop_rate > 0 is not on the hot path")
+        self.pos_drop = nn.Dropout(p=drop_rate)
+
+        self.body = nn.ModuleList()
+        for i_block in range(self.num_blocks):
+            self.body.append(RDSTB(
+                input_dim=embed_dim, input_resolution=(patches_resolution[0], patches_resolution[1]),
+                layer_depth=self.dense_layer_depths[i_block], num_heads=self.num_heads[i_block],
+                window_size=self.window_size[i_block], mlp_ratio=self.mlp_ratio, qkv_bias=self.qkv_bias,
+                qk_scale=self.qk_scale, drop=self.drop_rate, attn_drop=attn_drop, norm_layer=norm_layer,
+                img_size=self.input_resolution, patch_size=self.patch_size, resi_connection=self.resi_connection,
+                growth_rate=self.growth_rate, dense_scale=self.dense_scale, dim_modify_mode=self.dim_modify_mode,
+                num_blocks=self.rdb_depths[i_block], residual_scale=self.rdb_residual_scale, pre_norm=pre_norm))
+        self.norm = norm_layer(self.n_feats)
+
+        self.feature_last_operation = feature_last_operation
+        cab = _res_connection(resi_connection, embed_dim, embed_dim)
+        if cab is not None:
+            self.conv_after_body = cab
+
+        m_tail = []
+        if self.sr_scale > 1:
+            m_tail.append(UpSampler(default_conv, self.sr_scale, self.n_feats, act=None, bn=self.bn_in_conv))
+        m_tail.append(default_conv(self.n_feats, self.input_channel, 3))
+        self.tail = nn.Sequential(*m_tail)
+
+        self.compute_dtype = torch.float32
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 = parity mode (default); torch.bfloat16 = throughput mode (bf16 activations,
+        fp32 accumulation, fp32 parameters and gradients)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+    def forward_features_rows(self, feat):
+        """feat: rows (B,H,W,E) after the head conv -> rows (B,H,W,E): LN(body(patch_norm(feat))) * global_res_scale
+        (+ feat when there is no conv_after_body step to add it)."""
+        B, H, W, E = feat.shape
+        x_size = (H, W)
+        t = feat.view(B, H * W, E)
+        if self.patch_embed.norm is not None:
+            t = _norm_only(t, self.patch_embed.norm)
+        if self.ape:
+            t = t + self.absolute_pos_embed.to(t.dtype)
+        for blk in self.body:
+            t = blk(t, x_size)
+        return t
+
+    def forward_features(self, x):
+        """NCHW feature map -> NCHW (API parity with the reference's forward_features)."""
+        rows = ops.nchw_to_rows(x, self.compute_dtype)
+        t = self.forward_features_rows(rows)
+        B, H, W, E = rows.shape
+        return ops.rows_to_nchw(_norm_only(t, self.norm).view(B, H, W, E))
+
+    def forward(self, x, sr_scale=None):
+        rows = ops.nchw_to_rows(x, self.compute_dtype)          # (B,H,W,nc)
+        rows = self.sub_mean.forward_rows(rows)
+        feat = self.head.forward_rows(rows)                      # (B,H,W,E)
+        B, H, W, E = feat.shape
+        t = self.forward_features_rows(feat)
+        if self.feature_last_operation:
+            t = _norm_only(t, self.norm, out_scale=self.global_res_scale)
+            res = _apply_res_connection(self.conv_after_body, t.view(B, H, W, E), residual=feat)
+        else:
+            res = _norm_only(t, self.norm, out_scale=self.global_res_scale, residual=feat.view(B, H * W, E))
+            res = res.view(B, H, W, E)
+        y = res
+        for m in self.tail:
+            y = m.forward_rows(y)
+        y = self.add_mean.forward_rows(y)
+        return ops.rows_to_nchw(y)
+
+    def extra_repr(self):
+        return ''
+
+    def flops(self):
+        return None
+
+
+def make_RDSTSR(paras, mean=None, std=None):
+    """Build the network from a flat parameter namespace (the reference's ParametersLoader)."""
+    sr_scale = int(paras.sr_scale)
+    norm_layer = nn.LayerNorm if paras.rdst_layer_norm else nn.Identity
+    kw = dict(
+        img_size=paras.patch_size, patch_size=paras.swin_patch_size, in_chans=paras.input_channel,
+        sr_scale=sr_scale, embed_dim=paras.rdst_embed_dim,
+        dense_layer_depths=paras.rdst_dense_layer_depths, num_heads=paras.rdst_num_heads,
+        window_size=paras.rdst_window_size, rdb_depths=paras.rdst_rdb_depths,
+        mlp_ratio=paras.swin_hidden_ratio, qkv_bias=paras.swin_qkv_bias, qk_scale=paras.swin_qk_scale,
+        drop_rate=paras.swin_drop_rate, attn_drop=paras.swin_attn_drop_rate,
+        drop_path_rate=paras.swin_drop_path_rate,
+        norm_layer=norm_layer, ape=paras.rdst_ape, patch_norm=paras.rdst_patch_norm,
+        use_checkpoint=paras.rdst_use_checkpoint, resi_connection=paras.rdst_res_connection,
+        growth_rate=paras.rdst_growth_rate, dense_scale=paras.rdst_dense_scale,
+        dim_modify_mode=paras.rdst_dim_modify_mode,
+        rdb_residual_scale=paras.rdst_rdb_residual_scale, global_res_scale=paras.rdst_global_res_scale,
+        mean=mean, std=std,
+        act_in_conv=paras.rdst_act_in_conv, bn_in_conv=paras.rdst_bn_in_conv,
+        scale_free=paras.scale_free, pre_norm=paras.rdst_pre_norm)
+    # attributes the reference reads unconditionally (rdst_variations.py:1380-1382)
+    global_bottleneck = paras.rdst_global_bottleneck
+    _ratio = paras.rdst_global_bottleneck_ratio
+    feature_last_operation = paras.rdst_feature_last_operation
+    if not global_bottleneck:
+        return RDSTSR(feature_last_operation=feature_last_operation, **kw)
+    raise NotImplementedError(
+        "rdst_amd make_RDSTSR: rdst_global_bottleneck=True selects RDSTSR_N, which is a 'next' row of the "
+        "hot-path scope (SURVEY.md §8f N4); the shipped config uses rdst_global_bottleneck = False")

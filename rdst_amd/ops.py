@@ -3,8 +3,14 @@
 Every function here takes CUDA(=HIP) tensors, enqueues hand-written gfx950 kernels from
 librdst_hip.so on torch's current stream, and raises if the library is missing or a tensor lives
 on the CPU.  torch is used for device memory, streams and autograd bookkeeping only.
+
+Activations are "rows": (..., C) tensors whose last dim is contiguous and whose leading dims collapse
+to one row stride (so a slice ``buf[..., :C]`` of a wider buffer is passed without a copy).
+Parameters are always fp32; activations are fp32 (parity mode) or bf16 (throughput mode).
 """
 from __future__ import annotations
+
+from typing import Optional
 
 import torch
 
@@ -20,7 +26,7 @@ def _dtype_code(t: torch.Tensor) -> int:
     raise TypeError(f"rdst_amd: unsupported activation dtype {t.dtype} (float32 or bfloat16)")
 
 
-def _need_gpu(*ts: torch.Tensor) -> None:
+def _need_gpu(*ts: Optional[torch.Tensor]) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
             raise RuntimeError(
@@ -35,29 +41,45 @@ def _stream() -> int:
 def _rows(t: torch.Tensor) -> tuple[torch.Tensor, int]:
     """View `t` (..., C) as rows with one leading dimension `ld` (elements); copy only if the
     layout cannot be expressed that way."""
-    if t.stride(-1) != 1:
-        t = t.contiguous()
     if t.dim() == 1:
-        return t, t.shape[0]
-    ld = t.stride(-2)
-    ok = ld >= t.shape[-1]
-    exp = ld
-    for d in range(t.dim() - 2, -1, -1):
-        if t.shape[d] != 1 and t.stride(d) != exp:
-            ok = False
-            break
-        exp *= t.shape[d]
-    if not ok:
+        t = t.unsqueeze(0)
+    C = t.shape[-1]
+    if C != 1 and t.stride(-1) != 1:
         t = t.contiguous()
-        ld = t.shape[-1]
+    ld = None
+    exp = 0
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] == 1:
+            continue
+        if ld is None:
+            ld = t.stride(d)
+            exp = ld * t.shape[d]
+        elif t.stride(d) != exp:
+            return t.contiguous(), C
+        else:
+            exp *= t.shape[d]
+    if ld is None:
+        ld = C
+    if ld < C:
+        return t.contiguous(), C
     return t, ld
 
 
-def _f32p(t):
+def _param(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if t is None:
         return None
-    assert t.dtype == torch.float32 and t.is_contiguous()
-    return t.data_ptr()
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -65,39 +87,210 @@ def _f32p(t):
 # ------------------------------------------------------------------------------------------------
 class _WindowAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, table, H, W, heads, ws, shift, scale):
-        _need_gpu(qkv, table)
+    def forward(ctx, qkv, table, mask, H, W, heads, ws, shift, scale):
+        _need_gpu(qkv, table, mask)
         lib = _lib.load()
-        B = qkv.numel() // (H * W * qkv.shape[-1])
         C = qkv.shape[-1] // 3
+        B = qkv.numel() // (H * W * 3 * C)
         qkv_r, ld = _rows(qkv)
-        tab = table.detach().float().contiguous()
+        tab = _param(table)
+        msk = _param(mask)
+        nw = 0 if msk is None else msk.shape[0]
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
-        _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), out.data_ptr(), C, B, H, W, C, heads,
-                                      ws, shift, float(scale), _dtype_code(qkv), _stream()), "rdst_wattn_fwd")
-        ctx.save_for_backward(qkv_r, tab)
-        ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld)
+        _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H, W,
+                                      C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()), "rdst_wattn_fwd")
+        ctx.save_for_backward(qkv_r, tab, msk)
+        ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, tab = ctx.saved_tensors
-        B, H, W, C, heads, ws, shift, scale, ld = ctx.geom
+        qkv, tab, msk = ctx.saved_tensors
+        B, H, W, C, heads, ws, shift, scale, ld, nw = ctx.geom
         lib = _lib.load()
         dout_r, ldd = _rows(dout)
         dqkv = torch.empty(qkv.shape[:-1] + (3 * C,), dtype=qkv.dtype, device=qkv.device)
         dtable = torch.empty_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
-        wsp = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=qkv.device)
-        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), dout_r.data_ptr(), ldd, dqkv.data_ptr(),
-                                      3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C, heads, ws, shift,
-                                      scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
-        return dqkv, dtable, None, None, None, None, None, None
+        wsp = _workspace(nbytes, qkv.device)
+        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
+                                      dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
+                                      heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
+        return dqkv, dtable, None, None, None, None, None, None, None
 
 
 def window_attention(qkv: torch.Tensor, table: torch.Tensor, H: int, W: int, heads: int, ws: int, shift: int,
-                     scale: float) -> torch.Tensor:
+                     scale: float, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused roll + window partition + (q*scale)k^T + relative-position bias + shift mask + softmax
     + @v + window reverse + un-roll on token-major qkv (..., 3C) -> (..., C).
-    Replaces networks/swin_transformer_sr.py:244-267 with :117-138 inside (minus the Linears)."""
-    return _WindowAttention.apply(qkv, table, H, W, heads, ws, shift, scale)
+    Replaces networks/swin_transformer_sr.py:244-267 with :117-138 inside (minus the Linears).
+    ``mask`` (nW,N,N) overrides the analytic shifted-window mask (standalone WindowAttention API)."""
+    return _WindowAttention.apply(qkv, table, mask, H, W, heads, ws, shift, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# K3: (LayerNorm | activation ->) Linear (-> *scale + residual)
+# ------------------------------------------------------------------------------------------------
+class _LnLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, weight, bias, residual, in_act, out_scale):
+        _need_gpu(x, ln_w, ln_b, weight, bias, residual)
+        lib = _lib.load()
+        K = x.shape[-1]
+        N = K if weight is None else weight.shape[0]
+        M = x.numel() // K
+        x_r, ldx = _rows(x)
+        lw, lb, w, b = _param(ln_w), _param(ln_b), _param(weight), _param(bias)
+        y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        r_r, ldr = (None, 0)
+        if residual is not None:
+            if residual.dtype != x.dtype:
+                raise TypeError("rdst_amd.ln_linear: residual dtype differs from the activation dtype")
+            r_r, ldr = _rows(residual)
+        stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if lw is not None else None
+        _lib.check(lib.rdst_ln_linear_fwd(x_r.data_ptr(), ldx, _ptr(lw), _ptr(lb), int(in_act), _ptr(w), _ptr(b),
+                                          _ptr(r_r), ldr, y.data_ptr(), N, _ptr(stats), M, K, N, float(out_scale),
+                                          _dtype_code(x), _stream()), "rdst_ln_linear_fwd")
+        ctx.save_for_backward(x_r, lw, lb, w, stats)
+        ctx.meta = (M, K, N, ldx, int(in_act), float(out_scale), bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, lw, lb, w, stats = ctx.saved_tensors
+        M, K, N, ldx, in_act, out_scale, has_bias, has_res = ctx.meta
+        lib = _lib.load()
+        dy_r, lddy = _rows(dy)
+        need = ctx.needs_input_grad
+        dev = x.device
+        dx = torch.empty(x.shape[:-1] + (K,), dtype=x.dtype, device=dev) if need[0] else None
+        dlw = torch.empty_like(lw) if (lw is not None and need[1]) else None
+        dlb = torch.empty_like(lb) if (lb is not None and need[2]) else None
+        dw = torch.empty_like(w) if (w is not None and need[3]) else None
+        db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[4]) else None
+        nbytes = lib.rdst_ln_linear_bwd_workspace(M, K, N)
+        wsp = _workspace(nbytes, dev)
+        _lib.check(lib.rdst_ln_linear_bwd(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
+                                          dy_r.data_ptr(), lddy, _ptr(dx), K, 0, _ptr(dw), _ptr(db), _ptr(dlw),
+                                          _ptr(dlb), wsp.data_ptr(), nbytes, M, K, N, out_scale, _dtype_code(x),
+                                          _stream()), "rdst_ln_linear_bwd")
+        dres = dy if (has_res and need[5]) else None
+        return dx, dlw, dlb, dw, db, dres, None, None
+
+
+def ln_linear(x: torch.Tensor, ln_w: Optional[torch.Tensor], ln_b: Optional[torch.Tensor],
+              weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], *, in_act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None, out_scale: float = 1.0) -> torch.Tensor:
+    """y = (f(x) @ weight^T + bias) * out_scale + residual, f = LayerNorm (ln_w given) or the
+    activation ``in_act`` or identity; weight None = LayerNorm only.  One fused HIP op replacing the
+    reference's LayerNorm/Linear/GELU/add sequences (see include/rdst_hip.h, K3)."""
+    return _LnLinear.apply(x, ln_w, ln_b, weight, bias, residual, in_act, out_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# K4/K5/K6: conv on rows
+# ------------------------------------------------------------------------------------------------
+class _ConvRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, in_act, out_scale, shuffle):
+        _need_gpu(x, weight, bias, residual)
+        lib = _lib.load()
+        if x.dim() != 4:
+            raise ValueError("rdst_amd.conv_rows: x must be (B, H, W, Cin) token-major")
+        B, H, W, Cin = x.shape
+        Cout, cin_w, k, k2 = weight.shape
+        if cin_w != Cin or k != k2:
+            raise ValueError(f"rdst_amd.conv_rows: weight {tuple(weight.shape)} does not fit Cin={Cin}")
+        r = int(shuffle)
+        x_r, ldx = _rows(x)
+        w, b = _param(weight), _param(bias)
+        cy = Cout // (r * r)
+        y = torch.empty((B, H * r, W * r, cy), dtype=x.dtype, device=x.device)
+        r_r, ldr = (None, 0)
+        if residual is not None:
+            if residual.dtype != x.dtype or tuple(residual.shape) != tuple(y.shape):
+                raise ValueError("rdst_amd.conv_rows: residual must match the output shape/dtype")
+            r_r, ldr = _rows(residual)
+        _lib.check(lib.rdst_conv_fwd(x_r.data_ptr(), ldx, int(in_act), w.data_ptr(), _ptr(b), _ptr(r_r), ldr,
+                                     y.data_ptr(), cy, B, H, W, Cin, Cout, k, float(out_scale), r, _dtype_code(x),
+                                     _stream()), "rdst_conv_fwd")
+        ctx.save_for_backward(x_r, w)
+        ctx.meta = (B, H, W, Cin, Cout, k, ldx, int(in_act), float(out_scale), r, bias is not None,
+                    residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, Cin, Cout, k, ldx, in_act, out_scale, r, has_bias, has_res = ctx.meta
+        lib = _lib.load()
+        dy_r, lddy = _rows(dy)
+        need = ctx.needs_input_grad
+        dev = x.device
+        dx = torch.empty((B, H, W, Cin), dtype=x.dtype, device=dev) if need[0] else None
+        dw = torch.empty_like(w) if need[1] else None
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if (has_bias and need[2]) else None
+        nbytes = lib.rdst_conv_bwd_workspace(B, H, W, Cin, Cout, k)
+        wsp = _workspace(nbytes, dev)
+        _lib.check(lib.rdst_conv_bwd(x.data_ptr(), ldx, in_act, w.data_ptr(), dy_r.data_ptr(), lddy, _ptr(dx), Cin, 0,
+                                     _ptr(dw), _ptr(db), wsp.data_ptr(), nbytes, B, H, W, Cin, Cout, k, out_scale, r,
+                                     _dtype_code(x), _stream()), "rdst_conv_bwd")
+        dres = dy if (has_res and need[3]) else None
+        return dx, dw, db, dres, None, None, None
+
+
+def conv_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *, in_act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle: int = 1) -> torch.Tensor:
+    """k x k conv (k = 1, 3; zero pad k//2) on token-major x (B,H,W,Cin) with nn.Conv2d weights
+    (Cout,Cin,k,k): y = (conv(in_act(x)) + bias) * out_scale + residual, PixelShuffle(shuffle) folded
+    into the store -> (B, H*r, W*r, Cout/r^2).  See include/rdst_hip.h, K4/K5/K6."""
+    return _ConvRows.apply(x, weight, bias, residual, in_act, out_scale, shuffle)
+
+
+# ------------------------------------------------------------------------------------------------
+# NCHW boundary of the module
+# ------------------------------------------------------------------------------------------------
+class _NchwToRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _need_gpu(x)
+        lib = _lib.load()
+        B, C, H, W = x.shape
+        xs = x.detach().float().contiguous()
+        rows = torch.empty((B, H, W, C), dtype=dtype, device=x.device)
+        _lib.check(lib.rdst_nchw_to_rows(xs.data_ptr(), rows.data_ptr(), C, B, C, H, W, _dtype_code(rows), _stream()),
+                   "rdst_nchw_to_rows")
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        return _RowsToNchw.apply(drows), None
+
+
+class _RowsToNchw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows):
+        _need_gpu(rows)
+        lib = _lib.load()
+        B, H, W, C = rows.shape
+        r, ld = _rows(rows)
+        ctx.dtype = rows.dtype
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=rows.device)
+        _lib.check(lib.rdst_rows_to_nchw(r.data_ptr(), ld, out.data_ptr(), B, C, H, W, _dtype_code(rows), _stream()),
+                   "rdst_rows_to_nchw")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return _NchwToRows.apply(dout, ctx.dtype)
+
+
+def nchw_to_rows(x: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """fp32 NCHW image -> token-major rows (B,H,W,C) of `dtype` (PatchEmbed's flatten+transpose,
+    networks/swin_transformer_sr.py:515-516, done once at the module boundary)."""
+    return _NchwToRows.apply(x, dtype)
+
+
+def rows_to_nchw(rows: torch.Tensor) -> torch.Tensor:
+    """token-major rows (B,H,W,C) -> fp32 NCHW (PatchUnEmbed, networks/swin_transformer_sr.py:552-555)."""
+    return _RowsToNchw.apply(rows)

@@ -1,0 +1,147 @@
+"""K3/K4/K5 parity: fused LayerNorm/Linear and conv ops (through the C ABI) vs plain torch fp32 on CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rdst_oracle as O
+from util import rand
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+def _gpu(t, dtype=None):
+    t = t.to(DEV)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.requires_grad_(True)
+
+
+LIN = [  # M, K, N, ln, act, residual, scale
+    (256, 60, 180, True, 0, False, 1.0),     # norm1 + qkv
+    (256, 60, 60, False, 0, True, 1.0),      # proj + shortcut
+    (200, 90, 180, True, 0, False, 1.0),     # norm2 + fc1 (M not a tile multiple)
+    (256, 180, 90, False, 1, True, 1.0),     # GELU + fc2 + residual
+    (192, 120, 30, True, 0, False, 0.5),     # dense tail, dense_scale
+    (130, 48, 48, True, 0, True, 0.9),       # LayerNorm only (no weight), scale + residual
+    (64, 33, 17, False, 2, False, 1.0),      # odd sizes, LeakyReLU input
+]
+
+
+@pytest.mark.parametrize("M,K,N,ln,act,res,scale", LIN)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ln_linear(M, K, N, ln, act, res, scale, dtype):
+    from rdst_amd import ops
+    ln_only = ln and K == N and res and scale == 0.9
+    x = rand((2, M // 2, K), 1)
+    lw = 1 + 0.1 * rand((K,), 2) if ln else None
+    lb = 0.1 * rand((K,), 3) if ln else None
+    w = None if ln_only else rand((N, K), 4, K ** -0.5)
+    b = None if ln_only else 0.1 * rand((N,), 5)
+    r = rand((2, M // 2, N), 6) if res else None
+    gy = rand((2, M // 2, N), 7)
+    if dtype == torch.bfloat16:  # identical (bf16-representable) inputs on both sides
+        x, gy = x.bfloat16().float(), gy.bfloat16().float()
+        r = r.bfloat16().float() if res else None
+
+    xr = _leaf(x)
+    pr = [(_leaf(t) if t is not None else None) for t in (lw, lb, w, b, r)]
+    h = xr
+    if ln:
+        h = F.layer_norm(h, (K,), pr[0], pr[1], 1e-5)
+    elif act == 1:
+        h = O.gelu(h)
+    elif act == 2:
+        h = F.leaky_relu(h, 0.2)
+    if pr[2] is not None:
+        h = F.linear(h, pr[2], pr[3])
+    yr = h * scale + (pr[4] if res else 0)
+    yr.backward(gy)
+
+    xg = _gpu(x, dtype)
+    pg = [(_gpu(t) if t is not None else None) for t in (lw, lb, w, b)]
+    rg = _gpu(r, dtype) if res else None
+    yg = ops.ln_linear(xg, pg[0], pg[1], pg[2], pg[3], in_act=act, residual=rg, out_scale=scale)
+    yg.backward(gy.to(DEV).to(dtype))
+    torch.cuda.synchronize()
+
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    assert (yg.float().cpu() - yr).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+    gtol = 1e-4 if dtype == torch.float32 else 2e-2
+
+    def rel(a, b_):
+        return (a.float().cpu() - b_).norm().item() / max(b_.norm().item(), 1e-12)
+    assert rel(xg.grad, xr.grad) <= gtol
+    for a, b_ in zip(pg, pr[:4]):
+        if a is not None:
+            assert rel(a.grad, b_.grad) <= gtol
+    if res:
+        assert rel(rg.grad, pr[4].grad) <= gtol
+
+
+CONV = [  # B, H, W, Cin, Cout, k, act, residual, scale, shuffle
+    (2, 8, 8, 150, 60, 3, 0, True, 0.7, 1),    # RDB fusion conv + residual_scale + shortcut
+    (1, 8, 12, 60, 240, 3, 0, False, 1.0, 2),  # upsampler conv + PixelShuffle(2), non-square
+    (2, 9, 7, 1, 60, 3, 0, False, 1.0, 1),     # head conv, odd sizes
+    (1, 16, 16, 60, 1, 3, 0, False, 1.0, 1),   # last conv
+    (2, 6, 6, 37, 12, 1, 2, False, 1.0, 1),    # 1x1 conv reading through LeakyReLU ('3conv')
+    (1, 6, 6, 48, 108, 3, 0, False, 1.0, 3),   # x3 upsampler
+    (2, 5, 5, 3, 3, 1, 0, False, 1.0, 1),      # MeanShift
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,act,res,scale,r", CONV)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_rows(B, H, W, Cin, Cout, k, act, res, scale, r, dtype):
+    from rdst_amd import ops
+    x = rand((B, H, W, Cin), 1)
+    w = rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5)
+    b = 0.1 * rand((Cout,), 3)
+    cy = Cout // (r * r)
+    rr = rand((B, H * r, W * r, cy), 4) if res else None
+    gy = rand((B, H * r, W * r, cy), 5)
+    if dtype == torch.bfloat16:
+        x, gy = x.bfloat16().float(), gy.bfloat16().float()
+        rr = rr.bfloat16().float() if res else None
+
+    xr, wr, br = _leaf(x), _leaf(w), _leaf(b)
+    rres = _leaf(rr) if res else None
+    h = xr.permute(0, 3, 1, 2)
+    if act == 2:
+        h = F.leaky_relu(h, 0.2)
+    h = F.conv2d(h, wr, br, padding=k // 2)
+    if r > 1:
+        h = F.pixel_shuffle(h, r)
+    yr = h.permute(0, 2, 3, 1) * scale + (rres if res else 0)
+    yr.backward(gy)
+
+    xg, wg, bg = _gpu(x, dtype), _gpu(w), _gpu(b)
+    rg = _gpu(rr, dtype) if res else None
+    yg = ops.conv_rows(xg, wg, bg, in_act=act, residual=rg, out_scale=scale, shuffle=r)
+    yg.backward(gy.to(DEV).to(dtype))
+    torch.cuda.synchronize()
+
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    assert (yg.float().cpu() - yr).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+    gtol = 1e-4 if dtype == torch.float32 else 2e-2
+
+    def rel(a, b_):
+        return (a.float().cpu() - b_).norm().item() / max(b_.norm().item(), 1e-12)
+    assert rel(xg.grad, xr.grad) <= gtol
+    assert rel(wg.grad, wr.grad) <= gtol
+    assert rel(bg.grad, br.grad) <= gtol
+    if res:
+        assert rel(rg.grad, rres.grad) <= gtol
+
+
+def test_layout_roundtrip():
+    from rdst_amd import ops
+    x = rand((2, 3, 5, 7), 9).to(DEV)
+    rows = ops.nchw_to_rows(x, torch.float32)
+    assert torch.equal(rows, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.rows_to_nchw(rows), x)
+    assert torch.equal(ops.rows_to_nchw(ops.nchw_to_rows(x, torch.bfloat16)), x.bfloat16().float())
