@@ -85,6 +85,39 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # K1 / K2: fused window attention
 # ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Collects (start, end, algorithmic_bytes) HIP-event pairs around every K1 / K2 launch, recorded
+    on the stream the kernel is launched on (torch's current stream).  bench.py uses it for the
+    `roofline` object; it is None (no events, no overhead) everywhere else."""
+
+    def __init__(self):
+        self.fwd, self.bwd = [], []
+
+    @staticmethod
+    def _ms(pairs):
+        return [a.elapsed_time(b) for a, b, _ in pairs]
+
+    def summary(self, which="fwd"):
+        pairs = getattr(self, which)
+        ms = self._ms(pairs)
+        nbytes = sum(n for _, _, n in pairs)
+        return {"launches": len(pairs), "total_ms": sum(ms), "bytes": nbytes}
+
+
+_kernel_timer: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    global _kernel_timer
+    _kernel_timer = t
+
+
+def _event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
 class _WindowAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, table, mask, H, W, heads, ws, shift, scale):
@@ -97,8 +130,12 @@ class _WindowAttention(torch.autograd.Function):
         msk = _param(mask)
         nw = 0 if msk is None else msk.shape[0]
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
+        kt = _kernel_timer
+        e0 = _event() if kt is not None else None
         _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H, W,
                                       C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()), "rdst_wattn_fwd")
+        if kt is not None:  # algorithmic bytes of K1: read qkv (3C) + write out (C) per token
+            kt.fwd.append((e0, _event(), B * H * W * 4 * C * qkv.element_size()))
         ctx.save_for_backward(qkv_r, tab, msk)
         ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw)
         return out
@@ -113,9 +150,13 @@ class _WindowAttention(torch.autograd.Function):
         dtable = torch.empty_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, qkv.device)
+        kt = _kernel_timer
+        e0 = _event() if kt is not None else None
         _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
                                       dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
                                       heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
+        if kt is not None:  # K2: read qkv (3C) + dout (C), write dqkv (3C) per token
+            kt.bwd.append((e0, _event(), B * H * W * 7 * C * qkv.element_size()))
         return dqkv, dtable, None, None, None, None, None, None, None
 
 
