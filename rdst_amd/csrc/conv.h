@@ -34,9 +34,14 @@ struct ConvGeom {
 template <typename T>
 int conv_fwd_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr,
                   T* Y, int64_t ldy, const ConvGeom& g, float s, hipStream_t st);
+// The two backward hooks take dY as PLAIN rows (B*H*W, Cout): plain_dy() un-shuffles a pixel-shuffled
+// dY into scratch once (or returns dY itself when r == 1).
 template <typename T>
-int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int64_t lddy, T* dX,
+const T* plain_dy(const T* dY, int64_t lddy, const ConvGeom& g, void* scratch, int64_t& ld_out, hipStream_t st, int& rc);
+template <typename T>
+int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dYp, int64_t lddyp, T* dX,
                     int64_t lddx, int accumulate, const ConvGeom& g, float s, hipStream_t st);
 template <typename T>
-int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dY, int64_t lddy, float* dW, float* slab,
-                    const ConvGeom& g, float s, hipStream_t st);
+int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t lddyp, float* dW, float* dbias,
+                    float* slab, const ConvGeom& g, float s, hipStream_t st);
+size_t conv_mfma_scratch_bytes(const ConvGeom& g);

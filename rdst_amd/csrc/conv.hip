@@ -141,27 +141,38 @@ template <typename T>
 int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int64_t lddy, T* dX, int64_t lddx,
           int accumulate, float* dW, float* dbias, float* wsp, const ConvGeom& g, float s, hipStream_t st) {
   const int64_t wtotal = (int64_t)g.Cout * g.Cin * g.ks * g.ks;
+  // workspace carve: [generic split-K slab][small][MFMA scratch: un-shuffled dY, wgrad slab]
   float* slab = wsp;
   float* small = slab + (int64_t)kMaxSplits * wtotal;
-  if (dbias) {
+  char* mscr = reinterpret_cast<char*>(small + (int64_t)kSmallBlocks * g.Cout + 64);
+  // MFMA fast paths want dY as plain (B*H*W, Cout) rows
+  int prc = 0;
+  int64_t ldp = lddy;
+  const T* dYp = plain_dy<T>(dY, lddy, g, mscr, ldp, st, prc);
+  if (prc) return prc;
+  float* mslab = reinterpret_cast<float*>(mscr + (g.r > 1 ? (size_t)g.pixels() * g.Cout * 4 : 0));
+  bool wdone = false;
+  if (dW || dbias) {
+    const int rc = conv_wgrad_mfma<T>(X, ldx, in_act, dYp, ldp, dW, dbias, mslab, g, s, st);
+    if (rc == 0) wdone = true;
+    else if (rc != RDST_ENOTSUP) return rc;
+  }
+  if (!wdone && dbias) {
     ConvDyCol<T> f{dY, lddy, g, s};
     if (int rc = colsum_launch(f, g.pixels(), g.Cout, small, kSmallBlocks, dbias, st, "conv_dbias")) return rc;
   }
-  if (dW) {
-    int rc = conv_wgrad_mfma<T>(X, ldx, in_act, dY, lddy, dW, slab, g, s, st);
-    if (rc == RDST_ENOTSUP) {
-      ConvDyAT<T> la{dY, lddy, g, s};
-      ConvAT<T> lb{ConvA<T>{X, ldx, g, in_act}};
-      ConvSlabEp ep{slab, g};
-      const int splits = wgrad_splits(g);
-      const int z = gemm_valu_splits(g.pixels(), splits);
-      rc = gemm_valu_launch(la, lb, ep, g.Cout, g.ks * g.ks * g.Cin, g.pixels(), splits, st, "conv_wgrad");
-      if (!rc) rc = slab_reduce(slab, dW, z, wtotal, st);
-    }
+  if (!wdone && dW) {
+    ConvDyAT<T> la{dY, lddy, g, s};
+    ConvAT<T> lb{ConvA<T>{X, ldx, g, in_act}};
+    ConvSlabEp ep{slab, g};
+    const int splits = wgrad_splits(g);
+    const int z = gemm_valu_splits(g.pixels(), splits);
+    int rc = gemm_valu_launch(la, lb, ep, g.Cout, g.ks * g.ks * g.Cin, g.pixels(), splits, st, "conv_wgrad");
+    if (!rc) rc = slab_reduce(slab, dW, z, wtotal, st);
     if (rc) return rc;
   }
   if (dX) {
-    int rc = conv_dgrad_mfma<T>(X, ldx, in_act, Wc, dY, lddy, dX, lddx, accumulate, g, s, st);
+    int rc = conv_dgrad_mfma<T>(X, ldx, in_act, Wc, dYp, ldp, dX, lddx, accumulate, g, s, st);
     if (rc == RDST_ENOTSUP) {
       ConvDyA<T> la{dY, lddy, g, s};
       ConvBd lb{Wc, g};
@@ -220,7 +231,9 @@ extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const floa
 
 extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
-  return sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64);
+  ConvGeom g{B, H, W, Cin, Cout, ksize, ksize / 2, 2};  // r = 2 reserves room for an un-shuffled dY
+  return sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
+         conv_mfma_scratch_bytes(g);
 }
 
 extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY, int64_t ld_dy,

@@ -11,8 +11,9 @@ int linear_fwd_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_
 template <typename T>
 int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const float* Wt, const T* dY, int64_t lddy,
                       T* dX, int64_t lddx, int accumulate, float* dA, int64_t M, int K, int N, float s, hipStream_t st);
-// dW[N][K] = s * dY^T f(X)
+// dW[N][K] = s * dY^T f(X) and dbias[N] = s * colsum(dY) in one pass (either pointer may be NULL)
 template <typename T>
 int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
-                      const T* dY, int64_t lddy, float* dW, float* slab, int64_t M, int K, int N, float s,
+                      const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
                       hipStream_t st);
+size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N);

@@ -7,18 +7,23 @@
 #include "gemm_valu.h"
 #include "linear.h"
 
+// out[i] = sum_s slab[s*n + i]: 64 outputs x 4 slab-groups per block, fixed order => reproducible
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           int S, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
   float a = 0.f;
-  for (int s = 0; s < S; ++s) a += slab[(int64_t)s * n + i];
-  out[i] = a;
+  if (i < n)
+    for (int s = sg; s < S; s += 4) a += slab[(int64_t)s * n + i];
+  part[sg][o] = a;
+  __syncthreads();
+  if (sg == 0 && i < n) out[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
 }
 
 int slab_reduce(const float* slab, float* out, int S, int64_t n, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, out, S, n);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, out, S, n);
   return rdst_launch_status("slab_reduce");
 }
 
@@ -209,22 +214,31 @@ ln_bwd_rows_kernel(const float* __restrict__ dA, const T* __restrict__ X, int64_
 constexpr int kWgradSplits = 96;
 constexpr int kSmallBlocks = 512;
 
+size_t slab_floats(int64_t M, int K, int N) {
+  const size_t a = (size_t)kWgradSplits * N * K, b = linear_wgrad_mfma_slab_floats(M, K, N);
+  return a > b ? a : b;
+}
+
 template <typename T>
 int fwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt, const float* bias,
           const T* R, int64_t ldr, T* Y, int64_t ldy, float* stats, int64_t M, int K, int N, float s, hipStream_t st) {
-  if (ln_w) {
+  auto run_stats = [&]() -> int {
     hipLaunchKernelGGL((row_stats_kernel<T>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, X, ldx, stats, M, K);
-    if (int rc = rdst_launch_status("row_stats")) return rc;
-  }
+    return rdst_launch_status("row_stats");
+  };
   if (!Wt) {
+    if (int rc = run_stats()) return rc;
     const int64_t n = M * K;
     hipLaunchKernelGGL((ln_apply_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, stats, ln_w,
                        ln_b, R, ldr, Y, ldy, M, K, s);
     return rdst_launch_status("ln_apply");
   }
+  // the MFMA path computes (and stores) the LayerNorm statistics itself
   if (int rc = linear_fwd_mfma<T>(X, ldx, ln_w, ln_b, in_act, Wt, bias, R, ldr, Y, ldy, stats, M, K, N, s, st);
       rc != RDST_ENOTSUP)
     return rc;
+  if (ln_w)
+    if (int rc = run_stats()) return rc;
   LinIn<T> la{X, ldx, stats, ln_w, ln_b, in_act};
   WtB lb{Wt, K};
   FwdEp<T> ep{bias, R, ldr, Y, ldy, s};
@@ -238,24 +252,26 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
   // workspace carve: [dA: M*K] [slabW: splits*N*K] [small: kSmallBlocks * max(N, 2K)]
   float* dA = wsp;
   float* slabW = dA + (ln_w ? M * K : 0);
-  float* small = slabW + (int64_t)kWgradSplits * N * K;
+  float* small = slabW + slab_floats(M, K, N);
   LinIn<T> fin{X, ldx, stats, ln_w, ln_b, in_act};
   if (Wt) {
-    if (dbias) {
+    bool wgrad_done = false;
+    if (dW || dbias) {
+      const int rc = linear_wgrad_mfma<T>(X, ldx, ln_w, ln_b, stats, in_act, dY, lddy, dW, dbias, slabW, M, K, N, s, st);
+      if (rc == 0) wgrad_done = true;
+      else if (rc != RDST_ENOTSUP) return rc;
+    }
+    if (!wgrad_done && dbias) {
       DyCol<T> f{dY, lddy, s};
       if (int rc = colsum_launch(f, M, N, small, kSmallBlocks, dbias, st, "linear_dbias")) return rc;
     }
-    if (dW) {
-      if (int rc = linear_wgrad_mfma<T>(X, ldx, ln_w, ln_b, stats, in_act, dY, lddy, dW, slabW, M, K, N, s, st);
-          rc != 0) {
-        if (rc != RDST_ENOTSUP) return rc;
-        DyAT<T> la{dY, lddy, s};
-        LinInT<T> lb{fin};
-        SlabEp ep{slabW, (int64_t)N * K, K};
-        const int z = gemm_valu_splits(M, kWgradSplits);
-        if (int rc2 = gemm_valu_launch(la, lb, ep, N, K, M, kWgradSplits, st, "linear_wgrad")) return rc2;
-        if (int rc2 = slab_reduce(slabW, dW, z, (int64_t)N * K, st)) return rc2;
-      }
+    if (!wgrad_done && dW) {
+      DyAT<T> la{dY, lddy, s};
+      LinInT<T> lb{fin};
+      SlabEp ep{slabW, (int64_t)N * K, K};
+      const int z = gemm_valu_splits(M, kWgradSplits);
+      if (int rc2 = gemm_valu_launch(la, lb, ep, N, K, M, kWgradSplits, st, "linear_wgrad")) return rc2;
+      if (int rc2 = slab_reduce(slabW, dW, z, (int64_t)N * K, st)) return rc2;
     }
     if (dX) {
       int rc = linear_dgrad_mfma<T>(X, ldx, ln_w != nullptr, in_act, Wt, dY, lddy, dX, lddx, accumulate, dA, M, K, N, s, st);
@@ -352,7 +368,7 @@ extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w
 extern "C" size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   const size_t mx = (size_t)(N > 2 * K ? N : 2 * K);
-  return sizeof(float) * ((size_t)M * K + (size_t)kWgradSplits * N * K + (size_t)kSmallBlocks * mx + 2 * (size_t)K + 64);
+  return sizeof(float) * ((size_t)M * K + slab_floats(M, K, N) + (size_t)kSmallBlocks * mx + 2 * (size_t)K + 64);
 }
 
 extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,

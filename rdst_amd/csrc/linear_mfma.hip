@@ -1,16 +1,428 @@
-// K3 MFMA fast paths (gfx950).  Not yet covering any shape: every hook reports RDST_ENOTSUP and
-// linear.hip uses the generic functor GEMM.
+// K3 on the gfx950 matrix cores: Linear forward / dgrad / wgrad for the skinny GEMMs of the Swin
+// blocks (M = B*H*W tokens, K and N in 30..360).
+//
+// Design (MI355X-first, not a tiled-GEMM port):
+//  * forward / dgrad ("NT": both operands k-contiguous): PERSISTENT 8-wave workgroups, one per CU.
+//    The whole weight matrix (<= 104 KB in bf16) is converted fp32 -> compute type once per workgroup
+//    and stays resident in LDS; every wave then streams 32-row slabs of tokens: the slab is loaded
+//    straight from HBM in MFMA-fragment shape (16 B per lane per k-step, rows only dword aligned),
+//    LayerNorm (statistics via one cross-half shuffle) or GELU is applied in registers, the A
+//    fragments stay in registers across all column tiles, and the 32x32 accumulators are stored with
+//    bias / scale / residual (fwd) or activation-gradient / accumulate (dgrad) fused in.  HBM sees
+//    each activation byte once; no LayerNorm output, GELU output or transposed copy ever exists.
+//  * wgrad ("TN": contraction over tokens): each workgroup owns a contiguous range of tokens and all
+//    of dW (<= 48 accumulator tiles over 8 waves); token stripes of 32 rows are staged row-major in
+//    LDS and read TRANSPOSED by ds_read_b64_tr_b16 (bf16) or element-wise (fp32, 32x32x2 MFMA takes
+//    single k elements).  A ones-column appended to f(X) makes d(bias) fall out of the same MFMAs.
+//    Per-workgroup partials go to a slab and are summed in fixed order (deterministic).
 #include "linear.h"
+#include "mfma.h"
+#include <stdlib.h>
+
+namespace {
+
+bool mfma_disabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RDST_DISABLE_MFMA");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+constexpr int MODE_FWD = 0, MODE_DGRAD = 1;
+constexpr float kLnEps = 1e-5f;
 
 template <typename T>
-int linear_fwd_mfma(const T*, int64_t, const float*, const float*, int, const float*, const float*, const T*, int64_t,
-                    T*, int64_t, float*, int64_t, int, int, float, hipStream_t) { return RDST_ENOTSUP; }
+struct LinArgs {
+  const T* A; int64_t lda;            // rows being contracted: X (fwd) / dY (dgrad)
+  const float* lnw; const float* lnb; int in_act;
+  const float* Wt; int wK;            // nn.Linear weight (N_lin, K_lin), wK = K_lin
+  const float* bias;
+  const T* R; int64_t ldr;
+  T* Y; int64_t ldy;                  // fwd: Y, dgrad (no LN): dX
+  float* stats;                       // fwd + LN: (M,2) {mean, rstd}
+  float* dA;                          // dgrad + LN: fp32 (M, Nout)
+  const T* Xa; int64_t ldxa;          // dgrad: pre-activation X for act'
+  int accumulate;
+  int64_t M; int Kc; int Nout; float s;
+  int Tn; int ldw; int nch;
+};
+
+template <typename T, int TMAX, int MODE>
+__global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  constexpr int KP = MM::KP, HP = MM::HP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int Tn = p.Tn;
+  char* Ws = smem;
+  float* gam = reinterpret_cast<float*>(smem + (size_t)p.nch * p.ldw);
+  float* bet = gam + Tn * KP;
+  const bool has_ln = (MODE == MODE_FWD) && p.lnw != nullptr;
+  if (has_ln)
+    for (int i = tid; i < Tn * KP; i += 512) {
+      gam[i] = i < p.Kc ? p.lnw[i] : 0.f;
+      bet[i] = i < p.Kc ? p.lnb[i] : 0.f;
+    }
+  const int64_t nslabs = (p.M + 31) / 32;
+  const float invK = 1.0f / (float)p.Kc;
+
+  for (int n0 = 0; n0 < p.Nout; n0 += p.nch) {
+    __syncthreads();
+    const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
+    const int ncp = ((nc + 31) / 32) * 32;
+    for (int idx = tid; idx < ncp * 2 * Tn; idx += 512) {
+      const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
+      const bool ok = n < nc;
+      Pack16 w;
+      if (MODE == MODE_FWD) w = pack_from_f32<T>(p.Wt + (int64_t)(n0 + n) * p.wK, ph * HP, p.Kc, 1, ok);
+      else w = pack_from_f32<T>(p.Wt + (n0 + n), ph * HP, p.Kc, p.wK, ok);
+      *reinterpret_cast<Pack16*>(Ws + (size_t)n * p.ldw + ph * 16) = w;
+    }
+    __syncthreads();
+    const int nct = ncp / 32;
+
+    for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < nslabs; slab += (int64_t)gridDim.x * 8) {
+      const int64_t row = slab * 32 + r;
+      const bool valid = row < p.M;
+      const T* arow = p.A + (valid ? row : 0) * p.lda;
+      Pack16 a[TMAX];
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t < Tn) a[t] = load_pack<T>(arow, t * KP + h * HP, p.Kc, valid);
+      if (MODE == MODE_FWD) {
+        if (has_ln) {
+          float sum = 0.f;
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) {
+              float f[HP];
+              MM::unpack(a[t], f);
+#pragma unroll
+              for (int e = 0; e < HP; ++e) sum += f[e];
+            }
+          sum += __shfl_xor(sum, 32, 64);
+          const float mean = sum * invK;
+          float var = 0.f;
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) {
+              float f[HP];
+              MM::unpack(a[t], f);
+#pragma unroll
+              for (int e = 0; e < HP; ++e) {
+                const float d = (t * KP + h * HP + e < p.Kc) ? f[e] - mean : 0.f;
+                var = fmaf(d, d, var);
+              }
+            }
+          var += __shfl_xor(var, 32, 64);
+          const float rstd = 1.0f / sqrtf(var * invK + kLnEps);
+          if (n0 == 0 && h == 0 && valid && p.stats) {
+            p.stats[2 * row] = mean;
+            p.stats[2 * row + 1] = rstd;
+          }
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) {
+              float f[HP];
+              MM::unpack(a[t], f);
+              const int k0 = t * KP + h * HP;
+#pragma unroll
+              for (int e = 0; e < HP; ++e) f[e] = (f[e] - mean) * rstd * gam[k0 + e] + bet[k0 + e];
+              a[t] = MM::pack(f);
+            }
+        } else if (p.in_act) {
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) {
+              float f[HP];
+              MM::unpack(a[t], f);
+#pragma unroll
+              for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+              a[t] = MM::pack(f);
+            }
+        }
+      }
+      for (int ct = 0; ct < nct; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        const char* wrow = Ws + (size_t)(ct * 32 + r) * p.ldw + h * 16;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+          if (t < Tn) {
+            const Pack16 b = *reinterpret_cast<const Pack16*>(wrow + t * 32);
+            MM::mma(acc, a[t], b);
+          }
+        const int col = n0 + ct * 32 + r;
+        if (col < p.Nout) {
+          const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int64_t rr = slab * 32 + acc_row(v, h);
+            if (rr < p.M) {
+              float val = acc[v];
+              if (MODE == MODE_FWD) {
+                val = (val + bv) * p.s;
+                if (p.R) val += to_f32<T>(p.R[rr * p.ldr + col]);
+                p.Y[rr * p.ldy + col] = from_f32<T>(val);
+              } else {
+                val *= p.s;
+                if (p.dA) {
+                  p.dA[rr * p.Nout + col] = val;
+                } else {
+                  if (p.in_act) val *= act_grad(to_f32<T>(p.Xa[rr * p.ldxa + col]), p.in_act);
+                  if (p.accumulate) val += to_f32<T>(p.Y[rr * p.ldy + col]);
+                  p.Y[rr * p.ldy + col] = from_f32<T>(val);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int MODE>
+int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
+  using MM = Mma<T>;
+  p.Tn = (p.Kc + MM::KP - 1) / MM::KP;
+  if (p.Tn > 32) return RDST_ENOTSUP;
+  p.ldw = lds_row_bytes(p.Kc, sizeof(T));
+  const int npad = ((p.Nout + 31) / 32) * 32;
+  int nch = (128 * 1024 / p.ldw) / 32 * 32;
+  if (nch < 32) return RDST_ENOTSUP;
+  if (nch > npad) nch = npad;
+  p.nch = nch;
+  const size_t smem = (size_t)nch * p.ldw + (size_t)2 * p.Tn * MM::KP * sizeof(float);
+  const int64_t nslabs = (p.M + 31) / 32;
+  int64_t grid = (nslabs + 7) / 8;
+  if (grid > 256) grid = 256;
+#define RDST_LIN_LAUNCH(TM)                                                                                          \
+  {                                                                                                                  \
+    auto kern = lin_mfma_kernel<T, TM, MODE>;                                                                        \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);                                          \
+  }
+  if (p.Tn <= 8) RDST_LIN_LAUNCH(8) else if (p.Tn <= 16) RDST_LIN_LAUNCH(16) else RDST_LIN_LAUNCH(32)
+#undef RDST_LIN_LAUNCH
+  return rdst_launch_status(what);
+}
+
+template <typename T> bool rows_ok(const void*, int64_t) { return true; }  // load_pack checks alignment per access
+
+// ------------------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------------------
+constexpr int WG_MAXT = 6;      // accumulator tiles per wave (8 waves -> 48 tiles = 360 x 121 max)
+constexpr int WG_STRIPE = 32;   // token rows staged per step
+
 template <typename T>
-int linear_dgrad_mfma(const T*, int64_t, bool, int, const float*, const T*, int64_t, T*, int64_t, int, float*, int64_t,
-                      int, int, float, hipStream_t) { return RDST_ENOTSUP; }
+struct WgradArgs {
+  const T* X; int64_t ldx; const float* lnw; const float* lnb; const float* stats; int in_act;
+  const T* dY; int64_t lddy;
+  float* slab;
+  int64_t M; int K; int N; int Kx;
+  int64_t rows_per_wg;
+  int ldn, ldk;  // LDS row strides, bytes
+  int NT, KT;
+};
+
 template <typename T>
-int linear_wgrad_mfma(const T*, int64_t, const float*, const float*, const float*, int, const T*, int64_t, float*,
-                      float*, int64_t, int, int, float, hipStream_t) { return RDST_ENOTSUP; }
+__global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  constexpr int HP = MM::HP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  char* dYs = smem;
+  char* Xs = smem + (size_t)WG_STRIPE * p.ldn;
+  f32x16 acc[WG_MAXT];
+#pragma unroll
+  for (int j = 0; j < WG_MAXT; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  const int ntiles = p.NT * p.KT;
+  const int64_t m_begin = (int64_t)blockIdx.x * p.rows_per_wg;
+  const int64_t m_end = (m_begin + p.rows_per_wg < p.M) ? m_begin + p.rows_per_wg : p.M;
+  const int npk = p.NT * 32 / HP, kpk = p.KT * 32 / HP;
+
+  for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_STRIPE) {
+    __syncthreads();
+    for (int idx = tid; idx < WG_STRIPE * npk; idx += 512) {
+      const int row = idx / npk, pk = idx - row * npk;
+      const bool valid = m0 + row < m_end;
+      const Pack16 v = load_pack<T>(p.dY + (valid ? (m0 + row) : 0) * p.lddy, pk * HP, p.N, valid);
+      *reinterpret_cast<Pack16*>(dYs + (size_t)row * p.ldn + pk * 16) = v;
+    }
+    for (int idx = tid; idx < WG_STRIPE * kpk; idx += 512) {
+      const int row = idx / kpk, pk = idx - row * kpk;
+      const int64_t m = m0 + row;
+      const bool valid = m < m_end;
+      const int k0 = pk * HP;
+      Pack16 v = load_pack<T>(p.X + (valid ? m : 0) * p.ldx, k0, p.K, valid);
+      float f[HP];
+      MM::unpack(v, f);
+      if (p.lnw) {
+        const float mean = valid ? p.stats[2 * m] : 0.f, rstd = valid ? p.stats[2 * m + 1] : 0.f;
+#pragma unroll
+        for (int e = 0; e < HP; ++e)
+          f[e] = (k0 + e < p.K) ? (f[e] - mean) * rstd * p.lnw[k0 + e] + p.lnb[k0 + e] : 0.f;
+      } else if (p.in_act) {
+#pragma unroll
+        for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+      }
+#pragma unroll
+      for (int e = 0; e < HP; ++e) {
+        if (!valid) f[e] = 0.f;
+        else if (k0 + e == p.K) f[e] = 1.0f;  // ones column: dW[:, K] = sum_m dY = d(bias)
+      }
+      *reinterpret_cast<Pack16*>(Xs + (size_t)row * p.ldk + pk * 16) = MM::pack(f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WG_MAXT; ++j) {
+      const int ti = wave + 8 * j;
+      if (ti < ntiles) {
+        const int nt = ti / p.KT, kt = ti - nt * p.KT;
+        if constexpr (sizeof(T) == 2) {
+          // transposed fragment reads: 16-lane group g covers 16 columns, 4 token rows per read
+          const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+          const int colA = nt * 32 + 16 * (g & 1) + 4 * pp;
+          const int colB = kt * 32 + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+          for (int ms = 0; ms < WG_STRIPE / 16; ++ms) {
+            const int rowb = ms * 16 + 8 * h + q;
+            Pack16 a, b;
+            {
+              typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+              const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(dYs + (size_t)rowb * p.ldn + colA * 2));
+              const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(dYs + (size_t)(rowb + 4) * p.ldn + colA * 2));
+              const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + (size_t)rowb * p.ldk + colB * 2));
+              const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + (size_t)(rowb + 4) * p.ldk + colB * 2));
+              const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
+              const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
+              a.w[0] = ua0.x; a.w[1] = ua0.y; a.w[2] = ua1.x; a.w[3] = ua1.y;
+              b.w[0] = ub0.x; b.w[1] = ub0.y; b.w[2] = ub1.x; b.w[3] = ub1.y;
+            }
+            MM::mma(acc[j], a, b);
+          }
+        } else {
+          const float* dYf = reinterpret_cast<const float*>(dYs);
+          const float* Xf = reinterpret_cast<const float*>(Xs);
+          const int lda = p.ldn / 4, ldb = p.ldk / 4;
+#pragma unroll 8
+          for (int s2 = 0; s2 < WG_STRIPE / 2; ++s2) {
+            const float av = dYf[(2 * s2 + h) * lda + nt * 32 + r];
+            const float bv = Xf[(2 * s2 + h) * ldb + kt * 32 + r];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  float* my = p.slab + (int64_t)blockIdx.x * p.N * p.Kx;
+#pragma unroll
+  for (int j = 0; j < WG_MAXT; ++j) {
+    const int ti = wave + 8 * j;
+    if (ti < ntiles) {
+      const int nt = ti / p.KT, kt = ti - nt * p.KT;
+      const int k = kt * 32 + r;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int n = nt * 32 + acc_row(v, h);
+        if (n < p.N && k < p.Kx) my[(int64_t)n * p.Kx + k] = acc[j][v];
+      }
+    }
+  }
+}
+
+// dW[n][k] = s * sum_wg slab[wg][n][k] (k < K);  dbias[n] = s * sum_wg slab[wg][n][K]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int N, int K, int Kx,
+                                                           float s, float* __restrict__ dW, float* __restrict__ dbias) {
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  const int tot = N * Kx;
+  float a = 0.f;
+  if (i < tot)
+    for (int w = sg; w < nwg; w += 4) a += slab[(int64_t)w * tot + i];
+  part[sg][o] = a;
+  __syncthreads();
+  if (sg != 0 || i >= tot) return;
+  a = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+  const int n = i / Kx, k = i - n * Kx;
+  if (k < K) {
+    if (dW) dW[(int64_t)n * K + k] = a * s;
+  } else if (dbias) {
+    dbias[n] = a * s;
+  }
+}
+
+}  // namespace
+
+template <typename T>
+int linear_fwd_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt,
+                    const float* bias, const T* R, int64_t ldr, T* Y, int64_t ldy, float* stats, int64_t M, int K,
+                    int N, float s, hipStream_t st) {
+  if (mfma_disabled() || !rows_ok<T>(X, ldx)) return RDST_ENOTSUP;
+  LinArgs<T> p{};
+  p.A = X; p.lda = ldx; p.lnw = ln_w; p.lnb = ln_b; p.in_act = in_act; p.Wt = Wt; p.wK = K; p.bias = bias;
+  p.R = R; p.ldr = ldr; p.Y = Y; p.ldy = ldy; p.stats = stats; p.M = M; p.Kc = K; p.Nout = N; p.s = s;
+  return launch_lin<T, MODE_FWD>(p, st, "lin_fwd_mfma");
+}
+
+template <typename T>
+int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const float* Wt, const T* dY, int64_t lddy,
+                      T* dX, int64_t lddx, int accumulate, float* dA, int64_t M, int K, int N, float s, hipStream_t st) {
+  if (mfma_disabled() || !rows_ok<T>(dY, lddy)) return RDST_ENOTSUP;
+  LinArgs<T> p{};
+  p.A = dY; p.lda = lddy; p.in_act = in_act; p.Wt = Wt; p.wK = K; p.Y = dX; p.ldy = lddx;
+  p.dA = has_ln ? dA : nullptr; p.Xa = X; p.ldxa = ldx; p.accumulate = accumulate;
+  p.M = M; p.Kc = N; p.Nout = K; p.s = s;
+  return launch_lin<T, MODE_DGRAD>(p, st, "lin_dgrad_mfma");
+}
+
+size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N) {
+  (void)M;
+  return (size_t)256 * N * (K + 1);
+}
+
+template <typename T>
+int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
+                      const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
+                      hipStream_t st) {
+  if (mfma_disabled() || !rows_ok<T>(X, ldx) || !rows_ok<T>(dY, lddy)) return RDST_ENOTSUP;
+  WgradArgs<T> p{};
+  p.X = X; p.ldx = ldx; p.lnw = ln_w; p.lnb = ln_b; p.stats = stats; p.in_act = in_act; p.dY = dY; p.lddy = lddy;
+  p.slab = slab; p.M = M; p.K = K; p.N = N; p.Kx = K + 1;
+  p.NT = (N + 31) / 32; p.KT = (p.Kx + 31) / 32;
+  if (p.NT * p.KT > 8 * WG_MAXT) return RDST_ENOTSUP;
+  // LDS row strides: bf16 rows are read by ds_read_b64_tr_b16 (4 token rows x 64 B per 32 lanes):
+  // stride = 64 (mod 256) bytes puts the 4 rows on disjoint bank ranges; fp32 rows are read 32
+  // consecutive floats at a time, any stride works.
+  auto stride = [](int elems) {
+    const int b = elems * (int)sizeof(T);
+    if (sizeof(T) == 4) return b;
+    return b <= 64 ? 64 : ((b - 64 + 255) / 256) * 256 + 64;
+  };
+  p.ldn = stride(p.NT * 32);
+  p.ldk = stride(p.KT * 32);
+  const size_t smem = (size_t)WG_STRIPE * (p.ldn + p.ldk);
+  if (smem > 160 * 1024) return RDST_ENOTSUP;
+  int64_t nwg = (M + WG_STRIPE - 1) / WG_STRIPE;
+  if (nwg > 256) nwg = 256;
+  p.rows_per_wg = (((M + nwg - 1) / nwg + WG_STRIPE - 1) / WG_STRIPE) * WG_STRIPE;
+  nwg = (M + p.rows_per_wg - 1) / p.rows_per_wg;
+  auto kern = lin_wgrad_mfma_kernel<T>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), smem, st, p);
+  if (int rc = rdst_launch_status("lin_wgrad_mfma")) return rc;
+  const int tot = N * p.Kx;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
+  return rdst_launch_status("wgrad_reduce");
+}
 
 #define INST(T)                                                                                                        \
   template int linear_fwd_mfma<T>(const T*, int64_t, const float*, const float*, int, const float*, const float*,     \
@@ -18,6 +430,6 @@ int linear_wgrad_mfma(const T*, int64_t, const float*, const float*, const float
   template int linear_dgrad_mfma<T>(const T*, int64_t, bool, int, const float*, const T*, int64_t, T*, int64_t, int,  \
                                     float*, int64_t, int, int, float, hipStream_t);                                   \
   template int linear_wgrad_mfma<T>(const T*, int64_t, const float*, const float*, const float*, int, const T*,       \
-                                    int64_t, float*, float*, int64_t, int, int, float, hipStream_t);
+                                    int64_t, float*, float*, float*, int64_t, int, int, float, hipStream_t);
 INST(float)
 INST(bf16)
