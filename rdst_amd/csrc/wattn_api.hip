@@ -54,6 +54,8 @@ extern "C" int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* tabl
   if (!qkv || !table || !out) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: null pointer");
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: bad dtype %d", dtype);
   if (ld_qkv < 3 * C || ld_out < C) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: leading dimension too small");
+  if (int rc = wattn_fwd_mfma(qkv, ld_qkv, table, out, ld_out, g, scale, dtype, (hipStream_t)stream); rc != RDST_ENOTSUP)
+    return rc;
   return wattn_fwd_generic(qkv, ld_qkv, table, out, ld_out, g, scale, dtype, (hipStream_t)stream);
 }
 
@@ -80,8 +82,15 @@ extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* tabl
     return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* slab = (float*)workspace;
-  if (int rc = wattn_bwd_generic(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, g, scale, dtype, st)) return rc;
-  const int nwin = B * g.nWh * g.nWw;
+  int nwin = B * g.nWh * g.nWw;
+  int nslab = 0;
+  int rc = wattn_bwd_mfma(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, nwin, g, scale, dtype, &nslab, st);
+  if (rc == 0) {
+    nwin = nslab;  // one slab row per persistent workgroup
+  } else {
+    if (rc != RDST_ENOTSUP) return rc;
+    if (int rc2 = wattn_bwd_generic(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, g, scale, dtype, st)) return rc2;
+  }
   const int chunks = (g.T + 63) / 64;
   hipLaunchKernelGGL(dtable_reduce, dim3(heads * chunks), dim3(1024), 0, st, slab, dtable, nwin, heads, g.T);
   return rdst_launch_status("dtable_reduce");

@@ -1,0 +1,449 @@
+// K2 on the gfx950 matrix cores: fused window attention backward for 8x8 windows, 6 heads.
+//
+// Persistent workgroups of 2*heads = 12 waves; wave (t, hd) owns tile t (32 tokens) of head hd.
+// Per window the qkv rows and the dOut rows are read once from HBM into four LDS sections (Q is
+// pre-multiplied by scale [* log2 e in bf16 mode] on the way in, so S^T = K Qs^T needs no per-element
+// scaling and the relative-position bias is simply the INITIAL ACCUMULATOR of the MFMA chain).
+//   pass T (keys in the accumulator registers, query on the lane; = the forward's orientation):
+//     S^T -> softmax statistics (m, 1/l per query: in-lane + one cross-half shuffle) -> P^T;
+//     dP^T = V dO_h^T;  delta = rowsum(P dP);  dS^T = P^T (dP^T - delta);
+//     d(table) += dS^T by conflict-free LDS atomics (accumulated across all windows of the workgroup);
+//     dQ_h = scale * (dS^T)^T K_h   (accumulator tile as the A operand, K read transposed)
+//   pass N (queries in the registers, key on the lane): S, dP recomputed with the roles swapped,
+//     P / dS rebuilt from the per-query statistics in LDS;
+//     dV_h = P^T dO_h,  dK_h = dS^T Qs_h   (again accumulator-as-operand + transposed reads)
+// Heads are selected by masking packs to the head's channels (head dims 10/15/20 are not k-step
+// multiples).  dQ/dK/dV land in three more LDS sections and go back to HBM as full dqkv rows.
+// d(table) partials: one slab row per workgroup, summed in fixed order by dtable_reduce.
+#include "common.h"
+#include "wattn.h"
+#include "mfma.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TS = 24;
+constexpr int HEADS = 6;
+constexpr int NWAVES = 2 * HEADS;
+constexpr int NTHREADS = 64 * NWAVES;
+constexpr int MAXR = (64 + NWAVES - 1) / NWAVES;  // token rows staged per wave
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int GRAN> struct Chunk;
+template <> struct Chunk<16> { typedef u32x4_t type; };
+template <> struct Chunk<8> { typedef u32x2_t type; };
+template <> struct Chunk<4> { typedef uint32_t type; };
+
+template <typename T>
+struct WbArgs {
+  const T* qkv; int64_t ld;
+  const float* table;
+  const T* dout; int64_t ldd;
+  T* dqkv; int64_t ldq;
+  float* slab;
+  WinGeom g;
+  float scale;
+  int d, ldt;
+};
+
+__device__ __forceinline__ uint32_t mask_bits_bf16(int c0, int lo, int hi) {
+  return ((c0 >= lo && c0 < hi) ? 0x0000ffffu : 0u) | ((c0 + 1 >= lo && c0 + 1 < hi) ? 0xffff0000u : 0u);
+}
+
+template <typename T>
+__device__ __forceinline__ Pack16 masked_pack(const char* base, int c0, int c_lo, int c_hi) {
+  Pack16 p = *reinterpret_cast<const Pack16*>(base + (size_t)c0 * sizeof(T));
+  if (sizeof(T) == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.w[e] &= mask_bits_bf16(c0 + 2 * e, c_lo, c_hi);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.w[e] = (c0 + e >= c_lo && c0 + e < c_hi) ? p.w[e] : 0u;
+  }
+  return p;
+}
+
+// acc (32 x 32, rows = tokens of tile `rt`, cols = channel tile ct) += X^T . Bsec
+//   X[kk][v]: accumulator tiles whose ROW index (tokens of tile kk) is contracted; Bsec rows = those tokens.
+template <typename T>
+__device__ __forceinline__ void acc_xt_b(f32x16& acc, const f32x16 (&X)[2], const char* Bsec, int ldt, int ct, bool colin,
+                                         int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  if constexpr (sizeof(T) == 2) {
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int colB = ct * 32 + 16 * (gq & 1) + 4 * pp;
+    const uint32_t cm = colin ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Pack16 a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.w[e] = pack_bf16x2(X[kk][8 * s + 2 * e], X[kk][8 * s + 2 * e + 1]);
+        const int rowb = kk * 32 + 16 * s + 4 * h + q;
+        typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+        const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Bsec + (size_t)rowb * ldt + colB * 2));
+        const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Bsec + (size_t)(rowb + 8) * ldt + colB * 2));
+        const uint2 u0 = __builtin_bit_cast(uint2, b0), u1 = __builtin_bit_cast(uint2, b1);
+        Pack16 bb;
+        bb.w[0] = u0.x & cm; bb.w[1] = u0.y & cm; bb.w[2] = u1.x & cm; bb.w[3] = u1.y & cm;
+        Mma<T>::mma(acc, a, bb);
+      }
+  } else {
+    const float* Bf = reinterpret_cast<const float*>(Bsec);
+    const int ldb = ldt / 4;
+    const int col = ct * 32 + r;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float bv = Bf[(kk * 32 + acc_row(v, h)) * ldb + col];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X[kk][v], colin ? bv : 0.f, acc, 0, 0, 0);
+      }
+  }
+}
+
+template <typename T, int GRAN, int ITERS>
+__global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  using CH = typename Chunk<GRAN>::type;
+  constexpr int KP = MM::KP, HP = MM::HP;
+  constexpr bool BF = sizeof(T) == 2;
+  const WinGeom g = p.g;
+  const int C = g.C, d = p.d, ldt = p.ldt;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int secsz = 64 * ldt;
+  char* Qs = smem;                 // Q * scale (* log2 e)
+  char* Ks = Qs + secsz;
+  char* Vs = Ks + secsz;
+  char* Os = Vs + secsz;           // dOut
+  char* dQs = Os + secsz;
+  char* dKs = dQs + secsz;
+  char* dVs = dKs + secsz;
+  float* tabL = reinterpret_cast<float*>(dVs + secsz);      // [HEADS][15][TS]
+  float* dtabL = tabL + HEADS * 15 * TS;                     // [HEADS][15][TS]
+  float4* stats = reinterpret_cast<float4*>(dtabL + HEADS * 15 * TS);  // [HEADS][64] {m, 1/l, delta, -}
+
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  const float tabscale = BF ? LOG2E : 1.0f;
+  const float qscale = p.scale * tabscale;
+  const int nW = g.nWh * g.nWw;
+  const int nwin = g.B * nW;
+
+  for (int i = tid; i < HEADS * 15 * TS; i += NTHREADS) dtabL[i] = 0.f;
+  for (int i = tid; i < HEADS * 225; i += NTHREADS) {
+    const int hd = i / 225, rem = i - hd * 225;
+    const int dy = rem / 15, dx = rem - dy * 15;
+    tabL[(hd * 15 + dy) * TS + dx] = p.table[rem * HEADS + hd] * tabscale;
+  }
+  {  // zero the pad columns of the four input sections once
+    const int padw = (ldt - C * (int)sizeof(T)) / 4;
+    for (int idx = tid; idx < 4 * 64 * padw; idx += NTHREADS) {
+      const int row = idx / padw, w = idx - row * padw;
+      *reinterpret_cast<uint32_t*>(Qs + (size_t)row * ldt + C * sizeof(T) + 4 * w) = 0u;
+    }
+  }
+  const int secb = C * (int)sizeof(T);
+  const int cps = secb / GRAN;
+  const int per_row = 3 * cps;
+
+  const int t = wv & 1, hd = wv >> 1;       // this wave's tile and head
+  const int c_lo = hd * d, c_hi = c_lo + d;
+  const int t_lo = c_lo / KP, t_hi = (c_hi - 1) / KP;
+  const int ct_lo = c_lo / 32, ct_hi = (c_hi - 1) / 32;
+  const int thr = g.ws - g.shift;
+  const float NEG = -100.0f * tabscale;
+  const int yl = t * 4 + (r >> 3), xl = r & 7;  // window coords of this lane's token (tile t)
+  const bool fyl = yl < thr, fxl = xl < thr;
+
+  for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+    const int b = win / nW, wi = win - b * nW;
+    const int wr = wi / g.nWw, wc = wi - wr * g.nWw;
+    // ---- HBM -> LDS: qkv rows (3 sections, Q scaled) and dOut rows ---------------------------------
+    {
+      CH regs[MAXR][ITERS];
+      CH rego[MAXR];
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        int row = wv + NWAVES * i;
+        row = row < 64 ? row : 63;
+        const int64_t tok = win_token(b, wr, wc, row, g);
+        const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          int c = lane + 64 * it;
+          c = c < per_row ? c : per_row - 1;
+          regs[i][it] = *reinterpret_cast<const CH*>(src + (size_t)c * GRAN);
+        }
+        const int co = lane < cps ? lane : cps - 1;
+        rego[i] = *reinterpret_cast<const CH*>(reinterpret_cast<const char*>(p.dout + tok * p.ldd) + (size_t)co * GRAN);
+      }
+      __syncthreads();  // previous window fully copied out
+#pragma unroll
+      for (int i = 0; i < MAXR; ++i) {
+        const int row = wv + NWAVES * i;
+        if (row < 64) {
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) {
+            const int c = lane + 64 * it;
+            if (c < per_row) {
+              const int off = c * GRAN;
+              const int sec = (off >= secb) + (off >= 2 * secb);
+              CH v = regs[i][it];
+              if (sec == 0) {  // Q <- Q * scale (* log2 e)
+                uint32_t w[GRAN / 4];
+                __builtin_memcpy(w, &v, GRAN);
+#pragma unroll
+                for (int e = 0; e < GRAN / 4; ++e) {
+                  if (BF) w[e] = pack_bf16x2(bf16lo(w[e]) * qscale, bf16hi(w[e]) * qscale);
+                  else w[e] = __float_as_uint(__uint_as_float(w[e]) * qscale);
+                }
+                __builtin_memcpy(&v, w, GRAN);
+              }
+              *reinterpret_cast<CH*>(smem + sec * (secsz - secb) + row * ldt + off) = v;
+            }
+          }
+          if (lane < cps) *reinterpret_cast<CH*>(Os + row * ldt + lane * GRAN) = rego[i];
+        }
+      }
+    }
+    __syncthreads();
+
+    const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
+    const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
+
+    // ================= pass T: keys on registers, query (tile t) on the lane ======================
+    {
+      f32x16 X[2], D[2];
+      const float* tb = tabL + hd * 15 * TS + (yl + 7) * TS + (xl + 7) - 4 * h;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          X[kt][v] = tb[-((kt * 4 + (v >> 2)) * TS + (v & 3))];  // bias = initial accumulator
+          D[kt][v] = 0.f;
+        }
+      for (int ts = t_lo; ts <= t_hi; ++ts) {
+        const int c0 = ts * KP + h * HP;
+        const Pack16 qb = masked_pack<T>(Qs + (size_t)(t * 32 + r) * ldt, c0, c_lo, c_hi);
+        const Pack16 ob = masked_pack<T>(Os + (size_t)(t * 32 + r) * ldt, c0, c_lo, c_hi);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const Pack16 ka = *reinterpret_cast<const Pack16*>(Ks + (size_t)(kt * 32 + r) * ldt + (size_t)c0 * sizeof(T));
+          const Pack16 va = *reinterpret_cast<const Pack16*>(Vs + (size_t)(kt * 32 + r) * ldt + (size_t)c0 * sizeof(T));
+          MM::mma(X[kt], ka, qb);
+          MM::mma(D[kt], va, ob);
+        }
+      }
+      if (masked) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
+            const bool diff = (mrow && (fyl != (yj < thr))) || (mcol && (fxl != (xj < thr)));
+            X[kt][v] += diff ? NEG : 0.f;
+          }
+      }
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) m = fmaxf(m, X[kt][v]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const float e = BF ? __builtin_amdgcn_exp2f(X[kt][v] - m) : expf(X[kt][v] - m);
+          X[kt][v] = e;
+          l += e;
+        }
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      float dl = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          X[kt][v] *= inv;                       // P^T
+          dl = fmaf(X[kt][v], D[kt][v], dl);
+        }
+      dl += __shfl_xor(dl, 32, 64);              // delta_i
+      if (h == 0) stats[hd * 64 + t * 32 + r] = make_float4(m, inv, dl, 0.f);
+      float* dtb = dtabL + (tb - tabL);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const float ds = X[kt][v] * (D[kt][v] - dl);  // dS^T
+          D[kt][v] = ds;
+          atomicAdd(&dtb[-((kt * 4 + (v >> 2)) * TS + (v & 3))], ds);
+        }
+      // dQ_h (tile t) = scale * (dS^T)^T K_h
+      for (int ct = ct_lo; ct <= ct_hi; ++ct) {
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        const int col = ct * 32 + r;
+        const bool colin = col >= c_lo && col < c_hi;
+        acc_xt_b<T>(acc, D, Ks, ldt, ct, colin, lane);
+        if (colin) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            *(reinterpret_cast<T*>(dQs + (size_t)(t * 32 + acc_row(v, h)) * ldt) + col) = from_f32<T>(acc[v] * p.scale);
+        }
+      }
+    }
+    __syncthreads();  // statistics of both query tiles are in LDS
+
+    // ================= pass N: queries on registers, key (tile t) on the lane ======================
+    {
+      f32x16 Y[2], E[2];
+      const float* tb = tabL + hd * 15 * TS + (7 - yl) * TS + (7 - xl) + 4 * h;
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          Y[it][v] = tb[(it * 4 + (v >> 2)) * TS + (v & 3)];
+          E[it][v] = 0.f;
+        }
+      for (int ts = t_lo; ts <= t_hi; ++ts) {
+        const int c0 = ts * KP + h * HP;
+        const Pack16 kb = *reinterpret_cast<const Pack16*>(Ks + (size_t)(t * 32 + r) * ldt + (size_t)c0 * sizeof(T));
+        const Pack16 vb = *reinterpret_cast<const Pack16*>(Vs + (size_t)(t * 32 + r) * ldt + (size_t)c0 * sizeof(T));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const Pack16 qa = masked_pack<T>(Qs + (size_t)(it * 32 + r) * ldt, c0, c_lo, c_hi);
+          const Pack16 oa = masked_pack<T>(Os + (size_t)(it * 32 + r) * ldt, c0, c_lo, c_hi);
+          MM::mma(Y[it], qa, kb);
+          MM::mma(E[it], oa, vb);
+        }
+      }
+      if (masked) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int yi = it * 4 + (v >> 2), xi = (v & 3) + 4 * h;
+            const bool diff = (mrow && (fyl != (yi < thr))) || (mcol && (fxl != (xi < thr)));
+            Y[it][v] += diff ? NEG : 0.f;
+          }
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const float4 st = stats[hd * 64 + it * 32 + acc_row(v, h)];
+          const float pr = (BF ? __builtin_amdgcn_exp2f(Y[it][v] - st.x) : expf(Y[it][v] - st.x)) * st.y;  // P
+          Y[it][v] = pr;
+          E[it][v] = pr * (E[it][v] - st.z);                                                                // dS
+        }
+      for (int ct = ct_lo; ct <= ct_hi; ++ct) {
+        const int col = ct * 32 + r;
+        const bool colin = col >= c_lo && col < c_hi;
+        f32x16 av, ak;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { av[v] = 0.f; ak[v] = 0.f; }
+        acc_xt_b<T>(av, Y, Os, ldt, ct, colin, lane);   // dV_h = P^T dO_h
+        acc_xt_b<T>(ak, E, Qs, ldt, ct, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
+        if (colin) {
+          const float kfix = BF ? LN2 : 1.0f;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const size_t ro = (size_t)(t * 32 + acc_row(v, h)) * ldt;
+            *(reinterpret_cast<T*>(dVs + ro) + col) = from_f32<T>(av[v]);
+            *(reinterpret_cast<T*>(dKs + ro) + col) = from_f32<T>(ak[v] * kfix);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- LDS -> HBM: dqkv rows = [dQ | dK | dV] -------------------------------------------------------
+    for (int row = wv; row < 64; row += NWAVES) {
+      const int64_t tok = win_token(b, wr, wc, row, g);
+      char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq);
+      for (int c = lane; c < per_row; c += 64) {
+        const int off = c * GRAN;
+        const int sec = (off >= secb) + (off >= 2 * secb);
+        *reinterpret_cast<CH*>(dst + off) = *reinterpret_cast<const CH*>(dQs + sec * (secsz - secb) + row * ldt + off);
+      }
+    }
+  }
+  __syncthreads();
+  float* my = p.slab + (int64_t)blockIdx.x * HEADS * 225;
+  for (int i = tid; i < HEADS * 225; i += NTHREADS) {
+    const int hh = i / 225, rem = i - hh * 225;
+    const int dy = rem / 15, dx = rem - dy * 15;
+    my[i] = dtabL[(hh * 15 + dy) * TS + dx];
+  }
+}
+
+bool mfma_disabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RDST_DISABLE_MFMA");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+template <typename T>
+int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int64_t ldd, T* dqkv, int64_t ldq,
+               float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st) {
+  const int d = g.C / g.heads;
+  if (g.ws != 8 || g.heads != HEADS || d > 32 || g.C > 128 || g.mask) return RDST_ENOTSUP;
+  WbArgs<T> p{};
+  p.qkv = qkv; p.ld = ld; p.table = table; p.dout = dout; p.ldd = ldd; p.dqkv = dqkv; p.ldq = ldq; p.slab = slab;
+  p.g = g; p.scale = scale; p.d = d;
+  const int sec = g.C * (int)sizeof(T);
+  int gran = 0;
+  for (int gs = 16; gs >= 4; gs >>= 1) {
+    const auto ok = [&](const void* q, int64_t l) { return ((uintptr_t)q % gs) == 0 && (l * (int64_t)sizeof(T)) % gs == 0; };
+    if (sec % gs == 0 && ok(qkv, ld) && ok(dout, ldd) && ok(dqkv, ldq)) { gran = gs; break; }
+  }
+  if (!gran) return RDST_ENOTSUP;
+  int ldt = ((sec + 31) / 32) * 32;
+  if ((ldt / 16) % 2 == 0) ldt += 16;
+  p.ldt = ldt;
+  const size_t smem = (size_t)7 * 64 * ldt + (size_t)2 * HEADS * 15 * TS * 4 + (size_t)HEADS * 64 * 16;
+  if (smem > 160 * 1024) return RDST_ENOTSUP;
+  const int64_t nwin = (int64_t)g.B * g.nWh * g.nWw;
+  int64_t grid = 256;
+  if (grid > nwin) grid = nwin;
+  if (grid > slab_rows) grid = slab_rows;
+  *nslab = (int)grid;
+  const int per_row = 3 * sec / gran;
+  const int iters = (per_row + 63) / 64;
+#define RDST_WB_LAUNCH(GR, IT)                                                                                       \
+  {                                                                                                                  \
+    auto kern = wattn_bwd_mfma_kernel<T, GR, IT>;                                                                    \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), smem, st, p);                                     \
+  }
+  if (gran == 16 && iters == 1) RDST_WB_LAUNCH(16, 1)
+  else if (gran == 8 && iters == 1) RDST_WB_LAUNCH(8, 1)
+  else if (gran == 8 && iters <= 3) RDST_WB_LAUNCH(8, 3)
+  else if (gran == 4 && iters <= 3) RDST_WB_LAUNCH(4, 3)
+  else return RDST_ENOTSUP;
+#undef RDST_WB_LAUNCH
+  return rdst_launch_status("wattn_bwd_mfma");
+}
+
+}  // namespace
+
+// slab: [>= 256][heads][225] floats; *nslab = number of slab rows written (to be reduced by the caller)
+int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
+                   int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int dtype, int* nslab,
+                   hipStream_t st) {
+  if (mfma_disabled()) return RDST_ENOTSUP;
+  if (dtype == RDST_F32)
+    return launch_bwd<float>((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
+                             scale, nslab, st);
+  return launch_bwd<bf16>((const bf16*)qkv, ld, table, (const bf16*)dout, ldd, (bf16*)dqkv, ldq, slab, slab_rows, g, scale,
+                          nslab, st);
+}
