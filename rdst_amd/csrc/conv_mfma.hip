@@ -47,6 +47,7 @@ struct ConvArgs {
   int Nout;                          // fwd: Cout, dgrad: Cin
   float s;
   int Tn, ldw, nch;
+  int eps_off;
 };
 
 template <typename T, int TMAX, int MODE>
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
   const int ntap = g.ks * g.ks;
   const int64_t P = g.pixels();
   const int64_t nslabs = (P + 31) / 32;
+  float* eps = reinterpret_cast<float*>(smem + (p.eps_off < 0 ? 0 : p.eps_off)) + wave * 1024;  // wave-private epilogue tile
 
   for (int n0 = 0; n0 < p.Nout; n0 += p.nch) {
     __syncthreads();
@@ -132,29 +134,43 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
       for (int c = 0; c < CV_MAXCT; ++c)
         if (c < nct) {
           const int col = n0 + c * 32 + r;
-          if (col < p.Nout) {
-            const float bv = (MODE == CMODE_FWD && p.bias) ? p.bias[col] : 0.f;
+          const float bv = (MODE == CMODE_FWD && p.bias && col < p.Nout) ? p.bias[col] : 0.f;
+          if (p.eps_off < 0 || (MODE == CMODE_FWD && g.r > 1)) {
+            // element stores: PixelShuffle scatters consecutive channels to different pixels, or no LDS
+            // is left for the row-wise bounce (240-channel dgrad)
+            if (col < p.Nout) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-              const int64_t pp = slab * 32 + acc_row(v, h);
-              if (pp < P) {
-                float val = acc[c][v];
-                if (MODE == CMODE_FWD) {
-                  int b2, y2, x2;
-                  g.decode(pp, b2, y2, x2);
-                  int64_t row; int ch;
-                  g.out_rc(b2, y2, x2, col, row, ch);
-                  val = (val + bv) * p.s;
-                  if (p.R) val += to_f32<T>(p.R[row * p.ldr + ch]);
-                  p.Y[row * p.ldy + ch] = from_f32<T>(val);
-                } else {
-                  val *= p.s;
-                  if (p.in_act) val *= act_grad(to_f32<T>(p.Xa[pp * p.ldxa + col]), p.in_act);
-                  if (p.accumulate) val += to_f32<T>(p.Y[pp * p.ldy + col]);
-                  p.Y[pp * p.ldy + col] = from_f32<T>(val);
+              for (int v = 0; v < 16; ++v) {
+                const int64_t pp = slab * 32 + acc_row(v, h);
+                if (pp < P) {
+                  if (MODE == CMODE_FWD) {
+                    int b2, y2, x2;
+                    g.decode(pp, b2, y2, x2);
+                    int64_t row; int ch;
+                    g.out_rc(b2, y2, x2, col, row, ch);
+                    float val = (acc[c][v] + bv) * p.s;
+                    if (p.R) val += to_f32<T>(p.R[row * p.ldr + ch]);
+                    p.Y[row * p.ldy + ch] = from_f32<T>(val);
+                  } else {
+                    float val = acc[c][v] * p.s;
+                    if (p.in_act) val *= act_grad(to_f32<T>(p.Xa[pp * p.ldxa + col]), p.in_act);
+                    if (p.accumulate) val += to_f32<T>(p.Y[pp * p.ldy + col]);
+                    p.Y[pp * p.ldy + col] = from_f32<T>(val);
+                  }
                 }
               }
             }
+          } else {
+            float vals[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) vals[v] = (MODE == CMODE_FWD) ? (acc[c][v] + bv) * p.s : acc[c][v] * p.s;
+            TileEpilogue ep{};
+            if (MODE == CMODE_FWD) {
+              ep.R = p.R; ep.ldr = p.ldr; ep.Y = p.Y; ep.ldy = p.ldy;
+            } else {
+              ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.accumulate = p.accumulate;
+            }
+            tile_store_rows<T>(eps, vals, lane, slab * 32, P, n0 + c * 32, p.Nout, ep);
           }
         }
     }
@@ -169,12 +185,18 @@ int launch_conv(ConvArgs<T>& p, hipStream_t st, const char* what) {
   p.ldw = lds_row_bytes(p.CA, sizeof(T));
   const int ntap = p.g.ks * p.g.ks;
   const int npad = ((p.Nout + 31) / 32) * 32;
-  int nch = (int)((150 * 1024) / ((size_t)ntap * p.ldw)) / 32 * 32;
+  bool rows = true;  // row-wise epilogue needs 8 x 4 KB of LDS besides the weights
+  int nch = (int)((124 * 1024) / ((size_t)ntap * p.ldw)) / 32 * 32;
+  if (nch < 32) {
+    rows = false;
+    nch = (int)((156 * 1024) / ((size_t)ntap * p.ldw)) / 32 * 32;
+  }
   if (nch > 32 * CV_MAXCT) nch = 32 * CV_MAXCT;
   if (nch < 32) return RDST_ENOTSUP;
   if (nch > npad) nch = npad;
   p.nch = nch;
-  const size_t smem = (size_t)ntap * nch * p.ldw;
+  p.eps_off = rows ? ntap * nch * p.ldw : -1;
+  const size_t smem = (size_t)ntap * nch * p.ldw + (rows ? 8 * 4096 : 0);
   const int64_t nslabs = (p.g.pixels() + 31) / 32;
   int64_t grid = (nslabs + 7) / 8;
   if (grid > 256) grid = 256;

@@ -17,3 +17,9 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
                       const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
                       hipStream_t st);
 size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N);
+// dgrad with the LayerNorm backward fused in (K <= 128): dX written/accumulated, d(gamma)/d(beta) partials in
+// slab[*nslab][2][K] for the caller to reduce
+template <typename T>
+int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
+                         int64_t lddy, T* dX, int64_t lddx, int accumulate, float* slab, int* nslab, int64_t M, int K,
+                         int N, float s, hipStream_t st);

@@ -273,6 +273,19 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
       if (int rc2 = gemm_valu_launch(la, lb, ep, N, K, M, kWgradSplits, st, "linear_wgrad")) return rc2;
       if (int rc2 = slab_reduce(slabW, dW, z, (int64_t)N * K, st)) return rc2;
     }
+    if (dX && ln_w) {  // fused dgrad + LayerNorm backward
+      int nslab = 0;
+      const int rc = linear_dgrad_ln_mfma<T>(X, ldx, stats, ln_w, Wt, dY, lddy, dX, lddx, accumulate, small, &nslab, M, K,
+                                             N, s, st);
+      if (rc == 0) {
+        float* out2 = small + (int64_t)kSmallBlocks * 2 * K;
+        if (int rc2 = slab_reduce(small, out2, nslab, 2 * K, st)) return rc2;
+        if (dln_w) (void)hipMemcpyAsync(dln_w, out2, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+        if (dln_b) (void)hipMemcpyAsync(dln_b, out2 + K, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+        return 0;
+      }
+      if (rc != RDST_ENOTSUP) return rc;
+    }
     if (dX) {
       int rc = linear_dgrad_mfma<T>(X, ldx, ln_w != nullptr, in_act, Wt, dY, lddy, dX, lddx, accumulate, dA, M, K, N, s, st);
       if (rc == RDST_ENOTSUP) {

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
   char* Ws = smem;
   float* gam = reinterpret_cast<float*>(smem + (size_t)p.nch * p.ldw);
   float* bet = gam + Tn * KP;
+  float* eps = bet + Tn * KP + wave * 1024;  // wave-private 32x32 fp32 epilogue tile
   const bool has_ln = (MODE == MODE_FWD) && p.lnw != nullptr;
   if (has_ln)
     for (int i = tid; i < Tn * KP; i += 512) {
@@ -156,32 +157,208 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
             MM::mma(acc, a[t], b);
           }
         const int col = n0 + ct * 32 + r;
-        if (col < p.Nout) {
-          const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[col] : 0.f;
+        const float bv = (MODE == MODE_FWD && p.bias && col < p.Nout) ? p.bias[col] : 0.f;
+        float vals[16];
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const int64_t rr = slab * 32 + acc_row(v, h);
-            if (rr < p.M) {
-              float val = acc[v];
-              if (MODE == MODE_FWD) {
-                val = (val + bv) * p.s;
-                if (p.R) val += to_f32<T>(p.R[rr * p.ldr + col]);
-                p.Y[rr * p.ldy + col] = from_f32<T>(val);
-              } else {
-                val *= p.s;
-                if (p.dA) {
-                  p.dA[rr * p.Nout + col] = val;
+        for (int v = 0; v < 16; ++v) vals[v] = (MODE == MODE_FWD) ? (acc[v] + bv) * p.s : acc[v] * p.s;
+        TileEpilogue ep{};
+        if (MODE == MODE_FWD) {
+          ep.R = p.R; ep.ldr = p.ldr; ep.Y = p.Y; ep.ldy = p.ldy;
+        } else if (p.dA) {
+          ep.Yf32 = p.dA; ep.ldf = p.Nout;
+        } else {
+          ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.accumulate = p.accumulate;
+        }
+        tile_store_rows<T>(eps, vals, lane, slab * 32, p.M, n0 + ct * 32, p.Nout, ep);
+      }
+    }
+  }
+}
+
+// ---- dgrad of a Linear that sits behind a LayerNorm, with the LayerNorm backward fused in ----------
+// dA = s * dY @ W  (32 x K tile set per slab, K <= 128) is never written: per slab the column tiles are
+// produced TWICE (the MFMAs are cheap, the kernel is HBM-bound): pass 1 bounces each tile through the
+// wave's LDS buffer and accumulates, row-major, s1 = sum_k dA*gamma, s2 = sum_k dA*gamma*xhat and the
+// per-column d(gamma) / d(beta) partials; pass 2 rebuilds the tile and stores
+//   dX = rstd * (gamma*dA - s1/K - xhat*s2/K)  (+ dX)
+// with 8-16-B row stores.  d(gamma), d(beta): one [2][K] slab row per workgroup, reduced in fixed order.
+template <typename T>
+struct LnDgradArgs {
+  const T* dY; int64_t lddy;      // (M, N)
+  const float* Wt; int N, K;      // nn.Linear weight (N, K)
+  const T* X; int64_t ldx; const float* stats; const float* gamma;
+  T* dX; int64_t lddx; int accumulate;
+  float* slab;                    // [grid][2][K]
+  int64_t M; float s;
+  int Tn, ldw;
+};
+
+template <typename T, int TMAX>
+__global__ void __launch_bounds__(512) lin_dgrad_ln_kernel(const LnDgradArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  constexpr int KP = MM::KP, HP = MM::HP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int Tn = p.Tn, K = p.K;
+  const int kpad = ((K + 31) / 32) * 32, nct = kpad / 32;
+  char* Ws = smem;                                                      // [kpad][ldw]: W^T rows (k), n-contiguous
+  float* eps = reinterpret_cast<float*>(smem + (size_t)kpad * p.ldw) + wave * 1024;
+  float* red = reinterpret_cast<float*>(smem + (size_t)kpad * p.ldw) + 8 * 1024;  // [8 waves][2][128]
+  for (int idx = tid; idx < kpad * 2 * Tn; idx += 512) {
+    const int k = idx / (2 * Tn), ph = idx - k * (2 * Tn);
+    const Pack16 w = pack_from_f32<T>(p.Wt + k, ph * HP, p.N, p.K, k < K);  // element n at Wt[n*K + k]
+    *reinterpret_cast<Pack16*>(Ws + (size_t)k * p.ldw + ph * 16) = w;
+  }
+  __syncthreads();
+  const int chunk = lane & 7;
+  float gam[4][4], dg[4][4], db[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = c * 32 + chunk * 4 + q;
+      gam[c][q] = col < K ? p.gamma[col] : 0.f;
+      dg[c][q] = 0.f;
+      db[c][q] = 0.f;
+    }
+  const float invK = 1.0f / (float)K;
+  const int64_t nslabs = (p.M + 31) / 32;
+  for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < nslabs; slab += (int64_t)gridDim.x * 8) {
+    const int64_t row = slab * 32 + r;
+    const bool valid = row < p.M;
+    const T* arow = p.dY + (valid ? row : 0) * p.lddy;
+    Pack16 a[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+      if (t < Tn) a[t] = load_pack<T>(arow, t * KP + h * HP, p.N, valid);
+    float s1[4], s2[4], mean[4], rstd[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int64_t rr = slab * 32 + (lane >> 3) + 8 * ps;
+      s1[ps] = 0.f; s2[ps] = 0.f;
+      mean[ps] = rr < p.M ? p.stats[2 * rr] : 0.f;
+      rstd[ps] = rr < p.M ? p.stats[2 * rr + 1] : 0.f;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nct) {
+          f32x16 acc;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+          const char* wrow = Ws + (size_t)(c * 32 + r) * p.ldw + h * 16;
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) {
+              const Pack16 b = *reinterpret_cast<const Pack16*>(wrow + t * 32);
+              MM::mma(acc, a[t], b);
+            }
+#pragma unroll
+          for (int v = 0; v < 16; ++v) eps[acc_row(v, h) * 32 + r] = acc[v] * p.s;
+          __builtin_amdgcn_wave_barrier();
+          const int col = c * 32 + chunk * 4;
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) {
+            const int rowl = (lane >> 3) + 8 * ps;
+            const int64_t rr = slab * 32 + rowl;
+            const float4 d4 = *reinterpret_cast<const float4*>(eps + rowl * 32 + chunk * 4);
+            if (rr < p.M && col < K) {
+              const float da[4] = {d4.x, d4.y, d4.z, d4.w};
+              float xh[4];
+              const T* xp = p.X + rr * p.ldx + col;
+              if (col + 4 <= K && (reinterpret_cast<uintptr_t>(xp) & 3) == 0) {
+                if (sizeof(T) == 2) {
+                  const u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(xp);
+                  xh[0] = bf16lo(u.x); xh[1] = bf16hi(u.x); xh[2] = bf16lo(u.y); xh[3] = bf16hi(u.y);
                 } else {
-                  if (p.in_act) val *= act_grad(to_f32<T>(p.Xa[rr * p.ldxa + col]), p.in_act);
-                  if (p.accumulate) val += to_f32<T>(p.Y[rr * p.ldy + col]);
-                  p.Y[rr * p.ldy + col] = from_f32<T>(val);
+                  const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(xp);
+                  xh[0] = __uint_as_float(u.x); xh[1] = __uint_as_float(u.y); xh[2] = __uint_as_float(u.z); xh[3] = __uint_as_float(u.w);
+                }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xh[q] = col + q < K ? to_f32<T>(xp[q]) : 0.f;
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) xh[q] = (col + q < K) ? (xh[q] - mean[ps]) * rstd[ps] : 0.f;
+              if (pass == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float gq = da[q] * gam[c][q];
+                  s1[ps] += gq;
+                  s2[ps] = fmaf(gq, xh[q], s2[ps]);
+                  dg[c][q] = fmaf(da[q], xh[q], dg[c][q]);
+                  db[c][q] += da[q];
+                }
+              } else {
+                float f[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] = rstd[ps] * (da[q] * gam[c][q] - s1[ps] - xh[q] * s2[ps]);
+                T* dst = p.dX + rr * p.lddx + col;
+                const bool vec = col + 4 <= K && (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
+                if (p.accumulate) {
+                  if (vec && sizeof(T) == 2) {
+                    const u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(dst);
+                    f[0] += bf16lo(u.x); f[1] += bf16hi(u.x); f[2] += bf16lo(u.y); f[3] += bf16hi(u.y);
+                  } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (col + q < K) f[q] += to_f32<T>(dst[q]);
+                  }
+                }
+                if (vec && sizeof(T) == 2) {
+                  u32x2_a4 u;
+                  u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+                  *reinterpret_cast<u32x2_a4*>(dst) = u;
+                } else if (vec) {
+                  u32x4_a4 u;
+                  u.x = __float_as_uint(f[0]); u.y = __float_as_uint(f[1]); u.z = __float_as_uint(f[2]); u.w = __float_as_uint(f[3]);
+                  *reinterpret_cast<u32x4_a4*>(dst) = u;
+                } else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) if (col + q < K) dst[q] = from_f32<T>(f[q]);
                 }
               }
             }
           }
+          __builtin_amdgcn_wave_barrier();
+        }
+      if (pass == 0) {
+        // finish the row sums: the 8 lanes that share a row differ in lane bits 0..2
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+#pragma unroll
+          for (int o = 1; o < 8; o <<= 1) {
+            s1[ps] += __shfl_xor(s1[ps], o, 64);
+            s2[ps] += __shfl_xor(s2[ps], o, 64);
+          }
+          s1[ps] *= invK;
+          s2[ps] *= invK;
         }
       }
     }
+  }
+  // d(gamma), d(beta): lanes with equal `chunk` own the same columns -> reduce over lane bits 3..5, then waves
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        dg[c][q] += __shfl_xor(dg[c][q], o, 64);
+        db[c][q] += __shfl_xor(db[c][q], o, 64);
+      }
+      if (lane < 8) {
+        red[(wave * 2 + 0) * 128 + c * 32 + chunk * 4 + q] = dg[c][q];
+        red[(wave * 2 + 1) * 128 + c * 32 + chunk * 4 + q] = db[c][q];
+      }
+    }
+  __syncthreads();
+  for (int i = tid; i < 2 * K; i += 512) {
+    const int which = i / K, k = i - which * K;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[(w * 2 + which) * 128 + k];
+    p.slab[(int64_t)blockIdx.x * 2 * K + i] = a;
   }
 }
 
@@ -192,14 +369,15 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   if (p.Tn > 32) return RDST_ENOTSUP;
   p.ldw = lds_row_bytes(p.Kc, sizeof(T));
   const int npad = ((p.Nout + 31) / 32) * 32;
-  int nch = (128 * 1024 / p.ldw) / 32 * 32;
+  int nch = ((125 * 1024) / p.ldw) / 32 * 32;  // + 32 KB for the 8 epilogue tiles stays under 160 KB
   if (nch < 32) return RDST_ENOTSUP;
   if (nch > npad) nch = npad;
   p.nch = nch;
-  const size_t smem = (size_t)nch * p.ldw + (size_t)2 * p.Tn * MM::KP * sizeof(float);
+  const size_t smem = (size_t)nch * p.ldw + (size_t)2 * p.Tn * MM::KP * sizeof(float) + 8 * 4096;
   const int64_t nslabs = (p.M + 31) / 32;
   int64_t grid = (nslabs + 7) / 8;
-  if (grid > 256) grid = 256;
+  const int64_t cap = smem <= 78 * 1024 ? 512 : 256;  // two co-resident 8-wave workgroups per CU when LDS allows
+  if (grid > cap) grid = cap;
 #define RDST_LIN_LAUNCH(TM)                                                                                          \
   {                                                                                                                  \
     auto kern = lin_mfma_kernel<T, TM, MODE>;                                                                        \
@@ -248,39 +426,73 @@ __global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> 
   const int64_t m_end = (m_begin + p.rows_per_wg < p.M) ? m_begin + p.rows_per_wg : p.M;
   const int npk = p.NT * 32 / HP, kpk = p.KT * 32 / HP;
 
+  // Per-thread staging plan (loop invariant): which (stripe row, pack) of dY / X this thread moves.
+  constexpr int DYMAX = 24 / HP, XMAX = 16 / HP;  // 32 rows x (NT*32 <= 384 | KT*32 <= 256) elements over 512 threads
+  int dy_row[DYMAX], dy_pk[DYMAX], x_row[XMAX], x_pk[XMAX];
+#pragma unroll
+  for (int i = 0; i < DYMAX; ++i) {
+    const int idx = tid + 512 * i;
+    dy_row[i] = idx < WG_STRIPE * npk ? idx / npk : -1;
+    dy_pk[i] = idx - (idx / npk) * npk;
+  }
+#pragma unroll
+  for (int i = 0; i < XMAX; ++i) {
+    const int idx = tid + 512 * i;
+    x_row[i] = idx < WG_STRIPE * kpk ? idx / kpk : -1;
+    x_pk[i] = idx - (idx / kpk) * kpk;
+  }
+  Pack16 rdy[DYMAX], rx[XMAX];
+  float rmean[XMAX], rrstd[XMAX];
+  auto prefetch = [&](int64_t m0) {
+#pragma unroll
+    for (int i = 0; i < DYMAX; ++i)
+      if (dy_row[i] >= 0) {
+        const bool valid = m0 + dy_row[i] < m_end;
+        rdy[i] = load_pack<T>(p.dY + (valid ? (m0 + dy_row[i]) : 0) * p.lddy, dy_pk[i] * HP, p.N, valid);
+      }
+#pragma unroll
+    for (int i = 0; i < XMAX; ++i)
+      if (x_row[i] >= 0) {
+        const int64_t m = m0 + x_row[i];
+        const bool valid = m < m_end;
+        rx[i] = load_pack<T>(p.X + (valid ? m : 0) * p.ldx, x_pk[i] * HP, p.K, valid);
+        if (p.lnw) {
+          rmean[i] = valid ? p.stats[2 * m] : 0.f;
+          rrstd[i] = valid ? p.stats[2 * m + 1] : 0.f;
+        }
+      }
+  };
+  if (m_begin < m_end) prefetch(m_begin);
+
   for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_STRIPE) {
-    __syncthreads();
-    for (int idx = tid; idx < WG_STRIPE * npk; idx += 512) {
-      const int row = idx / npk, pk = idx - row * npk;
-      const bool valid = m0 + row < m_end;
-      const Pack16 v = load_pack<T>(p.dY + (valid ? (m0 + row) : 0) * p.lddy, pk * HP, p.N, valid);
-      *reinterpret_cast<Pack16*>(dYs + (size_t)row * p.ldn + pk * 16) = v;
-    }
-    for (int idx = tid; idx < WG_STRIPE * kpk; idx += 512) {
-      const int row = idx / kpk, pk = idx - row * kpk;
-      const int64_t m = m0 + row;
-      const bool valid = m < m_end;
-      const int k0 = pk * HP;
-      Pack16 v = load_pack<T>(p.X + (valid ? m : 0) * p.ldx, k0, p.K, valid);
-      float f[HP];
-      MM::unpack(v, f);
-      if (p.lnw) {
-        const float mean = valid ? p.stats[2 * m] : 0.f, rstd = valid ? p.stats[2 * m + 1] : 0.f;
+    __syncthreads();  // previous stripe's MFMAs are done with the LDS tiles
 #pragma unroll
-        for (int e = 0; e < HP; ++e)
-          f[e] = (k0 + e < p.K) ? (f[e] - mean) * rstd * p.lnw[k0 + e] + p.lnb[k0 + e] : 0.f;
-      } else if (p.in_act) {
+    for (int i = 0; i < DYMAX; ++i)
+      if (dy_row[i] >= 0) *reinterpret_cast<Pack16*>(dYs + (size_t)dy_row[i] * p.ldn + dy_pk[i] * 16) = rdy[i];
 #pragma unroll
-        for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+    for (int i = 0; i < XMAX; ++i)
+      if (x_row[i] >= 0) {
+        const bool valid = m0 + x_row[i] < m_end;
+        const int k0 = x_pk[i] * HP;
+        float f[HP];
+        MM::unpack(rx[i], f);
+        if (p.lnw) {
+#pragma unroll
+          for (int e = 0; e < HP; ++e)
+            f[e] = (k0 + e < p.K) ? (f[e] - rmean[i]) * rrstd[i] * p.lnw[k0 + e] + p.lnb[k0 + e] : 0.f;
+        } else if (p.in_act) {
+#pragma unroll
+          for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+        }
+#pragma unroll
+        for (int e = 0; e < HP; ++e) {
+          if (!valid) f[e] = 0.f;
+          else if (k0 + e == p.K) f[e] = 1.0f;  // ones column: dW[:, K] = sum_m dY = d(bias)
+        }
+        *reinterpret_cast<Pack16*>(Xs + (size_t)x_row[i] * p.ldk + x_pk[i] * 16) = MM::pack(f);
       }
-#pragma unroll
-      for (int e = 0; e < HP; ++e) {
-        if (!valid) f[e] = 0.f;
-        else if (k0 + e == p.K) f[e] = 1.0f;  // ones column: dW[:, K] = sum_m dY = d(bias)
-      }
-      *reinterpret_cast<Pack16*>(Xs + (size_t)row * p.ldk + pk * 16) = MM::pack(f);
-    }
     __syncthreads();
+    if (m0 + WG_STRIPE < m_end) prefetch(m0 + WG_STRIPE);  // in flight while this stripe is multiplied
 #pragma unroll
     for (int j = 0; j < WG_MAXT; ++j) {
       const int ti = wave + 8 * j;
@@ -384,6 +596,38 @@ int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const fl
   return launch_lin<T, MODE_DGRAD>(p, st, "lin_dgrad_mfma");
 }
 
+// dgrad + LayerNorm backward in one kernel; writes dX and a [*nslab][2][K] slab of d(gamma)/d(beta) partials
+template <typename T>
+int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
+                         int64_t lddy, T* dX, int64_t lddx, int accumulate, float* slab, int* nslab, int64_t M, int K,
+                         int N, float s, hipStream_t st) {
+  using MM = Mma<T>;
+  if (mfma_disabled() || K > 128 || !dX) return RDST_ENOTSUP;
+  LnDgradArgs<T> p{};
+  p.dY = dY; p.lddy = lddy; p.Wt = Wt; p.N = N; p.K = K; p.X = X; p.ldx = ldx; p.stats = stats; p.gamma = gamma;
+  p.dX = dX; p.lddx = lddx; p.accumulate = accumulate; p.slab = slab; p.M = M; p.s = s;
+  p.Tn = (N + MM::KP - 1) / MM::KP;
+  if (p.Tn > 32) return RDST_ENOTSUP;
+  p.ldw = lds_row_bytes(N, sizeof(T));
+  const int kpad = ((K + 31) / 32) * 32;
+  const size_t smem = (size_t)kpad * p.ldw + 8 * 4096 + 8 * 2 * 128 * sizeof(float);
+  if (smem > 160 * 1024) return RDST_ENOTSUP;
+  const int64_t nslabs = (M + 31) / 32;
+  int64_t grid = (nslabs + 7) / 8;
+  const int64_t cap = smem <= 78 * 1024 ? 512 : 256;
+  if (grid > cap) grid = cap;
+  *nslab = (int)grid;
+#define RDST_LND_LAUNCH(TM)                                                                                          \
+  {                                                                                                                  \
+    auto kern = lin_dgrad_ln_kernel<T, TM>;                                                                          \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);                                          \
+  }
+  if (p.Tn <= 8) RDST_LND_LAUNCH(8) else if (p.Tn <= 16) RDST_LND_LAUNCH(16) else RDST_LND_LAUNCH(32)
+#undef RDST_LND_LAUNCH
+  return rdst_launch_status("lin_dgrad_ln_mfma");
+}
+
 size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N) {
   (void)M;
   return (size_t)256 * N * (K + 1);
@@ -398,7 +642,7 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   p.X = X; p.ldx = ldx; p.lnw = ln_w; p.lnb = ln_b; p.stats = stats; p.in_act = in_act; p.dY = dY; p.lddy = lddy;
   p.slab = slab; p.M = M; p.K = K; p.N = N; p.Kx = K + 1;
   p.NT = (N + 31) / 32; p.KT = (p.Kx + 31) / 32;
-  if (p.NT * p.KT > 8 * WG_MAXT) return RDST_ENOTSUP;
+  if (p.NT * p.KT > 8 * WG_MAXT || p.NT > 12 || p.KT > 8) return RDST_ENOTSUP;
   // LDS row strides: bf16 rows are read by ds_read_b64_tr_b16 (4 token rows x 64 B per 32 lanes):
   // stride = 64 (mod 256) bytes puts the 4 rows on disjoint bank ranges; fp32 rows are read 32
   // consecutive floats at a time, any stride works.
@@ -425,6 +669,8 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
 }
 
 #define INST(T)                                                                                                        \
+  template int linear_dgrad_ln_mfma<T>(const T*, int64_t, const float*, const float*, const float*, const T*, int64_t, \
+                                       T*, int64_t, int, float*, int*, int64_t, int, int, float, hipStream_t);         \
   template int linear_fwd_mfma<T>(const T*, int64_t, const float*, const float*, int, const float*, const float*,     \
                                   const T*, int64_t, T*, int64_t, float*, int64_t, int, int, float, hipStream_t);     \
   template int linear_dgrad_mfma<T>(const T*, int64_t, bool, int, const float*, const T*, int64_t, T*, int64_t, int,  \

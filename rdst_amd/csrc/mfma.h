@@ -114,3 +114,85 @@ static inline int lds_row_bytes(int kelems, int esize) {
   const int b = ((kelems * esize + 31) / 32) * 32;
   return b + 16;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Row-wise epilogue for a 32x32 accumulator tile.
+// In the C/D layout a lane owns ONE column, so storing from the accumulators writes 2-4 bytes per
+// lane (128-256 B per store instruction) and the kernel becomes store-ISSUE-bound (~1.2 TB/s measured).
+// Instead each wave bounces the tile through a private 32x32 fp32 LDS buffer (row stride 128 B: the two
+// rows of a ds_read_b128 lane group fill the 64 banks exactly) and finishes it row-major: lane ->
+// (row = lane>>3 + 8*pass, 4 consecutive columns), with the residual / activation-gradient / accumulate
+// operands read as 8-16-B row segments and the result stored 8 B (bf16) or 16 B (fp32) per lane.
+// DS operations of one wave execute in order, so no barrier is needed around the bounce.
+struct TileEpilogue {
+  const void* R; int64_t ldr;        // + R[row][col]                        (forward residual)
+  const void* Xa; int64_t ldxa; int act;  // * act'(Xa[row][col])            (dgrad through an input activation)
+  void* Y; int64_t ldy; int accumulate;   // Y (+)= value
+  float* Yf32; int64_t ldf;          // alternative fp32 destination (dgrad in front of a LayerNorm)
+};
+
+template <typename T>
+__device__ __forceinline__ void tile_store_rows(float* __restrict__ eps, const float (&vals)[16], int lane, int64_t row0,
+                                                int64_t M, int col0, int N, const TileEpilogue& e) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) eps[acc_row(v, h) * 32 + r] = vals[v];
+  __builtin_amdgcn_wave_barrier();
+  const int chunk = lane & 7, col = col0 + chunk * 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = (lane >> 3) + 8 * pass;
+    const int64_t rr = row0 + row;
+    const float4 f4 = *reinterpret_cast<const float4*>(eps + row * 32 + chunk * 4);
+    if (rr < M && col < N) {
+      float f[4] = {f4.x, f4.y, f4.z, f4.w};
+      const bool full = col + 4 <= N;
+      if (e.Yf32) {
+        float* dst = e.Yf32 + rr * e.ldf + col;
+        if (full && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) *reinterpret_cast<float4*>(dst) = f4;
+        else
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (col + q < N) dst[q] = f[q];
+        continue;
+      }
+      T* dst = reinterpret_cast<T*>(e.Y) + rr * e.ldy + col;
+      const T* rp = e.R ? reinterpret_cast<const T*>(e.R) + rr * e.ldr + col : nullptr;
+      const T* xp = (e.Xa && e.act) ? reinterpret_cast<const T*>(e.Xa) + rr * e.ldxa + col : nullptr;
+      auto add4 = [&](const T* src, bool mul_actgrad) {
+        float g[4];
+        if (full && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+          if (sizeof(T) == 2) {
+            const u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(src);
+            g[0] = bf16lo(u.x); g[1] = bf16hi(u.x); g[2] = bf16lo(u.y); g[3] = bf16hi(u.y);
+          } else {
+            const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(src);
+            g[0] = __uint_as_float(u.x); g[1] = __uint_as_float(u.y); g[2] = __uint_as_float(u.z); g[3] = __uint_as_float(u.w);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) g[q] = (col + q < N) ? to_f32<T>(src[q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f[q] = mul_actgrad ? f[q] * act_grad(g[q], e.act) : f[q] + g[q];
+      };
+      if (xp) add4(xp, true);
+      if (rp) add4(rp, false);
+      if (e.accumulate) add4(dst, false);
+      if (full && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        if (sizeof(T) == 2) {
+          u32x2_a4 u;
+          u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+          *reinterpret_cast<u32x2_a4*>(dst) = u;
+        } else {
+          u32x4_a4 u;
+          u.x = __float_as_uint(f[0]); u.y = __float_as_uint(f[1]); u.z = __float_as_uint(f[2]); u.w = __float_as_uint(f[3]);
+          *reinterpret_cast<u32x4_a4*>(dst) = u;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (col + q < N) dst[q] = from_f32<T>(f[q]);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
