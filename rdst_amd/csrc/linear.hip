@@ -7,23 +7,29 @@
 #include "gemm_valu.h"
 #include "linear.h"
 
-// out[i] = sum_s slab[s*n + i]: 64 outputs x 4 slab-groups per block, fixed order => reproducible
+// out[i] = sum_s slab[s*n + i]: 16 outputs x 16 slab-groups per block (short dependent chains: these
+// reductions are latency-bound), fixed summation order => reproducible
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           int S, int64_t n) {
-  __shared__ float part[4][64];
-  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + o;
+  __shared__ float part[16][17];
+  const int o = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + o;
   float a = 0.f;
   if (i < n)
-    for (int s = sg; s < S; s += 4) a += slab[(int64_t)s * n + i];
+    for (int s = sg; s < S; s += 16) a += slab[(int64_t)s * n + i];
   part[sg][o] = a;
   __syncthreads();
-  if (sg == 0 && i < n) out[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+  if (sg == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][o];
+    out[i] = t;
+  }
 }
 
 int slab_reduce(const float* slab, float* out, int S, int64_t n, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, out, S, n);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, slab, out, S, n);
   return rdst_launch_status("slab_reduce");
 }
 

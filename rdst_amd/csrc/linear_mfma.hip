@@ -553,17 +553,19 @@ __global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> 
 // dW[n][k] = s * sum_wg slab[wg][n][k] (k < K);  dbias[n] = s * sum_wg slab[wg][n][K]
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int N, int K, int Kx,
                                                            float s, float* __restrict__ dW, float* __restrict__ dbias) {
-  __shared__ float part[4][64];
-  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;
+  __shared__ float part[8][33];
+  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
   const int tot = N * Kx;
   float a = 0.f;
   if (i < tot)
-    for (int w = sg; w < nwg; w += 4) a += slab[(int64_t)w * tot + i];
+    for (int w = sg; w < nwg; w += 8) a += slab[(int64_t)w * tot + i];
   part[sg][o] = a;
   __syncthreads();
   if (sg != 0 || i >= tot) return;
-  a = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+  a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a += part[k][o];
   const int n = i / Kx, k = i - n * Kx;
   if (k < K) {
     if (dW) dW[(int64_t)n * K + k] = a * s;
@@ -664,7 +666,7 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), smem, st, p);
   if (int rc = rdst_launch_status("lin_wgrad_mfma")) return rc;
   const int tot = N * p.Kx;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
   return rdst_launch_status("wgrad_reduce");
 }
 

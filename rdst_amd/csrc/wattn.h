@@ -23,6 +23,15 @@ __device__ __forceinline__ int64_t win_token(int b, int wr, int wc, int t, const
   return ((int64_t)b * g.H + r) * g.W + c;
 }
 
+// Same for 8x8 windows (shifts instead of divisions; the MFMA kernels only handle ws == 8).
+__device__ __forceinline__ int64_t win_token8(int b, int wr, int wc, int t, const WinGeom& g) {
+  int r = wr * 8 + (t >> 3) + g.shift;
+  if (r >= g.H) r -= g.H;
+  int c = wc * 8 + (t & 7) + g.shift;
+  if (c >= g.W) c -= g.W;
+  return ((int64_t)b * g.H + r) * g.W + c;
+}
+
 // Region id (0..8) of a token of the SHIFTED image: networks/swin_transformer_sr.py:215-225.
 // Tokens of one window with different ids are masked with -100 (:227-230).
 __device__ __forceinline__ int win_region(int wr, int wc, int t, const WinGeom& g) {

@@ -45,6 +45,7 @@ struct WbArgs {
   WinGeom g;
   float scale;
   int d, ldt;
+  int dbg;  // ablation switches (RDST_K2_DEBUG): 1 = skip d(table) atomics, 2 = skip pass T, 4 = skip pass N
 };
 
 __device__ __forceinline__ uint32_t mask_bits_bf16(int c0, int lo, int hi) {
@@ -159,6 +160,14 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
   const int yl = t * 4 + (r >> 3), xl = r & 7;  // window coords of this lane's token (tile t)
   const bool fyl = yl < thr, fxl = xl < thr;
 
+  // d(table): dS^T summed element-wise over all windows of this workgroup in registers (LDS float atomics
+  // cost ~180 cycles per wave-instruction: 230 of 370 us when issued per window); binned once at the end.
+  f32x16 Dsum[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) Dsum[kt][v] = 0.f;
+
   for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
     const int b = win / nW, wi = win - b * nW;
     const int wr = wi / g.nWw, wc = wi - wr * g.nWw;
@@ -170,7 +179,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
       for (int i = 0; i < MAXR; ++i) {
         int row = wv + NWAVES * i;
         row = row < 64 ? row : 63;
-        const int64_t tok = win_token(b, wr, wc, row, g);
+        const int64_t tok = win_token8(b, wr, wc, row, g);
         const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
 
     // ================= pass T: keys on registers, query (tile t) on the lane ======================
-    {
+    if (!(p.dbg & 2)) {
       f32x16 X[2], D[2];
       const float* tb = tabL + hd * 15 * TS + (yl + 7) * TS + (xl + 7) - 4 * h;
 #pragma unroll
@@ -275,14 +284,13 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         }
       dl += __shfl_xor(dl, 32, 64);              // delta_i
       if (h == 0) stats[hd * 64 + t * 32 + r] = make_float4(m, inv, dl, 0.f);
-      float* dtb = dtabL + (tb - tabL);
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const float ds = X[kt][v] * (D[kt][v] - dl);  // dS^T
           D[kt][v] = ds;
-          atomicAdd(&dtb[-((kt * 4 + (v >> 2)) * TS + (v & 3))], ds);
+          Dsum[kt][v] += ds;
         }
       // dQ_h (tile t) = scale * (dS^T)^T K_h
       for (int ct = ct_lo; ct <= ct_hi; ++ct) {
@@ -302,7 +310,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
     __syncthreads();  // statistics of both query tiles are in LDS
 
     // ================= pass N: queries on registers, key (tile t) on the lane ======================
-    {
+    if (!(p.dbg & 4)) {
       f32x16 Y[2], E[2];
       const float* tb = tabL + hd * 15 * TS + (7 - yl) * TS + (7 - xl) + 4 * h;
 #pragma unroll
@@ -346,18 +354,27 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
       for (int ct = ct_lo; ct <= ct_hi; ++ct) {
         const int col = ct * 32 + r;
         const bool colin = col >= c_lo && col < c_hi;
-        f32x16 av, ak;
+        const float kfix = BF ? LN2 : 1.0f;
+        {
+          f32x16 av;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) { av[v] = 0.f; ak[v] = 0.f; }
-        acc_xt_b<T>(av, Y, Os, ldt, ct, colin, lane);   // dV_h = P^T dO_h
-        acc_xt_b<T>(ak, E, Qs, ldt, ct, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
-        if (colin) {
-          const float kfix = BF ? LN2 : 1.0f;
+          for (int v = 0; v < 16; ++v) av[v] = 0.f;
+          acc_xt_b<T>(av, Y, Os, ldt, ct, colin, lane);   // dV_h = P^T dO_h
+          if (colin) {
 #pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const size_t ro = (size_t)(t * 32 + acc_row(v, h)) * ldt;
-            *(reinterpret_cast<T*>(dVs + ro) + col) = from_f32<T>(av[v]);
-            *(reinterpret_cast<T*>(dKs + ro) + col) = from_f32<T>(ak[v] * kfix);
+            for (int v = 0; v < 16; ++v)
+              *(reinterpret_cast<T*>(dVs + (size_t)(t * 32 + acc_row(v, h)) * ldt) + col) = from_f32<T>(av[v]);
+          }
+        }
+        {
+          f32x16 ak;
+#pragma unroll
+          for (int v = 0; v < 16; ++v) ak[v] = 0.f;
+          acc_xt_b<T>(ak, E, Qs, ldt, ct, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
+          if (colin) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+              *(reinterpret_cast<T*>(dKs + (size_t)(t * 32 + acc_row(v, h)) * ldt) + col) = from_f32<T>(ak[v] * kfix);
           }
         }
       }
@@ -365,7 +382,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
     __syncthreads();
     // ---- LDS -> HBM: dqkv rows = [dQ | dK | dV] -------------------------------------------------------
     for (int row = wv; row < 64; row += NWAVES) {
-      const int64_t tok = win_token(b, wr, wc, row, g);
+      const int64_t tok = win_token8(b, wr, wc, row, g);
       char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq);
       for (int c = lane; c < per_row; c += 64) {
         const int off = c * GRAN;
@@ -373,6 +390,13 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         *reinterpret_cast<CH*>(dst + off) = *reinterpret_cast<const CH*>(dQs + sec * (secsz - secb) + row * ldt + off);
       }
     }
+  }
+  {
+    float* dtb = dtabL + hd * 15 * TS + (yl + 7) * TS + (xl + 7) - 4 * h;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) atomicAdd(&dtb[-((kt * 4 + (v >> 2)) * TS + (v & 3))], Dsum[kt][v]);
   }
   __syncthreads();
   float* my = p.slab + (int64_t)blockIdx.x * HEADS * 225;
@@ -400,6 +424,7 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
   WbArgs<T> p{};
   p.qkv = qkv; p.ld = ld; p.table = table; p.dout = dout; p.ldd = ldd; p.dqkv = dqkv; p.ldq = ldq; p.slab = slab;
   p.g = g; p.scale = scale; p.d = d;
+  { const char* e = getenv("RDST_K2_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const int sec = g.C * (int)sizeof(T);
   int gran = 0;
   for (int gs = 16; gs >= 4; gs >>= 1) {

@@ -33,6 +33,7 @@ struct WaArgs {
   int d;          // head dim
   int ldt;        // LDS row stride of each Q/K/V section, bytes
   int gran;       // copy granule in bytes (16, 8 or 4)
+  int dbg;        // ablation switches (RDST_K1_DEBUG): 1 = skip compute, 2 = skip HBM loads, 4 = skip HBM stores
 };
 
 __device__ __forceinline__ uint32_t mask_bits_bf16(int c0, int lo, int hi) {
@@ -102,13 +103,28 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
   for (; win < nwin; win += gridDim.x) {
     const int b = win / nW, wi = win - b * nW;
     const int wr = wi / g.nWw, wc = wi - wr * g.nWw;
+    // token rows of this wave: window rows y = 2*wv, 2*wv+1 (8 tokens each).  Row index of token (y, x):
+    // rowbase(y) + col(x), col(x) = c0 + x (- W when it wraps: only the last window column of a shifted block)
+    const int c0 = wc * 8 + g.shift;
+    int64_t rbase[2];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      CH regs[8][ITERS];
+    for (int yy = 0; yy < 2; ++yy) {
+      int rr = wr * 8 + wv * 2 + yy + g.shift;
+      if (rr >= g.H) rr -= g.H;
+      rbase[yy] = ((int64_t)b * g.H + rr) * g.W;
+    }
+    constexpr int NPART = ITERS >= 3 ? 4 : 2;   // stage the wave's 16 token rows in parts to bound the staging registers
+    constexpr int RPP = 16 / NPART;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = wv * 16 + half * 8 + i;
-        const char* src = reinterpret_cast<const char*>(p.qkv + win_token(b, wr, wc, row, g) * p.ld);
+    for (int part = 0; part < NPART; ++part) {
+      CH regs[RPP][ITERS];
+#pragma unroll
+      for (int i = 0; i < RPP; ++i) {
+        const int ri = part * RPP + i;          // 0..15 within the wave
+        int col = c0 + (ri & 7);
+        if (col >= g.W) col -= g.W;
+        const int64_t tok = (p.dbg & 2) ? 0 : rbase[ri >> 3] + col;
+        const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           int c = lane + 64 * it;
@@ -116,17 +132,28 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
           regs[i][it] = *reinterpret_cast<const CH*>(src + (size_t)c * GRAN);
         }
       }
-      if (half == 0) __syncthreads();  // previous window's O has been copied out; the tile may be overwritten
+      if (part == 0) __syncthreads();  // previous window's O has been copied out; the tile may be overwritten
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = wv * 16 + half * 8 + i;
+      for (int i = 0; i < RPP; ++i) {
+        const int row = wv * 16 + part * RPP + i;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           const int c = lane + 64 * it;
           if (c < per_row) {
             const int off = c * GRAN;
             const int sec = (off >= secb) + (off >= 2 * secb);
-            *reinterpret_cast<CH*>(smem + sec * (64 * ldt - secb) + row * ldt + off) = regs[i][it];
+            CH v = regs[i][it];
+            if (sec == 0) {  // Q <- Q * scale (* log2 e): the bias can then be the initial accumulator
+              uint32_t w[GRAN / 4];
+              __builtin_memcpy(w, &v, GRAN);
+#pragma unroll
+              for (int e = 0; e < GRAN / 4; ++e) {
+                if (BF) w[e] = pack_bf16x2(bf16lo(w[e]) * qscale, bf16hi(w[e]) * qscale);
+                else w[e] = __float_as_uint(__uint_as_float(w[e]) * qscale);
+              }
+              __builtin_memcpy(&v, w, GRAN);
+            }
+            *reinterpret_cast<CH*>(smem + sec * (64 * ldt - secb) + row * ldt + off) = v;
           }
         }
       }
@@ -135,14 +162,15 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
 
     const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
-    for (int hd = hg; hd < heads; hd += 2) {
+    for (int hd = hg; hd < ((p.dbg & 1) ? 0 : heads); hd += 2) {
       const int c_lo = hd * d, c_hi = c_lo + d;
       const int t_lo = c_lo / KP, t_hi = (c_hi - 1) / KP;
       f32x16 X[2];
+      const float* tb = tabL + hd * 15 * TS + (yi + 7) * TS + (xi + 7) - 4 * h;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) X[kt][v] = 0.f;
+        for (int v = 0; v < 16; ++v) X[kt][v] = tb[-((kt * 4 + (v >> 2)) * TS + (v & 3))];  // bias = initial accumulator
       for (int t = t_lo; t <= t_hi; ++t) {
         const int c0 = t * KP + h * HP;
         Pack16 qb = *reinterpret_cast<const Pack16*>(Qs + (size_t)(qt * 32 + r) * ldt + (size_t)c0 * sizeof(T));
@@ -159,47 +187,52 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
           MM::mma(X[kt], ka, qb);
         }
       }
-      // X[kt][v] = S^T[key j = kt*32 + acc_row(v,h)][query i = qt*32 + r]  (unscaled)
-      const float* tb = tabL + hd * 15 * TS + (yi + 7) * TS + (xi + 7) - 4 * h;
-      float m = -INFINITY;
+      // X[kt][v] = logit (log2 domain in bf16 mode) of key j = kt*32 + acc_row(v,h), query i = qt*32 + r
       if (masked) {  // wave-uniform: only the last window row / column of a shifted block
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
-            float x = fmaf(X[kt][v], qscale, tb[-((kt * 4 + (v >> 2)) * TS + (v & 3))]);
             const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
-            const bool diff = (mrow && (fyi != (yj < thr))) || (mcol && (fxi != (xj < thr)));
-            x += diff ? NEG : 0.f;
-            X[kt][v] = x;
-            m = fmaxf(m, x);
-          }
-      } else {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int v = 0; v < 16; ++v) {
-            const float x = fmaf(X[kt][v], qscale, tb[-((kt * 4 + (v >> 2)) * TS + (v & 3))]);
-            X[kt][v] = x;
-            m = fmaxf(m, x);
+            const bool dyf = mrow & (fyi != (yj < thr)), dxf = mcol & (fxi != (xj < thr));
+            X[kt][v] += (dyf | dxf) ? NEG : 0.f;
           }
       }
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
-      float l = 0.f;
+      float m = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const float e = BF ? __builtin_amdgcn_exp2f(X[kt][v] - m) : expf(X[kt][v] - m);
-          X[kt][v] = e;
-          l += e;
+        for (int v = 0; v < 16; ++v) m = fmaxf(m, X[kt][v]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 l2 = {0.f, 0.f};
+      const f32x2 m2 = {m, m};
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+          f32x2 x2 = {X[kt][v], X[kt][v + 1]};
+          x2 -= m2;                                   // v_pk_add_f32
+          f32x2 e2;
+          e2.x = BF ? __builtin_amdgcn_exp2f(x2.x) : expf(x2.x);
+          e2.y = BF ? __builtin_amdgcn_exp2f(x2.y) : expf(x2.y);
+          l2 += e2;
+          X[kt][v] = e2.x;
+          X[kt][v + 1] = e2.y;
         }
+      float l = l2.x + l2.y;
       l += __shfl_xor(l, 32, 64);
       const float inv = 1.0f / l;
+      const f32x2 inv2 = {inv, inv};
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) X[kt][v] *= inv;
+        for (int v = 0; v < 16; v += 2) {
+          f32x2 p2 = {X[kt][v], X[kt][v + 1]};
+          p2 *= inv2;                                  // v_pk_mul_f32
+          X[kt][v] = p2.x;
+          X[kt][v + 1] = p2.y;
+        }
 
       // O_h = P V_h over the column tiles that overlap the head
       const int ct_lo = c_lo / 32, ct_hi = (c_hi - 1) / 32;
@@ -209,6 +242,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
         const int col = ct * 32 + r;
         const bool colin = col >= c_lo && col < c_hi;
+        const uint32_t cmask = colin ? 0xffffffffu : 0u;
         if constexpr (BF) {
           const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
           const int colB = ct * 32 + 16 * (gq & 1) + 4 * pp;
@@ -226,8 +260,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
               const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Vs + (size_t)(rowb + 8) * ldt + colB * 2));
               const uint2 u0 = __builtin_bit_cast(uint2, b0), u1 = __builtin_bit_cast(uint2, b1);
               Pack16 bb;
-              bb.w[0] = colin ? u0.x : 0u; bb.w[1] = colin ? u0.y : 0u;
-              bb.w[2] = colin ? u1.x : 0u; bb.w[3] = colin ? u1.y : 0u;
+              bb.w[0] = u0.x & cmask; bb.w[1] = u0.y & cmask; bb.w[2] = u1.x & cmask; bb.w[3] = u1.y & cmask;
               MM::mma(acc, a, bb);
             }
         } else {
@@ -253,12 +286,16 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
     }
     __syncthreads();
     // LDS (Q section now holds O) -> global rows: wave w copies rows w, w+4, ...; no divisions
-    for (int row = wave; row < 64; row += 4) {
-      const int64_t tok = win_token(b, wr, wc, row, g);
-      char* dst = reinterpret_cast<char*>(p.out + tok * p.ldo);
-      const char* src = Qs + (size_t)row * ldt;
-      for (int ch = lane; ch < cps; ch += 64)
-        *reinterpret_cast<CH*>(dst + (size_t)ch * GRAN) = *reinterpret_cast<const CH*>(src + (size_t)ch * GRAN);
+    if (!(p.dbg & 4)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int col = c0 + (i & 7);
+        if (col >= g.W) col -= g.W;
+        const int64_t tok = rbase[i >> 3] + col;
+        char* dst = reinterpret_cast<char*>(p.out + tok * p.ldo);
+        const char* src = Qs + (size_t)(wv * 16 + i) * ldt;
+        if (lane < cps) *reinterpret_cast<CH*>(dst + (size_t)lane * GRAN) = *reinterpret_cast<const CH*>(src + (size_t)lane * GRAN);
+      }
     }
   }
 }
@@ -285,6 +322,7 @@ int launch_fwd(const T* qkv, int64_t ld, const float* table, T* out, int64_t ldo
   if (g.ws != 8 || d > 32 || g.C > 128 || g.mask) return RDST_ENOTSUP;
   WaArgs<T> p{};
   p.qkv = qkv; p.ld = ld; p.table = table; p.out = out; p.ldo = ldo; p.g = g; p.scale = scale; p.d = d;
+  { const char* e = getenv("RDST_K1_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const int sec = g.C * (int)sizeof(T);
   p.gran = pick_gran((uintptr_t)qkv, (uintptr_t)out, ld * (int64_t)sizeof(T), ldo * (int64_t)sizeof(T), sec);
   if (!p.gran) return RDST_ENOTSUP;

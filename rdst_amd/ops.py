@@ -82,6 +82,22 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# The weight-gradient branch and the data-gradient branch of a Linear / conv backward are independent
+# and each under-fills the chip, so they run concurrently: wgrad on a side HIP stream, dgrad on the
+# current one, joined before the op returns (fork/join is capturable into a HIP graph).
+_side_streams: dict = {}
+TWO_STREAM_BACKWARD = True
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
 # ------------------------------------------------------------------------------------------------
 # K1 / K2: fused window attention
 # ------------------------------------------------------------------------------------------------
@@ -210,11 +226,27 @@ class _LnLinear(torch.autograd.Function):
         dw = torch.empty_like(w) if (w is not None and need[3]) else None
         db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[4]) else None
         nbytes = lib.rdst_ln_linear_bwd_workspace(M, K, N)
-        wsp = _workspace(nbytes, dev)
-        _lib.check(lib.rdst_ln_linear_bwd(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
-                                          dy_r.data_ptr(), lddy, _ptr(dx), K, 0, _ptr(dw), _ptr(db), _ptr(dlw),
-                                          _ptr(dlb), wsp.data_ptr(), nbytes, M, K, N, out_scale, _dtype_code(x),
-                                          _stream()), "rdst_ln_linear_bwd")
+        code = _dtype_code(x)
+
+        def call(dx_, dw_, db_, dlw_, dlb_, wsp_):
+            _lib.check(lib.rdst_ln_linear_bwd(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
+                                              dy_r.data_ptr(), lddy, _ptr(dx_), K, 0, _ptr(dw_), _ptr(db_), _ptr(dlw_),
+                                              _ptr(dlb_), wsp_.data_ptr(), nbytes, M, K, N, out_scale, code, _stream()),
+                       "rdst_ln_linear_bwd")
+
+        wgrad = dw is not None or db is not None
+        dgrad = dx is not None or dlw is not None or dlb is not None
+        if TWO_STREAM_BACKWARD and wgrad and dgrad:
+            cur, side = torch.cuda.current_stream(), _side_stream(dev)
+            wsp_w = _workspace(nbytes, dev)
+            wsp_d = _workspace(nbytes, dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                call(None, dw, db, None, None, wsp_w)
+            call(dx, None, None, dlw, dlb, wsp_d)
+            cur.wait_stream(side)
+        else:
+            call(dx, dw, db, dlw, dlb, _workspace(nbytes, dev))
         dres = dy if (has_res and need[5]) else None
         return dx, dlw, dlb, dw, db, dres, None, None
 
@@ -272,10 +304,24 @@ class _ConvRows(torch.autograd.Function):
         dw = torch.empty_like(w) if need[1] else None
         db = torch.empty(Cout, dtype=torch.float32, device=dev) if (has_bias and need[2]) else None
         nbytes = lib.rdst_conv_bwd_workspace(B, H, W, Cin, Cout, k)
-        wsp = _workspace(nbytes, dev)
-        _lib.check(lib.rdst_conv_bwd(x.data_ptr(), ldx, in_act, w.data_ptr(), dy_r.data_ptr(), lddy, _ptr(dx), Cin, 0,
-                                     _ptr(dw), _ptr(db), wsp.data_ptr(), nbytes, B, H, W, Cin, Cout, k, out_scale, r,
-                                     _dtype_code(x), _stream()), "rdst_conv_bwd")
+        code = _dtype_code(x)
+
+        def call(dx_, dw_, db_, wsp_):
+            _lib.check(lib.rdst_conv_bwd(x.data_ptr(), ldx, in_act, w.data_ptr(), dy_r.data_ptr(), lddy, _ptr(dx_), Cin,
+                                         0, _ptr(dw_), _ptr(db_), wsp_.data_ptr(), nbytes, B, H, W, Cin, Cout, k,
+                                         out_scale, r, code, _stream()), "rdst_conv_bwd")
+
+        if TWO_STREAM_BACKWARD and dx is not None and (dw is not None or db is not None):
+            cur, side = torch.cuda.current_stream(), _side_stream(dev)
+            wsp_w = _workspace(nbytes, dev)
+            wsp_d = _workspace(nbytes, dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                call(None, dw, db, wsp_w)
+            call(dx, None, None, wsp_d)
+            cur.wait_stream(side)
+        else:
+            call(dx, dw, db, _workspace(nbytes, dev))
         dres = dy if (has_res and need[3]) else None
         return dx, dw, db, dres, None, None, None
 
