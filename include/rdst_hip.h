@@ -38,6 +38,7 @@ extern "C" {
 #define RDST_ACT_NONE 0
 #define RDST_ACT_GELU 1       /* exact erf GELU (nn.GELU default), swin_transformer_sr.py:14,19 */
 #define RDST_ACT_LEAKY02 2    /* LeakyReLU(0.2), rdst_variations.py:425 ('3conv' variant) */
+#define RDST_ACT_LEAKY001 3   /* LeakyReLU(0.01) = nn.LeakyReLU default, swin_transformer_sr.py:752 (SwinIR) */
 
 int rdst_abi_version(void);
 const char* rdst_last_error(void);

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librdst_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_LEAKY02 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_LEAKY02, ACT_LEAKY001 = 0, 1, 2, 3
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 

@@ -50,10 +50,12 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == RDST_ACT_GELU) return gelu_erf(x);
   if (act == RDST_ACT_LEAKY02) return x > 0.f ? x : 0.2f * x;
+  if (act == RDST_ACT_LEAKY001) return x > 0.f ? x : 0.01f * x;
   return x;
 }
 __device__ __forceinline__ float act_grad(float xpre, int act) {
   if (act == RDST_ACT_GELU) return gelu_erf_grad(xpre);
   if (act == RDST_ACT_LEAKY02) return xpre > 0.f ? 1.f : 0.2f;
+  if (act == RDST_ACT_LEAKY001) return xpre > 0.f ? 1.f : 0.01f;
   return 1.f;
 }

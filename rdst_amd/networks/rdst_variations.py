@@ -339,6 +339,98 @@ class RDSTSR(nn.Module):
         return None
 
 
+class RDSTSR_N(RDSTSR):
+    """RDSTSR with an RDN-style global bottleneck: the outputs of all RDSTBs are concatenated and fused by
+    Linear -> Linear ('mlp') or conv1x1 -> conv3x3 ('conv').  Reference: rdst_variations.py:824-1112 ("next"
+    row N4).  Like the reference's forward (:1090-1106) it uses neither the final ``norm`` nor
+    ``conv_after_body`` (both still exist as parameters, for state-dict parity)."""
+
+    def __init__(self, img_size=48, patch_size=1, in_chans=1, sr_scale=2, embed_dim=60,
+                 dense_layer_depths=[2, 2, 2, 2], num_heads=[6, 6, 6, 6],
+                 window_size=[4, 4, 4, 4], rdb_depths=[3, 3, 3, 3],
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop=0., drop_path_rate=0.,
+                 norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, resi_connection='1conv',
+                 growth_rate=30, dense_scale=1., dim_modify_mode='tail',
+                 rdb_residual_scale=1., global_res_scale=1., mean=None, std=None,
+                 act_in_conv='leaky_relu', bn_in_conv=None, scale_free=False, scale_embedding=False,
+                 pre_norm=False, global_bottleneck=True, global_bottleneck_ratio=1., global_bottleneck_mode='mlp'):
+        super().__init__(img_size=img_size, patch_size=patch_size, in_chans=in_chans, sr_scale=sr_scale,
+                         embed_dim=embed_dim, dense_layer_depths=dense_layer_depths, num_heads=num_heads,
+                         window_size=window_size, rdb_depths=rdb_depths, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                         qk_scale=qk_scale, drop_rate=drop_rate, attn_drop=attn_drop, drop_path_rate=drop_path_rate,
+                         norm_layer=norm_layer, ape=ape, patch_norm=patch_norm, use_checkpoint=use_checkpoint,
+                         resi_connection=resi_connection, growth_rate=growth_rate, dense_scale=dense_scale,
+                         dim_modify_mode=dim_modify_mode, rdb_residual_scale=rdb_residual_scale,
+                         global_res_scale=global_res_scale, mean=mean, std=std, act_in_conv=act_in_conv,
+                         bn_in_conv=bn_in_conv, scale_free=scale_free, scale_embedding=scale_embedding,
+                         pre_norm=pre_norm, feature_last_operation=False)
+        del self.feature_last_operation
+        # the reference registers: ... body, norm, bottleneck, conv_after_body, tail  (rdst_variations.py:984-1046)
+        cab = self._modules.pop('conv_after_body', None)
+        tail = self._modules.pop('tail')
+        self.global_bottleneck_mode = global_bottleneck_mode
+        self.do_global_bottleneck = global_bottleneck
+        if self.do_global_bottleneck:
+            cin = self.n_feats * self.num_blocks
+            cf = int(self.n_feats * global_bottleneck_ratio)
+            if global_bottleneck_mode == 'mlp':
+                self.bottleneck = nn.Sequential(nn.Linear(cin, cf), nn.Linear(cf, cf))
+            elif global_bottleneck_mode == 'conv':
+                self.bottleneck = nn.Sequential(default_conv(cin, cf, 1), default_conv(cf, cf, 3))
+            else:
+                raise ValueError(f"global_bottleneck_mode {global_bottleneck_mode!r} (mlp or conv)")
+        else:
+            cf = self.n_feats
+            self.bottleneck = None
+        if cab is not None:
+            self.conv_after_body = cab
+        if cf != self.n_feats:
+            m_tail = []
+            if self.sr_scale > 1:
+                m_tail.append(UpSampler(default_conv, self.sr_scale, cf, act=None, bn=self.bn_in_conv))
+            m_tail.append(default_conv(cf, self.input_channel, 3))
+            tail = nn.Sequential(*m_tail)
+        self.tail = tail
+        if self.bottleneck is not None:
+            self.bottleneck.apply(self._init_weights)
+
+    def forward(self, x, sr_scale=None):
+        rows = ops.nchw_to_rows(x, self.compute_dtype)
+        rows = self.sub_mean.forward_rows(rows)
+        feat = self.head.forward_rows(rows)
+        B, H, W, E = feat.shape
+        t = feat.view(B, H * W, E)
+        if self.patch_embed.norm is not None:
+            t = _norm_only(t, self.patch_embed.norm)
+        if self.ape:
+            t = t + self.absolute_pos_embed.to(t.dtype)
+        gs = self.global_res_scale
+        if self.do_global_bottleneck:
+            maps = []
+            for blk in self.body:
+                t = blk(t, (H, W))
+                maps.append(t)
+            fm = torch.cat(maps, 2)
+            if self.global_bottleneck_mode == 'mlp':
+                y = ops.ln_linear(fm, None, None, self.bottleneck[0].weight, self.bottleneck[0].bias)
+                res = ops.ln_linear(y, None, None, self.bottleneck[1].weight, self.bottleneck[1].bias, out_scale=gs,
+                                    residual=feat.view(B, H * W, E)).view(B, H, W, -1)
+            else:
+                y = self.bottleneck[0].forward_rows(fm.view(B, H, W, -1))
+                res = self.bottleneck[1].forward_rows(y, out_scale=gs, residual=feat)
+        else:
+            for blk in self.body:
+                t = blk(t, (H, W))
+            res = (t * gs + feat.view(B, H * W, E)).view(B, H, W, E)
+        y = res
+        for m in self.tail:
+            y = m.forward_rows(y)
+        y = self.add_mean.forward_rows(y)
+        return ops.rows_to_nchw(y)
+
+
 def make_RDSTSR(paras, mean=None, std=None):
     """Build the network from a flat parameter namespace (the reference's ParametersLoader)."""
     sr_scale = int(paras.sr_scale)
@@ -365,6 +457,5 @@ def make_RDSTSR(paras, mean=None, std=None):
     feature_last_operation = paras.rdst_feature_last_operation
     if not global_bottleneck:
         return RDSTSR(feature_last_operation=feature_last_operation, **kw)
-    raise NotImplementedError(
-        "rdst_amd make_RDSTSR: rdst_global_bottleneck=True selects RDSTSR_N, which is a 'next' row of the "
-        "hot-path scope (SURVEY.md §8f N4); the shipped config uses rdst_global_bottleneck = False")
+    return RDSTSR_N(global_bottleneck=global_bottleneck, global_bottleneck_ratio=_ratio,
+                    global_bottleneck_mode=paras.rdst_global_bottleneck_mode, **kw)

@@ -253,3 +253,251 @@ class PatchUnEmbed(_PatchBase):
     def forward(self, x, x_size):
         B, HW, C = x.shape
         return ops.rows_to_nchw(x.view(B, x_size[0], x_size[1], C))
+
+
+# ----------------------------------------------------------------------------------------------------
+# SwinIR baseline on the same primitives ("next" row N4 of the hot-path scope):
+# RSTB :412-484, Upsample :562-580, UpsampleOneStep :583-602, SwinIR :605-826, swinir_make_model :829-868.
+# ----------------------------------------------------------------------------------------------------
+import math  # noqa: E402
+
+from .common import Conv2d  # noqa: E402
+
+
+def _leaky_code(m):
+    if isinstance(m, nn.LeakyReLU):
+        if abs(m.negative_slope - 0.2) < 1e-12:
+            return ops.ACT_LEAKY02
+        if abs(m.negative_slope - 0.01) < 1e-12:
+            return ops.ACT_LEAKY001
+    raise NotImplementedError(f"rdst_amd: activation {m} between convs (LeakyReLU 0.2 / 0.01)")
+
+
+def _conv_chain_rows(mod, x, residual=None, out_scale=1.0):
+    """A Conv2d, or a Sequential of Conv2d / LeakyReLU as the reference builds for '3conv', applied on rows;
+    each LeakyReLU rides on the NEXT conv's input load; a trailing activation is returned as a pending code."""
+    if isinstance(mod, Conv2d):
+        return mod.forward_rows(x, residual=residual, out_scale=out_scale), ops.ACT_NONE
+    mods = list(mod)
+    pending = ops.ACT_NONE
+    n_conv = sum(isinstance(m, Conv2d) for m in mods)
+    seen = 0
+    for m in mods:
+        if isinstance(m, Conv2d):
+            seen += 1
+            last = seen == n_conv
+            x = m.forward_rows(x, in_act=pending, residual=residual if last else None,
+                               out_scale=out_scale if last else 1.0)
+            pending = ops.ACT_NONE
+        else:
+            pending = _leaky_code(m)
+    return x, pending
+
+
+def _res_conv(resi_connection, dim):
+    if resi_connection == '1conv':
+        return Conv2d(dim, dim, 3, 1, 1)
+    if resi_connection == '3conv':
+        return nn.Sequential(Conv2d(dim, dim // 4, 3, 1, 1), nn.LeakyReLU(negative_slope=0.2, inplace=True),
+                             Conv2d(dim // 4, dim // 4, 1, 1, 0), nn.LeakyReLU(negative_slope=0.2, inplace=True),
+                             Conv2d(dim // 4, dim, 3, 1, 1))
+    return None
+
+
+class RSTB(nn.Module):
+    """Residual Swin Transformer Block: BasicLayer + conv + residual."""
+
+    def __init__(self, dim, input_resolution, depth, num_heads, window_size,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 img_size=224, patch_size=4, resi_connection='1conv'):
+        super().__init__()
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.residual_group = BasicLayer(dim=dim, input_resolution=input_resolution, depth=depth, num_heads=num_heads,
+                                         window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                         qk_scale=qk_scale, drop=drop, attn_drop=attn_drop, drop_path=drop_path,
+                                         norm_layer=norm_layer, downsample=downsample, use_checkpoint=use_checkpoint)
+        conv = _res_conv(resi_connection, dim)
+        if conv is not None:
+            self.conv = conv
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=0, embed_dim=dim, norm_layer=None)
+        self.patch_unembed = PatchUnEmbed(img_size=img_size, patch_size=patch_size, in_chans=0, embed_dim=dim,
+                                          norm_layer=None)
+
+    def forward(self, x, x_size):
+        B, L, C = x.shape
+        H, W = x_size
+        y = self.residual_group(x, x_size)
+        out, _ = _conv_chain_rows(self.conv, y.view(B, H, W, C), residual=x.view(B, H, W, C))
+        return out.view(B, L, C)
+
+
+class Upsample(nn.Sequential):
+    """conv(n, 4n) + PixelShuffle(2), log2(scale) times (or conv(n, 9n) + PixelShuffle(3))."""
+
+    def __init__(self, scale, num_feat):
+        m = []
+        if (scale & (scale - 1)) == 0:
+            for _ in range(int(math.log(scale, 2))):
+                m.append(Conv2d(num_feat, 4 * num_feat, 3, 1, 1))
+                m.append(nn.PixelShuffle(2))
+        elif scale == 3:
+            m.append(Conv2d(num_feat, 9 * num_feat, 3, 1, 1))
+            m.append(nn.PixelShuffle(3))
+        else:
+            raise ValueError(f'scale {scale} is not supported. ' 'Supported scales: 2^n and 3.')
+        super().__init__(*m)
+
+    def forward_rows(self, x, in_act=ops.ACT_NONE):
+        mods = list(self)
+        for i in range(0, len(mods), 2):
+            x = mods[i].forward_rows(x, in_act=in_act, shuffle=mods[i + 1].upscale_factor)
+            in_act = ops.ACT_NONE
+        return x
+
+
+class UpsampleOneStep(nn.Sequential):
+    """One conv + one PixelShuffle (lightweight SR)."""
+
+    def __init__(self, scale, num_feat, num_out_ch, input_resolution=None):
+        self.num_feat = num_feat
+        self.input_resolution = input_resolution
+        super().__init__(Conv2d(num_feat, (scale ** 2) * num_out_ch, 3, 1, 1), nn.PixelShuffle(scale))
+
+    def forward_rows(self, x, in_act=ops.ACT_NONE):
+        return self[0].forward_rows(x, in_act=in_act, shuffle=self[1].upscale_factor)
+
+
+class SwinIR(nn.Module):
+    """SwinIR (the paper's comparison baseline) on the HIP primitives.  Stochastic depth is accepted at
+    construction (drop_path_rate) and is the identity in eval(); training with drop_path_rate > 0 raises."""
+
+    def __init__(self, img_size=64, patch_size=1, in_chans=3,
+                 embed_dim=96, depths=[6, 6, 6, 6], num_heads=[6, 6, 6, 6],
+                 window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1,
+                 norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                 use_checkpoint=False, upscale=2, img_range=1., upsampler='', resi_connection='1conv',
+                 **kwargs):
+        super().__init__()
+        num_in_ch = in_chans
+        num_out_ch = in_chans
+        num_feat = 64
+        self.img_range = img_range
+        if in_chans == 3:
+            self.mean = torch.Tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1)
+        else:
+            self.mean = torch.zeros(1, 1, 1, 1)
+        self.upscale = upscale
+        self.upsampler = upsampler
+        self.drop_path_rate = drop_path_rate
+        self.conv_first = Conv2d(num_in_ch, embed_dim, 3, 1, 1)
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.ape = ape
+        self.patch_norm = patch_norm
+        self.num_features = embed_dim
+        self.mlp_ratio = mlp_ratio
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=embed_dim, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if self.patch_norm else None)
+        num_patches = self.patch_embed.num_patches
+        patches_resolution = self.patch_embed.patches_resolution
+        self.patches_resolution = patches_resolution
+        self.patch_unembed = PatchUnEmbed(img_size=img_size, patch_size=patch_size, in_chans=embed_dim,
+                                          embed_dim=embed_dim, norm_layer=norm_layer if self.patch_norm else None)
+        if self.ape:
+            self.absolute_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
+            trunc_normal_(self.absolute_pos_embed, std=.02)
+        _no_dropout(drop_rate, "drop_rate")
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.layers = nn.ModuleList()
+        for i_layer in range(self.num_layers):
+            self.layers.append(RSTB(dim=embed_dim, input_resolution=(patches_resolution[0], patches_resolution[1]),
+                                    depth=depths[i_layer], num_heads=num_heads[i_layer], window_size=window_size,
+                                    mlp_ratio=self.mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                                    attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer, downsample=None,
+                                    use_checkpoint=use_checkpoint, img_size=img_size, patch_size=patch_size,
+                                    resi_connection=resi_connection))
+        self.norm = norm_layer(self.num_features)
+        cab = _res_conv(resi_connection, embed_dim)
+        if cab is not None:
+            self.conv_after_body = cab
+        if self.upsampler == 'pixelshuffle':
+            self.conv_before_upsample = nn.Sequential(Conv2d(embed_dim, num_feat, 3, 1, 1), nn.LeakyReLU(inplace=True))
+            self.upsample = Upsample(upscale, num_feat)
+            self.conv_last = Conv2d(num_feat, num_out_ch, 3, 1, 1)
+        elif self.upsampler == 'pixelshuffledirect':
+            self.upsample = UpsampleOneStep(upscale, embed_dim, num_out_ch, (patches_resolution[0], patches_resolution[1]))
+        elif self.upsampler == 'nearest+conv':
+            raise NotImplementedError("rdst_amd SwinIR: upsampler 'nearest+conv' (nearest interpolation) is not built")
+        else:
+            self.conv_last = Conv2d(embed_dim, num_out_ch, 3, 1, 1)
+        self.compute_dtype = torch.float32
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+        return self
+
+    def _features_rows(self, feat):
+        B, H, W, E = feat.shape
+        t = feat.view(B, H * W, E)
+        if self.patch_embed.norm is not None:
+            t = _norm_only(t, self.patch_embed.norm)
+        if self.ape:
+            t = t + self.absolute_pos_embed.to(t.dtype)
+        for layer in self.layers:
+            t = layer(t, (H, W))
+        return _norm_only(t, self.norm).view(B, H, W, E)
+
+    def forward(self, x):
+        if self.training and self.drop_path_rate and self.drop_path_rate > 0.:
+            raise NotImplementedError("rdst_amd SwinIR: stochastic depth (drop_path_rate > 0) in training mode is "
+                                      "not built; use eval() or drop_path_rate=0")
+        self.mean = self.mean.type_as(x)
+        xin = (x - self.mean) * self.img_range
+        rows = ops.nchw_to_rows(xin, self.compute_dtype)
+        feat = self.conv_first.forward_rows(rows)
+        res, pend = _conv_chain_rows(self.conv_after_body, self._features_rows(feat), residual=feat)
+        if self.upsampler == 'pixelshuffle':
+            y, pend = _conv_chain_rows(self.conv_before_upsample, res)
+            y = self.upsample.forward_rows(y, in_act=pend)
+            y = self.conv_last.forward_rows(y)
+        elif self.upsampler == 'pixelshuffledirect':
+            y = self.upsample.forward_rows(res)
+        else:
+            y = self.conv_last.forward_rows(res, residual=rows)
+        return ops.rows_to_nchw(y) / self.img_range + self.mean
+
+
+def swinir_make_model(paras):
+    upscale = paras.sr_scale
+    window_size = paras.sir_window_size
+    img_size = int(paras.patch_size // upscale // window_size + 1) * window_size
+    return SwinIR(
+        img_size=img_size, patch_size=paras.sir_token_size, in_chans=paras.input_channel,
+        embed_dim=paras.sir_embed_dim, depths=paras.sir_swintr_layers, num_heads=paras.sir_num_heads,
+        window_size=window_size, mlp_ratio=paras.sir_hidden_ratio, qkv_bias=paras.sir_qkv_bias,
+        qk_scale=paras.sir_qk_scale, drop_rate=paras.sir_drop_rate, attn_drop_rate=paras.sir_attn_drop_rate,
+        drop_path_rate=paras.sir_drop_path_rate, norm_layer=nn.LayerNorm if paras.sir_layer_norm else nn.Identity,
+        ape=paras.sir_ape, patch_norm=paras.sir_patch_norm, use_checkpoint=paras.sir_use_checkpoint,
+        upscale=int(upscale), img_range=paras.sir_img_range, upsampler=paras.sir_upsampler,
+        resi_connection=paras.sir_res_connection)

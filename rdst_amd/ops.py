@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_LEAKY02, ACT_NONE, BF16, F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_LEAKY001, ACT_LEAKY02, ACT_NONE, BF16, F32  # noqa: F401
 
 
 def _dtype_code(t: torch.Tensor) -> int:

@@ -39,9 +39,10 @@ def _import_reference():
     class DropPath(nn.Module):
         def __init__(self, p=0.0):
             super().__init__()
-            assert p == 0.0
+            self.p = p
 
         def forward(self, x):
+            assert self.p == 0.0 or not self.training, "stochastic depth is only the identity in eval()"
             return x
 
     layers = types.ModuleType("timm.models.layers")
@@ -51,10 +52,17 @@ def _import_reference():
     sys.modules.setdefault("timm", types.ModuleType("timm"))
     sys.modules.setdefault("timm.models", types.ModuleType("timm.models"))
     sys.modules["timm.models.layers"] = layers
-    sys.path.insert(0, REF)
+    # The reference's `networks` is a namespace package (no __init__.py); this repository's drop-in shim
+    # `networks/` is a regular package and would win regardless of path order, so hide the repo root while
+    # the reference is imported.
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [q for q in saved if os.path.abspath(q or ".") != ROOT]
+    for k in [k for k in sys.modules if k == "networks" or k.startswith("networks.")]:
+        del sys.modules[k]
     import networks.rdst_variations as rv  # noqa
     import networks.swin_transformer_sr as st  # noqa
-    sys.path.remove(REF)
+    assert rv.__file__.startswith(REF) and st.__file__.startswith(REF), (rv.__file__, st.__file__)
+    sys.path[:] = saved
     return rv, st
 
 
@@ -205,6 +213,36 @@ def run_block_case(st, name, C, heads, ws, shift, res, x_size, B, seed):
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
 
 
+def run_model_case(rv, st, name):
+    """'Next'-row models (SwinIR baseline, RDSTSR_N): fixtures straight from the reference module."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import MODEL_CASES, seeded_fill
+    kind, kw, xshape, seed, train = MODEL_CASES[name]
+    net = (st.SwinIR if kind == "swinir" else rv.RDSTSR_N)(**kw)
+    net.load_state_dict(seeded_fill(net.state_dict(), seed), strict=True)
+    layout = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
+    with open(os.path.join(HERE, f"state_dict_{name}.json"), "w") as f:
+        json.dump({"entries": layout}, f)
+    x = seeded(xshape, seed + 500)
+    out = {"x": x.numpy()}
+    if train:
+        net.train()
+        y = net(x)
+        tgt = seeded(tuple(y.shape), seed + 1000)
+        loss = F.l1_loss(y, tgt)
+        loss.backward()
+        grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+        keys = sorted(grads)
+        out.update(y=y.detach().numpy(), target=tgt.numpy(), loss=np.float64(loss.item()), grad_keys=np.array(keys),
+                   grad_l2=np.array([grads[k].double().norm().item() for k in keys]))
+    else:
+        net.eval()
+        with torch.no_grad():
+            out["y"] = net(x).numpy()
+    print(f"[{name}] fixture from the reference: out {tuple(out['y'].shape)}, {len(layout)} state-dict entries")
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -241,6 +279,9 @@ def main():
                       rdb_residual_scale=0.7, global_res_scale=0.9)
     run_net_case(rv, "net_3conv_x3", cfg3, seeded((2, 1, 16, 16), 105), 4,
                  grad_keys=["body.0.conv.0.weight", "body.0.body.0.tail.0.weight"])
+    # --- "next" rows: SwinIR baseline and the RDSTSR_N bottleneck variant ----------------------------
+    for name in ("swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "rdstsr_n_mlp", "rdstsr_n_conv"):
+        run_model_case(rv, st, name)
 
 
 if __name__ == "__main__":

@@ -107,3 +107,18 @@ def test_package_does_not_import_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dp, fn)
+
+
+@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "rdstsr_n_mlp", "rdstsr_n_conv"])
+def test_next_row_models_state_dict_layout(name):
+    """SwinIR baseline and RDSTSR_N ("next" rows): same state-dict keys / order / shapes / dtypes as the reference."""
+    from util import MODEL_CASES
+    kind, kw, _x, _seed, _train = MODEL_CASES[name]
+    if kind == "swinir":
+        from networks.swin_transformer_sr import SwinIR as cls
+    else:
+        from networks.rdst_variations import RDSTSR_N as cls
+    net = cls(**kw)
+    ref = json.load(open(os.path.join(GOLDEN, f"state_dict_{name}.json")))["entries"]
+    mine = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
+    assert list(mine) == list(ref) and mine == ref

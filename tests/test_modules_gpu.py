@@ -139,3 +139,82 @@ def test_standalone_window_attention_with_explicit_mask():
     att.to(DEV)
     got = att(xw.to(DEV), mask=mask.to(DEV))
     assert (got.cpu() - ref).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "rdstsr_n_mlp", "rdstsr_n_conv"])
+def test_next_row_models_vs_reference_fixture(name):
+    """SwinIR baseline / RDSTSR_N on the HIP primitives vs outputs, loss and gradient norms of the reference."""
+    from util import MODEL_CASES, seeded_fill
+    kind, kw, _xs, seed, train = MODEL_CASES[name]
+    if kind == "swinir":
+        from rdst_amd.networks.swin_transformer_sr import SwinIR as cls
+    else:
+        from rdst_amd.networks.rdst_variations import RDSTSR_N as cls
+    g = load_golden(name)
+    net = cls(**kw)
+    net.load_state_dict(seeded_fill(net.state_dict(), seed), strict=True)
+    net.to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    if not train:
+        net.eval()
+        with torch.no_grad():
+            y = net(x)
+        scale = max(1.0, float(np.abs(g["y"]).max()))
+        assert np.abs(y.cpu().numpy() - g["y"]).max() <= 1e-4 * scale
+        return
+    net.train()
+    y = net(x)
+    loss = F.l1_loss(y, torch.from_numpy(g["target"]).to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.abs(y.detach().cpu().numpy() - g["y"]).max() <= 1e-4
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    params = dict(net.named_parameters())
+    for k, l2 in zip([str(k) for k in g["grad_keys"]], g["grad_l2"]):
+        assert abs(params[k].grad.double().norm().item() - l2) <= 1e-3 * max(l2, 1e-9), k
+
+
+def test_full_size_batch_independence_properties():
+    """BASELINE shape (RDST-E1 x4, batch 32 of 1x64x64), both arithmetic modes: size-independent properties the
+    domain offers — patches never interact, so (1) the output of a sub-batch equals the slice of the full batch,
+    (2) permuting the batch permutes the output, (3) two runs are bit-identical (deterministic forward)."""
+    import bench
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 0.0)):
+        net = bench.build_net(torch.device(DEV), dtype).eval()
+        g = torch.Generator().manual_seed(5)
+        x = torch.rand(32, 1, 64, 64, generator=g).to(DEV)
+        with torch.no_grad():
+            y = net(x)
+            y2 = net(x)
+            ysub = net(x[3:7])
+            perm = torch.randperm(32, generator=g).to(DEV)
+            yp = net(x[perm])
+        assert y.shape == (32, 1, 256, 256) and torch.isfinite(y).all()
+        assert torch.equal(y, y2)
+        assert (ysub - y[3:7]).abs().max().item() <= tol
+        assert (yp - y[perm]).abs().max().item() <= tol
+
+
+def test_full_size_gradient_linearity_over_batch():
+    """fwd+bwd at the BASELINE shape in fp32: with a sum-reduced loss the parameter gradient of the full batch
+    equals the sum of the gradients of its two halves (linearity of backprop over independent patches)."""
+    import bench
+    net = bench.build_net(torch.device(DEV), torch.float32)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(32, 1, 64, 64, generator=g).to(DEV)
+    w = torch.randn(32, 1, 256, 256, generator=g).to(DEV)
+    keys = ["head.weight", "body.0.body.0.body.blocks.1.attn.relative_position_bias_table",
+            "body.4.body.1.body.blocks.0.attn.qkv.weight", "body.7.conv.weight", "norm.bias", "tail.1.weight"]
+    params = dict(net.named_parameters())
+
+    def grads(xs, ws):
+        net.zero_grad(set_to_none=True)
+        (net(xs) * ws).sum().backward()
+        return {k: params[k].grad.detach().clone() for k in keys}
+
+    full = grads(x, w)
+    a, b = grads(x[:16], w[:16]), grads(x[16:], w[16:])
+    for k in keys:
+        ref = full[k]
+        err = (a[k] + b[k] - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        assert err <= 2e-4, (k, err)

@@ -43,3 +43,56 @@ def build_net(cfg, mean=None, std=None):
         dense_scale=cfg["dense_scale"], rdb_residual_scale=cfg["rdb_residual_scale"],
         global_res_scale=cfg["global_res_scale"], mean=mean, std=std, pre_norm=cfg["pre_norm"],
         feature_last_operation=cfg["feature_last_operation"])
+
+
+def seeded_fill(state_dict, seed):
+    """Deterministic weights for ANY module, keyed by state-dict name (numpy PCG64): the golden generator
+    fills the reference with it, the tests fill the HIP module with it; integer buffers, masks and MeanShift
+    tensors keep their constructed values."""
+    import zlib
+    out = {}
+    for k, v in state_dict.items():
+        if (not v.dtype.is_floating_point) or k.endswith("attn_mask") or k.startswith(("sub_mean.", "add_mean.")):
+            out[k] = v.clone()
+            continue
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(k.encode())]))
+        n = torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32))
+        if k.endswith("relative_position_bias_table"):
+            a = 0.5 * n
+        elif v.dim() == 1 and k.endswith("weight"):
+            a = 1.0 + 0.1 * n            # LayerNorm weight
+        elif v.dim() == 1:
+            a = 0.05 * n                 # biases
+        elif v.dim() == 4:
+            a = n / float(np.sqrt(v.shape[1] * v.shape[2] * v.shape[3]))
+        elif v.dim() == 2:
+            a = 0.7 * n / float(np.sqrt(v.shape[1]))
+        else:
+            a = 0.02 * n
+        out[k] = a
+    return out
+
+
+MODEL_CASES = {
+    # name: (kind, ctor kwargs, input shape, seed, train?)
+    "swinir_ps_x4": ("swinir", dict(img_size=16, in_chans=1, embed_dim=60, depths=[2, 2], num_heads=[6, 6], window_size=8,
+                                    mlp_ratio=2., upscale=4, img_range=1., upsampler="pixelshuffle", drop_path_rate=0.),
+                     (2, 1, 16, 16), 21, True),
+    "swinir_psd_x2_rgb": ("swinir", dict(img_size=16, in_chans=3, embed_dim=48, depths=[2], num_heads=[6], window_size=8,
+                                         mlp_ratio=2., upscale=2, img_range=255., upsampler="pixelshuffledirect",
+                                         drop_path_rate=0.1, resi_connection="3conv"),
+                          (1, 3, 16, 24), 22, False),
+    "swinir_denoise": ("swinir", dict(img_size=16, in_chans=1, embed_dim=48, depths=[2], num_heads=[6], window_size=8,
+                                      mlp_ratio=2., upscale=1, img_range=1., upsampler="", drop_path_rate=0.),
+                       (1, 1, 16, 16), 23, True),
+    "rdstsr_n_mlp": ("rdstsr_n", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2, 2],
+                                      num_heads=[6, 6], window_size=[8, 8], rdb_depths=[2, 2], mlp_ratio=2.,
+                                      growth_rate=24, pre_norm=True, global_bottleneck=True, global_bottleneck_ratio=1.,
+                                      global_bottleneck_mode="mlp", global_res_scale=0.8),
+                     (2, 1, 16, 16), 24, True),
+    "rdstsr_n_conv": ("rdstsr_n", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2, 2],
+                                       num_heads=[6, 6], window_size=[8, 8], rdb_depths=[2, 2], mlp_ratio=2.,
+                                       growth_rate=24, pre_norm=True, global_bottleneck=True, global_bottleneck_ratio=1.,
+                                       global_bottleneck_mode="conv"),
+                      (1, 1, 16, 16), 25, True),
+}
