@@ -394,7 +394,9 @@ template <typename T> bool rows_ok(const void*, int64_t) { return true; }  // lo
 // ------------------------------------------------------------------------------------------------
 // wgrad
 // ------------------------------------------------------------------------------------------------
-constexpr int WG_MAXT = 6;      // accumulator tiles per wave (8 waves -> 48 tiles = 360 x 121 max)
+constexpr int WG_WAVES = 16;    // waves per workgroup (one workgroup per CU: 4 waves per SIMD)
+constexpr int WG_THREADS = 64 * WG_WAVES;
+constexpr int WG_MAXT = 3;      // accumulator tiles per wave (16 waves -> 48 tiles = 360 x 121 max)
 constexpr int WG_STRIPE = 32;   // token rows staged per step
 
 template <typename T>
@@ -409,7 +411,7 @@ struct WgradArgs {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
+__global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using MM = Mma<T>;
   constexpr int HP = MM::HP;
@@ -427,17 +429,17 @@ __global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> 
   const int npk = p.NT * 32 / HP, kpk = p.KT * 32 / HP;
 
   // Per-thread staging plan (loop invariant): which (stripe row, pack) of dY / X this thread moves.
-  constexpr int DYMAX = 24 / HP, XMAX = 16 / HP;  // 32 rows x (NT*32 <= 384 | KT*32 <= 256) elements over 512 threads
+  constexpr int DYMAX = (12 + HP - 1) / HP, XMAX = 8 / HP;  // 32 rows x (NT*32 <= 384 | KT*32 <= 256) elements over 1024 threads
   int dy_row[DYMAX], dy_pk[DYMAX], x_row[XMAX], x_pk[XMAX];
 #pragma unroll
   for (int i = 0; i < DYMAX; ++i) {
-    const int idx = tid + 512 * i;
+    const int idx = tid + WG_THREADS * i;
     dy_row[i] = idx < WG_STRIPE * npk ? idx / npk : -1;
     dy_pk[i] = idx - (idx / npk) * npk;
   }
 #pragma unroll
   for (int i = 0; i < XMAX; ++i) {
-    const int idx = tid + 512 * i;
+    const int idx = tid + WG_THREADS * i;
     x_row[i] = idx < WG_STRIPE * kpk ? idx / kpk : -1;
     x_pk[i] = idx - (idx / kpk) * kpk;
   }
@@ -495,7 +497,7 @@ __global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> 
     if (m0 + WG_STRIPE < m_end) prefetch(m0 + WG_STRIPE);  // in flight while this stripe is multiplied
 #pragma unroll
     for (int j = 0; j < WG_MAXT; ++j) {
-      const int ti = wave + 8 * j;
+      const int ti = wave + WG_WAVES * j;
       if (ti < ntiles) {
         const int nt = ti / p.KT, kt = ti - nt * p.KT;
         if constexpr (sizeof(T) == 2) {
@@ -537,7 +539,7 @@ __global__ void __launch_bounds__(512) lin_wgrad_mfma_kernel(const WgradArgs<T> 
   float* my = p.slab + (int64_t)blockIdx.x * p.N * p.Kx;
 #pragma unroll
   for (int j = 0; j < WG_MAXT; ++j) {
-    const int ti = wave + 8 * j;
+    const int ti = wave + WG_WAVES * j;
     if (ti < ntiles) {
       const int nt = ti / p.KT, kt = ti - nt * p.KT;
       const int k = kt * 32 + r;
@@ -644,7 +646,7 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   p.X = X; p.ldx = ldx; p.lnw = ln_w; p.lnb = ln_b; p.stats = stats; p.in_act = in_act; p.dY = dY; p.lddy = lddy;
   p.slab = slab; p.M = M; p.K = K; p.N = N; p.Kx = K + 1;
   p.NT = (N + 31) / 32; p.KT = (p.Kx + 31) / 32;
-  if (p.NT * p.KT > 8 * WG_MAXT || p.NT > 12 || p.KT > 8) return RDST_ENOTSUP;
+  if (p.NT * p.KT > WG_WAVES * WG_MAXT || p.NT > 12 || p.KT > 8) return RDST_ENOTSUP;
   // LDS row strides: bf16 rows are read by ds_read_b64_tr_b16 (4 token rows x 64 B per 32 lanes):
   // stride = 64 (mod 256) bytes puts the 4 rows on disjoint bank ranges; fp32 rows are read 32
   // consecutive floats at a time, any stride works.
@@ -663,7 +665,7 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   nwg = (M + p.rows_per_wg - 1) / p.rows_per_wg;
   auto kern = lin_wgrad_mfma_kernel<T>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WG_THREADS), smem, st, p);
   if (int rc = rdst_launch_status("lin_wgrad_mfma")) return rc;
   const int tot = N * p.Kx;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
