@@ -130,11 +130,12 @@ def main():
     loss_buf = torch.zeros((), device=device)
 
     def fwd_bwd():
-        bucket.zero()
+        bucket.detach_grads()       # autograd assigns fresh grads (no per-parameter accumulate kernels) ...
         y = net(x)
         loss = F.l1_loss(y, tgt)
         loss_buf.copy_(loss.detach())
         loss.backward()
+        bucket.gather()             # ... which are flattened into the one all-reduce / Adam bucket
 
     def step_eager():
         fwd_bwd()

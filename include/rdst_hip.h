@@ -95,14 +95,16 @@ int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const flo
                        int64_t ld_y, float* stats, int64_t M, int K, int N, float out_scale,
                        int dtype, void* stream);
 
-/* Backward of rdst_ln_linear_fwd.  dY (M,N) -> dX (M,K) [overwritten, or accumulated when
- * accumulate_dx != 0], dW (N,K), dbias (N), dln_w/dln_b (K) [overwritten; any of them may be NULL
- * to skip].  The residual's gradient is dY itself and is the caller's business. */
+/* Backward of rdst_ln_linear_fwd.  dY (M,N) -> dX (M,K) = dX_add + f'(...) where dX_add is an optional
+ * (M,K) tensor added on the way out (NULL = none; it may alias dX for an in-place accumulate) - this is how
+ * the gradient of a residual fan-out is summed without a separate add kernel; dW (N,K), dbias (N),
+ * dln_w/dln_b (K) [overwritten; any of them may be NULL to skip].  The gradient of the forward's residual
+ * operand R is dY itself and is the caller's business. */
 size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N);
 int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b,
                        const float* stats, int in_act, const float* Wt, const void* dY,
-                       int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx, float* dW,
-                       float* dbias, float* dln_w, float* dln_b, void* workspace,
+                       int64_t ld_dy, void* dX, int64_t ld_dx, const void* dX_add, int64_t ld_dx_add,
+                       float* dW, float* dbias, float* dln_w, float* dln_b, void* workspace,
                        size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
                        void* stream);
 
@@ -121,12 +123,12 @@ int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, cons
                   const void* R, int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin,
                   int Cout, int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
-/* Backward: dY (output geometry) -> dX (B*H*W, Cin) [overwrite / accumulate], dW (Cout,Cin,k,k),
- * dbias (Cout) [overwritten; may be NULL]. */
+/* Backward: dY (output geometry) -> dX (B*H*W, Cin) = dX_add + ... (dX_add optional, may alias dX),
+ * dW (Cout,Cin,k,k), dbias (Cout) [overwritten; may be NULL]. */
 size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize);
 int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY,
-                  int64_t ld_dy, void* dX, int64_t ld_dx, int accumulate_dx, float* dW, float* dbias,
-                  void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
+                  int64_t ld_dy, void* dX, int64_t ld_dx, const void* dX_add, int64_t ld_dx_add, float* dW,
+                  float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
                   int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
 /* ---- layout helpers at the NCHW boundary of the module ------------------------------------------

@@ -22,11 +22,11 @@ SIGNATURES = {
     "rdst_wattn_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _l, _p, _l, _p, _l, _i, _i, _f, _i, _p]),
     "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
-    "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _i, _p, _p, _p, _p, _p, _z,
+    "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
                                 _l, _i, _i, _f, _i, _p]),
     "rdst_conv_fwd": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
-    "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _i, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,
+    "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,
                            _f, _i, _i, _p]),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),

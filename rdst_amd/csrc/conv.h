@@ -40,7 +40,7 @@ template <typename T>
 const T* plain_dy(const T* dY, int64_t lddy, const ConvGeom& g, void* scratch, int64_t& ld_out, hipStream_t st, int& rc);
 template <typename T>
 int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dYp, int64_t lddyp, T* dX,
-                    int64_t lddx, int accumulate, const ConvGeom& g, float s, hipStream_t st);
+                    int64_t lddx, const T* acc, int64_t ldacc, const ConvGeom& g, float s, hipStream_t st);
 template <typename T>
 int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t lddyp, float* dW, float* dbias,
                     float* slab, const ConvGeom& g, float s, hipStream_t st);

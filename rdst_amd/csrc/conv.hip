@@ -99,11 +99,11 @@ struct ConvFwdEp {
 };
 template <typename T>
 struct ConvDxEp {
-  const T* X; int64_t ldx; T* dX; int64_t lddx; int act; int accumulate;
+  const T* X; int64_t ldx; T* dX; int64_t lddx; int act; const T* addp; int64_t ldacc;
   __device__ __forceinline__ void operator()(int64_t p, int ci, float acc, int) const {
     float v = acc;
     if (act) v *= act_grad(to_f32<T>(X[p * ldx + ci]), act);
-    if (accumulate) v += to_f32<T>(dX[p * lddx + ci]);
+    if (addp) v += to_f32<T>(addp[p * ldacc + ci]);
     dX[p * lddx + ci] = from_f32<T>(v);
   }
 };
@@ -139,7 +139,7 @@ int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bia
 
 template <typename T>
 int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int64_t lddy, T* dX, int64_t lddx,
-          int accumulate, float* dW, float* dbias, float* wsp, const ConvGeom& g, float s, hipStream_t st) {
+          const T* acc, int64_t ldacc, float* dW, float* dbias, float* wsp, const ConvGeom& g, float s, hipStream_t st) {
   const int64_t wtotal = (int64_t)g.Cout * g.Cin * g.ks * g.ks;
   // workspace carve: [generic split-K slab][small][MFMA scratch: un-shuffled dY, wgrad slab]
   float* slab = wsp;
@@ -172,11 +172,11 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
     if (rc) return rc;
   }
   if (dX) {
-    int rc = conv_dgrad_mfma<T>(X, ldx, in_act, Wc, dYp, ldp, dX, lddx, accumulate, g, s, st);
+    int rc = conv_dgrad_mfma<T>(X, ldx, in_act, Wc, dYp, ldp, dX, lddx, acc, ldacc, g, s, st);
     if (rc == RDST_ENOTSUP) {
       ConvDyA<T> la{dY, lddy, g, s};
       ConvBd lb{Wc, g};
-      ConvDxEp<T> ep{X, ldx, dX, lddx, in_act, accumulate};
+      ConvDxEp<T> ep{X, ldx, dX, lddx, in_act, acc, ldacc};
       rc = gemm_valu_launch(la, lb, ep, g.pixels(), g.Cin, (int64_t)g.ks * g.ks * g.Cout, 1, st, "conv_dgrad");
     }
     if (rc) return rc;
@@ -237,7 +237,8 @@ extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout
 }
 
 extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY, int64_t ld_dy,
-                             void* dX, int64_t ld_dx, int accumulate_dx, float* dW, float* dbias, void* workspace,
+                             void* dX, int64_t ld_dx, const void* dX_add, int64_t ld_dx_add, float* dW, float* dbias,
+                             void* workspace,
                              size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int ksize, float out_scale,
                              int shuffle_r, int dtype, void* stream) {
   ConvGeom g;
@@ -249,8 +250,8 @@ extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const floa
   if (workspace_bytes < rdst_conv_bwd_workspace(B, H, W, Cin, Cout, ksize)) return rdst_fail(RDST_EINVAL, "rdst_conv_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RDST_F32)
-    return bwd_t<float>((const float*)X, ld_x, in_act, Wc, (const float*)dY, ld_dy, (float*)dX, ld_dx, accumulate_dx, dW, dbias, (float*)workspace, g, out_scale, st);
-  return bwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, accumulate_dx, dW, dbias, (float*)workspace, g, out_scale, st);
+    return bwd_t<float>((const float*)X, ld_x, in_act, Wc, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dW, dbias, (float*)workspace, g, out_scale, st);
+  return bwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dW, dbias, (float*)workspace, g, out_scale, st);
 }
 
 extern "C" int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int B, int C, int H, int W, int dtype, void* stream) {

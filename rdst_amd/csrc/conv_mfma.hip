@@ -42,7 +42,7 @@ struct ConvArgs {
   const T* R; int64_t ldr;
   T* Y; int64_t ldy;                 // fwd: Y (output geometry), dgrad: dX
   const T* Xa; int64_t ldxa;         // dgrad: X for act'
-  int in_act; int accumulate;
+  int in_act; const T* Acc; int64_t ldacc;   // dgrad: + dX_add
   ConvGeom g;
   int Nout;                          // fwd: Cout, dgrad: Cin
   float s;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
                   } else {
                     float val = acc[c][v] * p.s;
                     if (p.in_act) val *= act_grad(to_f32<T>(p.Xa[pp * p.ldxa + col]), p.in_act);
-                    if (p.accumulate) val += to_f32<T>(p.Y[pp * p.ldy + col]);
+                    if (p.Acc) val += to_f32<T>(p.Acc[pp * p.ldacc + col]);
                     p.Y[pp * p.ldy + col] = from_f32<T>(val);
                   }
                 }
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
             if (MODE == CMODE_FWD) {
               ep.R = p.R; ep.ldr = p.ldr; ep.Y = p.Y; ep.ldy = p.ldy;
             } else {
-              ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.accumulate = p.accumulate;
+              ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.Acc = p.Acc; ep.ldacc = p.ldacc;
             }
             tile_store_rows<T>(eps, vals, lane, slab * 32, P, n0 + c * 32, p.Nout, ep);
           }
@@ -421,12 +421,12 @@ const T* plain_dy(const T* dY, int64_t lddy, const ConvGeom& g, void* scratch, i
 
 template <typename T>
 int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dYp, int64_t lddyp, T* dX,
-                    int64_t lddx, int accumulate, const ConvGeom& g, float s, hipStream_t st) {
+                    int64_t lddx, const T* acc, int64_t ldacc, const ConvGeom& g, float s, hipStream_t st) {
   // dYp must already be plain rows (B*H*W, Cout)
   if (mfma_disabled() || !rows_ok<T>(dYp, lddyp) || g.Cout < 8) return RDST_ENOTSUP;
   ConvArgs<T> p{};
   p.A = dYp; p.lda = lddyp; p.CA = g.Cout; p.Wc = Wc; p.Y = dX; p.ldy = lddx; p.Xa = X; p.ldxa = ldx;
-  p.in_act = in_act; p.accumulate = accumulate; p.g = g; p.Nout = g.Cin; p.s = s;
+  p.in_act = in_act; p.Acc = acc; p.ldacc = ldacc; p.g = g; p.Nout = g.Cin; p.s = s;
   return launch_conv<T, CMODE_DGRAD>(p, st, "conv_dgrad_mfma");
 }
 
@@ -469,8 +469,8 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
 #define INST(T)                                                                                                       \
   template int conv_fwd_mfma<T>(const T*, int64_t, int, const float*, const float*, const T*, int64_t, T*, int64_t,  \
                                 const ConvGeom&, float, hipStream_t);                                                \
-  template int conv_dgrad_mfma<T>(const T*, int64_t, int, const float*, const T*, int64_t, T*, int64_t, int,         \
-                                  const ConvGeom&, float, hipStream_t);                                              \
+  template int conv_dgrad_mfma<T>(const T*, int64_t, int, const float*, const T*, int64_t, T*, int64_t, const T*,    \
+                                  int64_t, const ConvGeom&, float, hipStream_t);                                     \
   template int conv_wgrad_mfma<T>(const T*, int64_t, int, const T*, int64_t, float*, float*, float*, const ConvGeom&, \
                                   float, hipStream_t);                                                               \
   template const T* plain_dy<T>(const T*, int64_t, const ConvGeom&, void*, int64_t&, hipStream_t, int&);

@@ -96,6 +96,7 @@ static inline int gemm_valu_splits(int64_t K, int splits) {
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           int S, int64_t n);
 int slab_reduce(const float* slab, float* out, int S, int64_t n, hipStream_t st);
+int slab_reduce2(const float* slab, float* out_a, float* out_b, int S, int K, hipStream_t st);
 
 // column sums of a functor matrix F(m, n), m < M, n < N <= 1024: out[n] = sum_m F(m,n).
 // Two passes through a [blocks][N] slab for a reproducible result.

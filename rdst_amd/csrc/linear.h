@@ -10,7 +10,8 @@ int linear_fwd_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_
 // dA[M][K] = s * dY[M][N] @ Wt[N][K]; has_ln: write fp32 dA, else dX = dA*act'(X) (+dX)
 template <typename T>
 int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const float* Wt, const T* dY, int64_t lddy,
-                      T* dX, int64_t lddx, int accumulate, float* dA, int64_t M, int K, int N, float s, hipStream_t st);
+                      T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* dA, int64_t M, int K, int N, float s,
+                      hipStream_t st);
 // dW[N][K] = s * dY^T f(X) and dbias[N] = s * colsum(dY) in one pass (either pointer may be NULL)
 template <typename T>
 int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
@@ -21,5 +22,5 @@ size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N);
 // slab[*nslab][2][K] for the caller to reduce
 template <typename T>
 int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
-                         int64_t lddy, T* dX, int64_t lddx, int accumulate, float* slab, int* nslab, int64_t M, int K,
-                         int N, float s, hipStream_t st);
+                         int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* slab, int* nslab,
+                         int64_t M, int K, int N, float s, hipStream_t st);

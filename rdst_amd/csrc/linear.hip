@@ -33,6 +33,29 @@ int slab_reduce(const float* slab, float* out, int S, int64_t n, hipStream_t st)
   return rdst_launch_status("slab_reduce");
 }
 
+// slab [S][2][K] -> out_a[K] (first half), out_b[K] (second half); either may be NULL.
+// One wave per output (4 outputs per block): lanes stride over the S slab rows with independent loads and
+// combine with a fixed shuffle tree, so the result is reproducible and the kernel is not a serial chain.
+__global__ void __launch_bounds__(256) slab_reduce2_kernel(const float* __restrict__ slab, float* __restrict__ out_a,
+                                                           float* __restrict__ out_b, int S, int K) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= 2 * K) return;
+  float a = 0.f;
+  for (int s = lane; s < S; s += 64) a += slab[(int64_t)s * 2 * K + i];
+  a = wave_sum(a);
+  if (lane == 0) {
+    if (i < K) { if (out_a) out_a[i] = a; }
+    else if (out_b) out_b[i - K] = a;
+  }
+}
+
+int slab_reduce2(const float* slab, float* out_a, float* out_b, int S, int K, hipStream_t st) {
+  if (K <= 0 || (!out_a && !out_b)) return 0;
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3((unsigned)((2 * K + 3) / 4)), dim3(256), 0, st, slab, out_a, out_b, S, K);
+  return rdst_launch_status("slab_reduce2");
+}
+
 namespace {
 
 constexpr float kLnEps = 1e-5f;  // nn.LayerNorm default
@@ -143,11 +166,11 @@ struct DaEp {  // LN case: keep d(LN output) in fp32 for the row-wise LN backwar
 };
 template <typename T>
 struct DxEp {  // no LN: dX = dA * act'(X) (+ existing dX)
-  const T* X; int64_t ldx; T* dX; int64_t lddx; int act; int accumulate;
+  const T* X; int64_t ldx; T* dX; int64_t lddx; int act; const T* addp; int64_t ldacc;
   __device__ __forceinline__ void operator()(int64_t m, int k, float acc, int) const {
     float v = acc;
     if (act) v *= act_grad(to_f32<T>(X[m * ldx + k]), act);
-    if (accumulate) v += to_f32<T>(dX[m * lddx + k]);
+    if (addp) v += to_f32<T>(addp[m * ldacc + k]);
     dX[m * lddx + k] = from_f32<T>(v);
   }
 };
@@ -157,7 +180,8 @@ struct DxEp {  // no LN: dX = dA * act'(X) (+ existing dX)
 template <typename T, int KC>
 __global__ void __launch_bounds__(256)
 ln_bwd_rows_kernel(const float* __restrict__ dA, const T* __restrict__ X, int64_t ldx, const float* __restrict__ stats,
-                   const float* __restrict__ gamma, T* dX, int64_t lddx, int accumulate, float* __restrict__ slab,
+                   const float* __restrict__ gamma, T* dX, int64_t lddx, const T* acc, int64_t ldacc,
+                   float* __restrict__ slab,
                    int64_t M, int K) {
   __shared__ float red[4][2][64 * KC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -198,7 +222,7 @@ ln_bwd_rows_kernel(const float* __restrict__ dA, const T* __restrict__ X, int64_
       if (k < K) {
         float v = rstd * (g[c] - s1 - xh[c] * s2);
         if (dX) {
-          if (accumulate) v += to_f32<T>(dX[row * lddx + k]);
+          if (acc) v += to_f32<T>(acc[row * ldacc + k]);
           dX[row * lddx + k] = from_f32<T>(v);
         }
       }
@@ -253,7 +277,8 @@ int fwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_
 
 template <typename T>
 int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act, const float* Wt,
-          const T* dY, int64_t lddy, T* dX, int64_t lddx, int accumulate, float* dW, float* dbias, float* dln_w,
+          const T* dY, int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* dW, float* dbias,
+          float* dln_w,
           float* dln_b, float* wsp, int64_t M, int K, int N, float s, hipStream_t st) {
   // workspace carve: [dA: M*K] [slabW: splits*N*K] [small: kSmallBlocks * max(N, 2K)]
   float* dA = wsp;
@@ -281,19 +306,15 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
     }
     if (dX && ln_w) {  // fused dgrad + LayerNorm backward
       int nslab = 0;
-      const int rc = linear_dgrad_ln_mfma<T>(X, ldx, stats, ln_w, Wt, dY, lddy, dX, lddx, accumulate, small, &nslab, M, K,
+      const int rc = linear_dgrad_ln_mfma<T>(X, ldx, stats, ln_w, Wt, dY, lddy, dX, lddx, acc, ldacc, small, &nslab, M, K,
                                              N, s, st);
       if (rc == 0) {
-        float* out2 = small + (int64_t)kSmallBlocks * 2 * K;
-        if (int rc2 = slab_reduce(small, out2, nslab, 2 * K, st)) return rc2;
-        if (dln_w) (void)hipMemcpyAsync(dln_w, out2, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
-        if (dln_b) (void)hipMemcpyAsync(dln_b, out2 + K, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
-        return 0;
+        return slab_reduce2(small, dln_w, dln_b, nslab, K, st);
       }
       if (rc != RDST_ENOTSUP) return rc;
     }
     if (dX) {
-      int rc = linear_dgrad_mfma<T>(X, ldx, ln_w != nullptr, in_act, Wt, dY, lddy, dX, lddx, accumulate, dA, M, K, N, s, st);
+      int rc = linear_dgrad_mfma<T>(X, ldx, ln_w != nullptr, in_act, Wt, dY, lddy, dX, lddx, acc, ldacc, dA, M, K, N, s, st);
       if (rc == RDST_ENOTSUP) {
         DyA<T> la{dY, lddy, s};
         WtBT lb{Wt, K};
@@ -301,7 +322,7 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
           DaEp ep{dA, K};
           rc = gemm_valu_launch(la, lb, ep, M, K, N, 1, st, "linear_dgrad");
         } else {
-          DxEp<T> ep{X, ldx, dX, lddx, in_act, accumulate};
+          DxEp<T> ep{X, ldx, dX, lddx, in_act, acc, ldacc};
           rc = gemm_valu_launch(la, lb, ep, M, K, N, 1, st, "linear_dgrad");
         }
       }
@@ -316,15 +337,12 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
     const int kc = (K + 63) / 64;
 #define RDST_LNB(KC)                                                                                              \
   hipLaunchKernelGGL((ln_bwd_rows_kernel<T, KC>), dim3(blocks), dim3(256), 0, st, dAsrc, X, ldx, stats, ln_w, dX, \
-                     lddx, accumulate, small, M, K)
+                     lddx, acc, ldacc, small, M, K)
     if (kc <= 1) RDST_LNB(1); else if (kc <= 2) RDST_LNB(2); else if (kc <= 4) RDST_LNB(4); else RDST_LNB(8);
 #undef RDST_LNB
     if (int rc = rdst_launch_status("ln_bwd_rows")) return rc;
     // slab is [blocks][2][K] -> reduce to a [2][K] scratch then copy out
-    float* out2 = small + (int64_t)kSmallBlocks * 2 * K;
-    if (int rc = slab_reduce(small, out2, blocks, 2 * K, st)) return rc;
-    if (dln_w) (void)hipMemcpyAsync(dln_w, out2, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
-    if (dln_b) (void)hipMemcpyAsync(dln_b, out2 + K, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
+    if (int rc = slab_reduce2(small, dln_w, dln_b, blocks, K, st)) return rc;
   }
   return 0;
 }
@@ -341,7 +359,7 @@ __global__ void __launch_bounds__(256) scale_to_f32_kernel(const T* __restrict__
 
 template <typename T>
 int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, const T* dY, int64_t lddy, T* dX,
-                int64_t lddx, int accumulate, float* dln_w, float* dln_b, float* wsp, int64_t M, int K, float s,
+                int64_t lddx, const T* acc, int64_t ldacc, float* dln_w, float* dln_b, float* wsp, int64_t M, int K, float s,
                 hipStream_t st) {
   float* dA = wsp;
   float* small = dA + M * K;
@@ -353,15 +371,11 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
   const int kc = (K + 63) / 64;
 #define RDST_LNB(KC)                                                                                           \
   hipLaunchKernelGGL((ln_bwd_rows_kernel<T, KC>), dim3(blocks), dim3(256), 0, st, dA, X, ldx, stats, ln_w, dX, \
-                     lddx, accumulate, small, M, K)
+                     lddx, acc, ldacc, small, M, K)
   if (kc <= 1) RDST_LNB(1); else if (kc <= 2) RDST_LNB(2); else if (kc <= 4) RDST_LNB(4); else RDST_LNB(8);
 #undef RDST_LNB
   if (int rc = rdst_launch_status("ln_bwd_rows")) return rc;
-  float* out2 = small + (int64_t)kSmallBlocks * 2 * K;
-  if (int rc = slab_reduce(small, out2, blocks, 2 * K, st)) return rc;
-  if (dln_w) (void)hipMemcpyAsync(dln_w, out2, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
-  if (dln_b) (void)hipMemcpyAsync(dln_b, out2 + K, sizeof(float) * K, hipMemcpyDeviceToDevice, st);
-  return 0;
+  return slab_reduce2(small, dln_w, dln_b, blocks, K, st);
 }
 
 }  // namespace
@@ -392,7 +406,8 @@ extern "C" size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N) {
 
 extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
                                   int in_act, const float* Wt, const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx,
-                                  int accumulate_dx, float* dW, float* dbias, float* dln_w, float* dln_b, void* workspace,
+                                  const void* dX_add, int64_t ld_dx_add, float* dW, float* dbias, float* dln_w, float* dln_b,
+                                  void* workspace,
                                   size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
                                   void* stream) {
   if (!X || !dY || !workspace) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: null pointer");
@@ -407,10 +422,10 @@ extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w
   float* wsp = (float*)workspace;
   if (!Wt) {
     if (dtype == RDST_F32)
-      return ln_only_bwd<float>((const float*)X, ld_x, ln_w, stats, (const float*)dY, ld_dy, (float*)dX, ld_dx, accumulate_dx, dln_w, dln_b, wsp, M, K, out_scale, st);
-    return ln_only_bwd<bf16>((const bf16*)X, ld_x, ln_w, stats, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, accumulate_dx, dln_w, dln_b, wsp, M, K, out_scale, st);
+      return ln_only_bwd<float>((const float*)X, ld_x, ln_w, stats, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dln_w, dln_b, wsp, M, K, out_scale, st);
+    return ln_only_bwd<bf16>((const bf16*)X, ld_x, ln_w, stats, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dln_w, dln_b, wsp, M, K, out_scale, st);
   }
   if (dtype == RDST_F32)
-    return bwd_t<float>((const float*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const float*)dY, ld_dy, (float*)dX, ld_dx, accumulate_dx, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
-  return bwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, accumulate_dx, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
+    return bwd_t<float>((const float*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
+  return bwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
 }

@@ -44,7 +44,7 @@ struct LinArgs {
   float* stats;                       // fwd + LN: (M,2) {mean, rstd}
   float* dA;                          // dgrad + LN: fp32 (M, Nout)
   const T* Xa; int64_t ldxa;          // dgrad: pre-activation X for act'
-  int accumulate;
+  const T* Acc; int64_t ldacc;        // dgrad: + dX_add
   int64_t M; int Kc; int Nout; float s;
   int Tn; int ldw; int nch;
 };
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
         } else if (p.dA) {
           ep.Yf32 = p.dA; ep.ldf = p.Nout;
         } else {
-          ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.accumulate = p.accumulate;
+          ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.Acc = p.Acc; ep.ldacc = p.ldacc;
         }
         tile_store_rows<T>(eps, vals, lane, slab * 32, p.M, n0 + ct * 32, p.Nout, ep);
       }
@@ -187,7 +187,7 @@ struct LnDgradArgs {
   const T* dY; int64_t lddy;      // (M, N)
   const float* Wt; int N, K;      // nn.Linear weight (N, K)
   const T* X; int64_t ldx; const float* stats; const float* gamma;
-  T* dX; int64_t lddx; int accumulate;
+  T* dX; int64_t lddx; const T* Acc; int64_t ldacc;   // dX = Acc + ...
   float* slab;                    // [grid][2][K]
   int64_t M; float s;
   int Tn, ldw;
@@ -296,13 +296,14 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln_kernel(const LnDgradArgs<T> 
                 for (int q = 0; q < 4; ++q) f[q] = rstd[ps] * (da[q] * gam[c][q] - s1[ps] - xh[q] * s2[ps]);
                 T* dst = p.dX + rr * p.lddx + col;
                 const bool vec = col + 4 <= K && (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
-                if (p.accumulate) {
-                  if (vec && sizeof(T) == 2) {
-                    const u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(dst);
+                if (p.Acc) {
+                  const T* ap = p.Acc + rr * p.ldacc + col;
+                  if (col + 4 <= K && sizeof(T) == 2 && (reinterpret_cast<uintptr_t>(ap) & 3) == 0) {
+                    const u32x2_a4 u = *reinterpret_cast<const u32x2_a4*>(ap);
                     f[0] += bf16lo(u.x); f[1] += bf16hi(u.x); f[2] += bf16lo(u.y); f[3] += bf16hi(u.y);
                   } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (col + q < K) f[q] += to_f32<T>(dst[q]);
+                    for (int q = 0; q < 4; ++q) if (col + q < K) f[q] += to_f32<T>(ap[q]);
                   }
                 }
                 if (vec && sizeof(T) == 2) {
@@ -591,11 +592,12 @@ int linear_fwd_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_
 
 template <typename T>
 int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const float* Wt, const T* dY, int64_t lddy,
-                      T* dX, int64_t lddx, int accumulate, float* dA, int64_t M, int K, int N, float s, hipStream_t st) {
+                      T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* dA, int64_t M, int K, int N, float s,
+                      hipStream_t st) {
   if (mfma_disabled() || !rows_ok<T>(dY, lddy)) return RDST_ENOTSUP;
   LinArgs<T> p{};
   p.A = dY; p.lda = lddy; p.in_act = in_act; p.Wt = Wt; p.wK = K; p.Y = dX; p.ldy = lddx;
-  p.dA = has_ln ? dA : nullptr; p.Xa = X; p.ldxa = ldx; p.accumulate = accumulate;
+  p.dA = has_ln ? dA : nullptr; p.Xa = X; p.ldxa = ldx; p.Acc = acc; p.ldacc = ldacc;
   p.M = M; p.Kc = N; p.Nout = K; p.s = s;
   return launch_lin<T, MODE_DGRAD>(p, st, "lin_dgrad_mfma");
 }
@@ -603,13 +605,13 @@ int linear_dgrad_mfma(const T* X, int64_t ldx, bool has_ln, int in_act, const fl
 // dgrad + LayerNorm backward in one kernel; writes dX and a [*nslab][2][K] slab of d(gamma)/d(beta) partials
 template <typename T>
 int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
-                         int64_t lddy, T* dX, int64_t lddx, int accumulate, float* slab, int* nslab, int64_t M, int K,
-                         int N, float s, hipStream_t st) {
+                         int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* slab, int* nslab,
+                         int64_t M, int K, int N, float s, hipStream_t st) {
   using MM = Mma<T>;
   if (mfma_disabled() || K > 128 || !dX) return RDST_ENOTSUP;
   LnDgradArgs<T> p{};
   p.dY = dY; p.lddy = lddy; p.Wt = Wt; p.N = N; p.K = K; p.X = X; p.ldx = ldx; p.stats = stats; p.gamma = gamma;
-  p.dX = dX; p.lddx = lddx; p.accumulate = accumulate; p.slab = slab; p.M = M; p.s = s;
+  p.dX = dX; p.lddx = lddx; p.Acc = acc; p.ldacc = ldacc; p.slab = slab; p.M = M; p.s = s;
   p.Tn = (N + MM::KP - 1) / MM::KP;
   if (p.Tn > 32) return RDST_ENOTSUP;
   p.ldw = lds_row_bytes(N, sizeof(T));
@@ -674,11 +676,12 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
 
 #define INST(T)                                                                                                        \
   template int linear_dgrad_ln_mfma<T>(const T*, int64_t, const float*, const float*, const float*, const T*, int64_t, \
-                                       T*, int64_t, int, float*, int*, int64_t, int, int, float, hipStream_t);         \
+                                       T*, int64_t, const T*, int64_t, float*, int*, int64_t, int, int, float,         \
+                                       hipStream_t);                                                                   \
   template int linear_fwd_mfma<T>(const T*, int64_t, const float*, const float*, int, const float*, const float*,     \
                                   const T*, int64_t, T*, int64_t, float*, int64_t, int, int, float, hipStream_t);     \
-  template int linear_dgrad_mfma<T>(const T*, int64_t, bool, int, const float*, const T*, int64_t, T*, int64_t, int,  \
-                                    float*, int64_t, int, int, float, hipStream_t);                                   \
+  template int linear_dgrad_mfma<T>(const T*, int64_t, bool, int, const float*, const T*, int64_t, T*, int64_t,       \
+                                    const T*, int64_t, float*, int64_t, int, int, float, hipStream_t);                \
   template int linear_wgrad_mfma<T>(const T*, int64_t, const float*, const float*, const float*, int, const T*,       \
                                     int64_t, float*, float*, float*, int64_t, int, int, float, hipStream_t);
 INST(float)

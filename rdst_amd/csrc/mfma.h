@@ -127,7 +127,8 @@ static inline int lds_row_bytes(int kelems, int esize) {
 struct TileEpilogue {
   const void* R; int64_t ldr;        // + R[row][col]                        (forward residual)
   const void* Xa; int64_t ldxa; int act;  // * act'(Xa[row][col])            (dgrad through an input activation)
-  void* Y; int64_t ldy; int accumulate;   // Y (+)= value
+  void* Y; int64_t ldy;                   // Y = value (+ ...)
+  const void* Acc; int64_t ldacc;         // + Acc[row][col]  (dX_add of the backward; may alias Y)
   float* Yf32; int64_t ldf;          // alternative fp32 destination (dgrad in front of a LayerNorm)
 };
 
@@ -177,7 +178,7 @@ __device__ __forceinline__ void tile_store_rows(float* __restrict__ eps, const f
       };
       if (xp) add4(xp, true);
       if (rp) add4(rp, false);
-      if (e.accumulate) add4(dst, false);
+      if (e.Acc) add4(reinterpret_cast<const T*>(e.Acc) + rr * e.ldacc + col, false);
       if (full && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
         if (sizeof(T) == 2) {
           u32x2_a4 u;

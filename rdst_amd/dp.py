@@ -17,7 +17,14 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
-    """Owns one contiguous fp32 buffer; ``p.grad`` of every trainable parameter is a view of it."""
+    """Owns one contiguous fp32 buffer; ``p.grad`` of every trainable parameter is a view of it.
+
+    Two ways to fill it:
+      * ``zero()`` then ``backward()``: autograd ACCUMULATES into the views (one small add kernel per
+        parameter, 750 for RDST-E1);
+      * ``detach_grads()`` then ``backward()`` then ``gather()``: autograd ASSIGNS fresh gradient tensors
+        (no adds, no memset) and ``gather()`` flattens them into the bucket with a handful of batched copy
+        kernels and re-points ``p.grad`` at the views.  This is what bench.py captures into its HIP graph."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -40,6 +47,24 @@ class FlatGradBucket:
     def zero(self) -> None:
         """One memset instead of 750 (replaces optimizer.zero_grad(), trans_sr_trainer.py:170)."""
         self.flat.zero_()
+
+    def detach_grads(self) -> None:
+        """Forget the views: the next backward() assigns new gradient tensors instead of accumulating."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self) -> None:
+        """Flatten the freshly assigned gradients into the bucket (parameters the loss does not reach get
+        zeros) and make ``p.grad`` the bucket views again."""
+        pieces = []
+        for p in self.params:
+            g = p.grad
+            pieces.append(torch.zeros_like(p).reshape(-1) if g is None else g.reshape(-1))
+        torch.cat(pieces, out=self.flat)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
 
     def check_views(self) -> bool:
         """True while every p.grad still aliases the bucket (zero_grad(set_to_none=True) breaks it)."""

@@ -178,11 +178,17 @@ class SwinTransformerBlock(nn.Module):
     def forward(self, x, x_size):
         H, W = x_size
         n1w, n1b = _ln_params(self.norm1)
-        qkv = ops.ln_linear(x, n1w, n1b, self.attn.qkv.weight, self.attn.qkv.bias)
-        a = ops.window_attention(qkv, self.attn.relative_position_bias_table, H, W, self.num_heads,
-                                 self.window_size, self.shift_size, self.attn.scale)
-        x = ops.ln_linear(a, None, None, self.attn.proj.weight, self.attn.proj.bias, residual=x)
-        return self.mlp(x, norm=self.norm2, residual=x)
+        n2w, n2b = _ln_params(self.norm2)
+        at, mlp = self.attn, self.mlp
+        if at.qkv.bias is None:  # qkv_bias=False: fall back to the op-level chain
+            qkv = ops.ln_linear(x, n1w, n1b, at.qkv.weight, None)
+            a = ops.window_attention(qkv, at.relative_position_bias_table, H, W, self.num_heads, self.window_size,
+                                     self.shift_size, at.scale)
+            x = ops.ln_linear(a, None, None, at.proj.weight, at.proj.bias, residual=x)
+            return self.mlp(x, norm=self.norm2, residual=x)
+        return ops.swin_block(x, n1w, n1b, at.qkv.weight, at.qkv.bias, at.relative_position_bias_table, at.proj.weight,
+                              at.proj.bias, n2w, n2b, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, H, W,
+                              self.num_heads, self.window_size, self.shift_size, at.scale)
 
     def extra_repr(self) -> str:
         return f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, " \

@@ -185,6 +185,31 @@ def window_attention(qkv: torch.Tensor, table: torch.Tensor, H: int, W: int, hea
     return _WindowAttention.apply(qkv, table, mask, H, W, heads, ws, shift, scale)
 
 
+def _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy, lddy, dx, lddx, dx_add, ld_add, dw, db, dlw, dlb,
+                     M, K, N, out_scale, code, dev):
+    """rdst_ln_linear_bwd with the weight-gradient half on the side stream (see TWO_STREAM_BACKWARD)."""
+    nbytes = lib.rdst_ln_linear_bwd_workspace(M, K, N)
+
+    def call(dx_, add_, dw_, db_, dlw_, dlb_, wsp_):
+        _lib.check(lib.rdst_ln_linear_bwd(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
+                                          dy.data_ptr(), lddy, _ptr(dx_), lddx, _ptr(add_), ld_add, _ptr(dw_), _ptr(db_),
+                                          _ptr(dlw_), _ptr(dlb_), wsp_.data_ptr(), nbytes, M, K, N, out_scale, code,
+                                          _stream()), "rdst_ln_linear_bwd")
+
+    wgrad = dw is not None or db is not None
+    dgrad = dx is not None or dlw is not None or dlb is not None
+    if TWO_STREAM_BACKWARD and wgrad and dgrad:
+        cur, side = torch.cuda.current_stream(), _side_stream(dev)
+        wsp_w, wsp_d = _workspace(nbytes, dev), _workspace(nbytes, dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            call(None, None, dw, db, None, None, wsp_w)
+        call(dx, dx_add, None, None, dlw, dlb, wsp_d)
+        cur.wait_stream(side)
+    elif wgrad or dgrad:
+        call(dx, dx_add, dw, db, dlw, dlb, _workspace(nbytes, dev))
+
+
 # ------------------------------------------------------------------------------------------------
 # K3: (LayerNorm | activation ->) Linear (-> *scale + residual)
 # ------------------------------------------------------------------------------------------------
@@ -225,28 +250,8 @@ class _LnLinear(torch.autograd.Function):
         dlb = torch.empty_like(lb) if (lb is not None and need[2]) else None
         dw = torch.empty_like(w) if (w is not None and need[3]) else None
         db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[4]) else None
-        nbytes = lib.rdst_ln_linear_bwd_workspace(M, K, N)
-        code = _dtype_code(x)
-
-        def call(dx_, dw_, db_, dlw_, dlb_, wsp_):
-            _lib.check(lib.rdst_ln_linear_bwd(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
-                                              dy_r.data_ptr(), lddy, _ptr(dx_), K, 0, _ptr(dw_), _ptr(db_), _ptr(dlw_),
-                                              _ptr(dlb_), wsp_.data_ptr(), nbytes, M, K, N, out_scale, code, _stream()),
-                       "rdst_ln_linear_bwd")
-
-        wgrad = dw is not None or db is not None
-        dgrad = dx is not None or dlw is not None or dlb is not None
-        if TWO_STREAM_BACKWARD and wgrad and dgrad:
-            cur, side = torch.cuda.current_stream(), _side_stream(dev)
-            wsp_w = _workspace(nbytes, dev)
-            wsp_d = _workspace(nbytes, dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                call(None, dw, db, None, None, wsp_w)
-            call(dx, None, None, dlw, dlb, wsp_d)
-            cur.wait_stream(side)
-        else:
-            call(dx, dw, db, dlw, dlb, _workspace(nbytes, dev))
+        _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy_r, lddy, dx, K, None, 0, dw, db, dlw, dlb, M, K, N,
+                         out_scale, _dtype_code(x), dev)
         dres = dy if (has_res and need[5]) else None
         return dx, dlw, dlb, dw, db, dres, None, None
 
@@ -258,6 +263,117 @@ def ln_linear(x: torch.Tensor, ln_w: Optional[torch.Tensor], ln_b: Optional[torc
     activation ``in_act`` or identity; weight None = LayerNorm only.  One fused HIP op replacing the
     reference's LayerNorm/Linear/GELU/add sequences (see include/rdst_hip.h, K3)."""
     return _LnLinear.apply(x, ln_w, ln_b, weight, bias, residual, in_act, out_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# A whole Swin block as ONE autograd node (5 forward kernels, backward chain called directly)
+# ------------------------------------------------------------------------------------------------
+class _SwinBlock(torch.autograd.Function):
+    """y = x1 + fc2(GELU(fc1(LN2(x1)))),  x1 = x + proj(WindowAttention(qkv(LN1(x)))).
+    One node instead of five: the backward runs the kernels in dependency order and folds the two
+    residual fan-out sums into the dgrad kernels (dX = dX_add + ...), so no gradient-accumulation add
+    kernels and no intermediate gradient copies are launched."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, H, W, heads, ws,
+                shift, scale):
+        _need_gpu(x, qkvw, table, projw, fc1w, fc2w)
+        lib = _lib.load()
+        C = x.shape[-1]
+        M = x.numel() // C
+        B = M // (H * W)
+        hid = fc1w.shape[0]
+        code = _dtype_code(x)
+        dev, dt = x.device, x.dtype
+        x_r, ldx = _rows(x)
+        P = [_param(t) for t in (n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b)]
+        n1w_, n1b_, qkvw_, qkvb_, tab_, projw_, projb_, n2w_, n2b_, fc1w_, fc1b_, fc2w_, fc2b_ = P
+        lead = x.shape[:-1]
+        st = _stream()
+
+        def lin(xp, ld, lw, lb, act, w, b, rp, ldr, out, N, stats, K):
+            _lib.check(lib.rdst_ln_linear_fwd(xp, ld, _ptr(lw), _ptr(lb), act, w.data_ptr(), _ptr(b), rp, ldr,
+                                              out.data_ptr(), N, _ptr(stats), M, K, N, 1.0, code, st), "rdst_ln_linear_fwd")
+
+        stats1 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n1w_ is not None else None
+        qkv = torch.empty(lead + (3 * C,), dtype=dt, device=dev)
+        lin(x_r.data_ptr(), ldx, n1w_, n1b_, ACT_NONE, qkvw_, qkvb_, None, 0, qkv, 3 * C, stats1, C)
+        a = torch.empty(lead + (C,), dtype=dt, device=dev)
+        kt = _kernel_timer
+        e0 = _event() if kt is not None else None
+        _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C, heads,
+                                      ws, shift, float(scale), code, st), "rdst_wattn_fwd")
+        if kt is not None:
+            kt.fwd.append((e0, _event(), M * 4 * C * x.element_size()))
+        x1 = torch.empty(lead + (C,), dtype=dt, device=dev)
+        lin(a.data_ptr(), C, None, None, ACT_NONE, projw_, projb_, x_r.data_ptr(), ldx, x1, C, None, C)
+        stats2 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n2w_ is not None else None
+        h = torch.empty(lead + (hid,), dtype=dt, device=dev)
+        lin(x1.data_ptr(), C, n2w_, n2b_, ACT_NONE, fc1w_, fc1b_, None, 0, h, hid, stats2, C)
+        y = torch.empty(lead + (C,), dtype=dt, device=dev)
+        lin(h.data_ptr(), hid, None, None, ACT_GELU, fc2w_, fc2b_, x1.data_ptr(), C, y, C, None, hid)
+        ctx.save_for_backward(x_r, stats1, qkv, a, x1, stats2, h, *P)
+        ctx.meta = (M, B, H, W, C, hid, heads, ws, shift, float(scale), ldx, code)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, stats1, qkv, a, x1, stats2, h, n1w, n1b, qkvw, qkvb, tab, projw, projb, n2w, n2b, fc1w, fc1b, fc2w,
+         fc2b) = ctx.saved_tensors
+        M, B, H, W, C, hid, heads, ws, shift, scale, ldx, code = ctx.meta
+        lib = _lib.load()
+        dev, dt = x.device, x.dtype
+        need = ctx.needs_input_grad
+        dy_r, lddy = _rows(dy)
+
+        def g(t, flag):
+            return torch.empty_like(t) if (t is not None and flag) else None
+
+        dn1w, dn1b, dqkvw, dqkvb = g(n1w, need[1]), g(n1b, need[2]), g(qkvw, need[3]), g(qkvb, need[4])
+        dprojw, dprojb = g(projw, need[6]), g(projb, need[7])
+        dn2w, dn2b, dfc1w, dfc1b = g(n2w, need[8]), g(n2b, need[9]), g(fc1w, need[10]), g(fc1b, need[11])
+        dfc2w, dfc2b = g(fc2w, need[12]), g(fc2b, need[13])
+        # fc2 (reads h through GELU):  dh = (dy W2) * gelu'(h)
+        dh = torch.empty_like(h)
+        _linear_bwd_call(lib, h, hid, None, None, None, ACT_GELU, fc2w, dy_r, lddy, dh, hid, None, 0, dfc2w, dfc2b, None,
+                         None, M, hid, C, 1.0, code, dev)
+        # LN2 + fc1, plus the residual fan-out of x1:  dx1 = dy + LN2'(dh W1)
+        dx1 = torch.empty_like(x1)
+        _linear_bwd_call(lib, x1, C, n2w, n2b, stats2, ACT_NONE, fc1w, dh, hid, dx1, C, dy_r, lddy, dfc1w, dfc1b, dn2w,
+                         dn2b, M, C, hid, 1.0, code, dev)
+        del dh
+        # proj:  da = dx1 Wp
+        da = torch.empty_like(a)
+        _linear_bwd_call(lib, a, C, None, None, None, ACT_NONE, projw, dx1, C, da, C, None, 0, dprojw, dprojb, None, None,
+                         M, C, C, 1.0, code, dev)
+        # window attention
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.empty_like(tab)
+        nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
+        wsp = _workspace(nbytes, dev)
+        kt = _kernel_timer
+        e0 = _event() if kt is not None else None
+        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), 3 * C, tab.data_ptr(), None, 0, da.data_ptr(), C, dqkv.data_ptr(),
+                                      3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C, heads, ws, shift, scale,
+                                      code, _stream()), "rdst_wattn_bwd")
+        if kt is not None:
+            kt.bwd.append((e0, _event(), M * 7 * C * x.element_size()))
+        del da
+        # LN1 + qkv, plus the residual fan-out of x:  dx = dx1 + LN1'(dqkv Wqkv)
+        dx = torch.empty(x.shape, dtype=dt, device=dev) if need[0] else None
+        _linear_bwd_call(lib, x, ldx, n1w, n1b, stats1, ACT_NONE, qkvw, dqkv, 3 * C, dx, C, dx1 if need[0] else None, C,
+                         dqkvw, dqkvb, dn1w, dn1b, M, C, 3 * C, 1.0, code, dev)
+        if not need[5]:
+            dtab = None
+        return (dx, dn1w, dn1b, dqkvw, dqkvb, dtab, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b,
+                None, None, None, None, None, None)
+
+
+def swin_block(x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, H, W, heads, ws, shift,
+               scale):
+    """SwinTransformerBlock.forward (networks/swin_transformer_sr.py:234-274) as one autograd node."""
+    return _SwinBlock.apply(x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, H, W, heads,
+                            ws, shift, scale)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -308,7 +424,7 @@ class _ConvRows(torch.autograd.Function):
 
         def call(dx_, dw_, db_, wsp_):
             _lib.check(lib.rdst_conv_bwd(x.data_ptr(), ldx, in_act, w.data_ptr(), dy_r.data_ptr(), lddy, _ptr(dx_), Cin,
-                                         0, _ptr(dw_), _ptr(db_), wsp_.data_ptr(), nbytes, B, H, W, Cin, Cout, k,
+                                         None, 0, _ptr(dw_), _ptr(db_), wsp_.data_ptr(), nbytes, B, H, W, Cin, Cout, k,
                                          out_scale, r, code, _stream()), "rdst_conv_bwd")
 
         if TWO_STREAM_BACKWARD and dx is not None and (dw is not None or db is not None):

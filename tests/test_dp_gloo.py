@@ -40,9 +40,14 @@ def _worker(rank, world, port, q):
     t = torch.rand(4, 1, 8, 8, generator=g)
     xs, ts = x[rank * 2:(rank + 1) * 2], t[rank * 2:(rank + 1) * 2]     # this rank's shard of the global batch
     opt = torch.optim.Adam(bucket.params, lr=1e-2)
-    for _ in range(2):
-        bucket.zero()
-        F.l1_loss(net(xs), ts).backward()
+    for it in range(2):
+        if it == 0:                       # both filling protocols give the same bucket
+            bucket.zero()
+            F.l1_loss(net(xs), ts).backward()
+        else:
+            bucket.detach_grads()
+            F.l1_loss(net(xs), ts).backward()
+            bucket.gather()
         bucket.all_reduce_mean()
         assert bucket.check_views()
         opt.step()
