@@ -186,8 +186,10 @@ def window_attention(qkv: torch.Tensor, table: torch.Tensor, H: int, W: int, hea
 
 
 def _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy, lddy, dx, lddx, dx_add, ld_add, dw, db, dlw, dlb,
-                     M, K, N, out_scale, code, dev):
-    """rdst_ln_linear_bwd with the weight-gradient half on the side stream (see TWO_STREAM_BACKWARD)."""
+                     M, K, N, out_scale, code, dev, join=True, keep=None):
+    """rdst_ln_linear_bwd with the weight-gradient half on the side stream (see TWO_STREAM_BACKWARD).
+    join=False leaves the side stream un-joined (the caller joins once, later) and parks the workspace in
+    `keep` so it outlives the asynchronous kernel."""
     nbytes = lib.rdst_ln_linear_bwd_workspace(M, K, N)
 
     def call(dx_, add_, dw_, db_, dlw_, dlb_, wsp_):
@@ -205,7 +207,10 @@ def _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy, lddy, dx, lddx, 
         with torch.cuda.stream(side):
             call(None, None, dw, db, None, None, wsp_w)
         call(dx, dx_add, None, None, dlw, dlb, wsp_d)
-        cur.wait_stream(side)
+        if join:
+            cur.wait_stream(side)
+        elif keep is not None:
+            keep.append(wsp_w)
     elif wgrad or dgrad:
         call(dx, dx_add, dw, db, dlw, dlb, _workspace(nbytes, dev))
 
@@ -333,19 +338,22 @@ class _SwinBlock(torch.autograd.Function):
         dprojw, dprojb = g(projw, need[6]), g(projb, need[7])
         dn2w, dn2b, dfc1w, dfc1b = g(n2w, need[8]), g(n2b, need[9]), g(fc1w, need[10]), g(fc1b, need[11])
         dfc2w, dfc2b = g(fc2w, need[12]), g(fc2b, need[13])
+        # The four weight-gradient kernels are leaves: they go to the side stream and are joined ONCE at the
+        # end of this block's backward, so they overlap the whole data-gradient chain below.  Everything they
+        # read (saved activations, dy, dh, dx1, dqkv, their workspaces) stays referenced until then.
+        keep = []
         # fc2 (reads h through GELU):  dh = (dy W2) * gelu'(h)
         dh = torch.empty_like(h)
         _linear_bwd_call(lib, h, hid, None, None, None, ACT_GELU, fc2w, dy_r, lddy, dh, hid, None, 0, dfc2w, dfc2b, None,
-                         None, M, hid, C, 1.0, code, dev)
+                         None, M, hid, C, 1.0, code, dev, join=False, keep=keep)
         # LN2 + fc1, plus the residual fan-out of x1:  dx1 = dy + LN2'(dh W1)
         dx1 = torch.empty_like(x1)
         _linear_bwd_call(lib, x1, C, n2w, n2b, stats2, ACT_NONE, fc1w, dh, hid, dx1, C, dy_r, lddy, dfc1w, dfc1b, dn2w,
-                         dn2b, M, C, hid, 1.0, code, dev)
-        del dh
+                         dn2b, M, C, hid, 1.0, code, dev, join=False, keep=keep)
         # proj:  da = dx1 Wp
         da = torch.empty_like(a)
         _linear_bwd_call(lib, a, C, None, None, None, ACT_NONE, projw, dx1, C, da, C, None, 0, dprojw, dprojb, None, None,
-                         M, C, C, 1.0, code, dev)
+                         M, C, C, 1.0, code, dev, join=False, keep=keep)
         # window attention
         dqkv = torch.empty_like(qkv)
         dtab = torch.empty_like(tab)
@@ -358,11 +366,12 @@ class _SwinBlock(torch.autograd.Function):
                                       code, _stream()), "rdst_wattn_bwd")
         if kt is not None:
             kt.bwd.append((e0, _event(), M * 7 * C * x.element_size()))
-        del da
         # LN1 + qkv, plus the residual fan-out of x:  dx = dx1 + LN1'(dqkv Wqkv)
         dx = torch.empty(x.shape, dtype=dt, device=dev) if need[0] else None
         _linear_bwd_call(lib, x, ldx, n1w, n1b, stats1, ACT_NONE, qkvw, dqkv, 3 * C, dx, C, dx1 if need[0] else None, C,
-                         dqkvw, dqkvb, dn1w, dn1b, M, C, 3 * C, 1.0, code, dev)
+                         dqkvw, dqkvb, dn1w, dn1b, M, C, 3 * C, 1.0, code, dev, join=False, keep=keep)
+        if TWO_STREAM_BACKWARD:
+            torch.cuda.current_stream().wait_stream(_side_stream(dev))   # the one join of this block
         if not need[5]:
             dtab = None
         return (dx, dn1w, dn1b, dqkvw, dqkvb, dtab, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b,
