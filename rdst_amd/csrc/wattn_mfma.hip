@@ -362,5 +362,9 @@ int wattn_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, i
                    float scale, int dtype, hipStream_t st) {
   if (mfma_disabled()) return RDST_ENOTSUP;
   if (dtype == RDST_F32) return launch_fwd<float>((const float*)qkv, ld, table, (float*)out, ldo, g, scale, st);
+  {  // the compile-time-specialised kernel (6 heads of dim 10/15/20) where it applies
+    const int rc = wattn_fwd_mfma_hd(qkv, ld, table, out, ldo, g, scale, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   return launch_fwd<bf16>((const bf16*)qkv, ld, table, (bf16*)out, ldo, g, scale, st);
 }
