@@ -139,6 +139,16 @@ int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int B, int C, i
 int rdst_rows_to_nchw(const void* rows, int64_t ld, float* nchw, int B, int C, int H, int W,
                       int dtype, void* stream);
 
+/* ---- fused Adam over flat buffers ------------------------------------------------
+ * One launch updates all `n` fp32 parameters in place with torch.optim.Adam's rule (amsgrad off),
+ * the optimizer utils/optim.py:30-53 builds and models/trans_sr_trainer.py:170-173 steps:
+ *   g = grad + weight_decay*p;  m += (g - m)(1 - beta1);  v = v*beta2 + (1 - beta2) g^2;
+ *   p -= lr/(1 - beta1^step) * m / (sqrt(v)/sqrt(1 - beta2^step) + eps)
+ * `step` is the 1-based count of this update.  All four buffers are 16-byte aligned device fp32. */
+int rdst_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
