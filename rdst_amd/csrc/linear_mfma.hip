@@ -395,9 +395,9 @@ template <typename T> bool rows_ok(const void*, int64_t) { return true; }  // lo
 // ------------------------------------------------------------------------------------------------
 // wgrad
 // ------------------------------------------------------------------------------------------------
-constexpr int WG_WAVES = 16;    // waves per workgroup (one workgroup per CU: 4 waves per SIMD)
+constexpr int WG_WAVES = 8;     // waves per workgroup, one workgroup per CU: 2 waves per SIMD, 256 VGPRs each
 constexpr int WG_THREADS = 64 * WG_WAVES;
-constexpr int WG_MAXT = 3;      // accumulator tiles per wave (16 waves -> 48 tiles = 360 x 121 max)
+constexpr int WG_MAXT = 6;      // accumulator tiles per wave (8 waves -> 48 tiles = 360 x 121 max)
 constexpr int WG_STRIPE = 32;   // token rows staged per step
 
 template <typename T>
@@ -411,14 +411,28 @@ struct WgradArgs {
   int NT, KT;
 };
 
-template <typename T>
+// The whole kernel is a memory pipeline: 2*M*(K+N)*elt bytes stream through once and the MFMA work is
+// small (2 k-steps per tile and 32-row stripe), so what matters is (a) how many bytes each CU keeps in
+// flight and (b) how few instructions a stripe costs (8 waves: the kernel is instruction-issue bound
+// before it is bandwidth bound).  PF stripes are prefetched into registers ahead of the one being
+// multiplied, the LDS tiles are double buffered (one barrier per stripe), LayerNorm's gamma/beta sit
+// in LDS, and every address is a precomputed per-thread offset plus a wave-uniform base.
+// XF: transform of X while it is staged — 0 none, 1 LayerNorm, 2 GELU, 3 any other activation
+template <typename T, int PF, int XF>
 __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using MM = Mma<T>;
   constexpr int HP = MM::HP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  char* dYs = smem;
-  char* Xs = smem + (size_t)WG_STRIPE * p.ldn;
+  constexpr int ES = (int)sizeof(T);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int buf_bytes = WG_STRIPE * (p.ldn + p.ldk);
+  float* gam = reinterpret_cast<float*>(smem + 2 * (size_t)buf_bytes);  // [KT*32] gamma, then [KT*32] beta
+  float* bet = gam + p.KT * 32;
+  if (XF == 1)
+    for (int k = tid; k < p.KT * 32; k += WG_THREADS) {
+      gam[k] = k < p.K ? p.lnw[k] : 0.f;
+      bet[k] = k < p.K ? p.lnb[k] : 0.f;
+    }
   f32x16 acc[WG_MAXT];
 #pragma unroll
   for (int j = 0; j < WG_MAXT; ++j)
@@ -429,111 +443,216 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
   const int64_t m_end = (m_begin + p.rows_per_wg < p.M) ? m_begin + p.rows_per_wg : p.M;
   const int npk = p.NT * 32 / HP, kpk = p.KT * 32 / HP;
 
-  // Per-thread staging plan (loop invariant): which (stripe row, pack) of dY / X this thread moves.
-  constexpr int DYMAX = (12 + HP - 1) / HP, XMAX = 8 / HP;  // 32 rows x (NT*32 <= 384 | KT*32 <= 256) elements over 1024 threads
-  int dy_row[DYMAX], dy_pk[DYMAX], x_row[XMAX], x_pk[XMAX];
+  // Per-thread staging plan (loop invariant): which (stripe row, pack) of dY / X this thread moves:
+  // 32 rows x (NT*32 <= 384 | KT*32 <= 256) elements over 512 threads.
+  // A pack that would run past the row's last element is loaded as the row's LAST full 16 bytes and
+  // shifted down in registers (never reads outside the row); what is shifted in above the row's end is
+  // don't-care: it only reaches accumulator rows / columns that are never stored, or is overwritten by
+  // the X transform (zeros, ones column).  Rows are dword aligned (checked by the launcher).
+  constexpr int DYMAX = (24 + HP - 1) / HP, XMAX = 16 / HP;
+  int dy_row[DYMAX], x_row[XMAX];       // stripe row, -1 = slot unused
+  int dy_col[DYMAX], x_col[XMAX];       // byte offset of the 16-B load inside the global row
+  int dy_sh[DYMAX], x_sh[XMAX];         // right shift in bytes after the load (0 = full pack)
+  int dy_lds[DYMAX], x_lds[XMAX];       // byte offset inside the LDS tile
+  int x_k0[XMAX];
 #pragma unroll
   for (int i = 0; i < DYMAX; ++i) {
     const int idx = tid + WG_THREADS * i;
-    dy_row[i] = idx < WG_STRIPE * npk ? idx / npk : -1;
-    dy_pk[i] = idx - (idx / npk) * npk;
+    const int row = idx / npk, pk = idx - row * npk;
+    int k0 = pk * HP;
+    dy_row[i] = idx < WG_STRIPE * npk ? row : -1;
+    dy_lds[i] = row * p.ldn + pk * 16;
+    if (k0 >= p.N) k0 = 0;  // slot entirely past the row: any in-row pack will do (feeds unstored rows)
+    dy_sh[i] = (k0 + HP > p.N) ? (k0 + HP - p.N) * ES : 0;
+    dy_col[i] = k0 * ES - dy_sh[i];
   }
 #pragma unroll
   for (int i = 0; i < XMAX; ++i) {
     const int idx = tid + WG_THREADS * i;
-    x_row[i] = idx < WG_STRIPE * kpk ? idx / kpk : -1;
-    x_pk[i] = idx - (idx / kpk) * kpk;
+    const int row = idx / kpk, pk = idx - row * kpk;
+    const int k0 = pk * HP;
+    x_row[i] = idx < WG_STRIPE * kpk ? row : -1;
+    x_lds[i] = WG_STRIPE * p.ldn + row * p.ldk + pk * 16;
+    x_k0[i] = k0;
+    const int kl = k0 < p.K ? k0 : 0;
+    x_sh[i] = (kl + HP > p.K) ? (kl + HP - p.K) * ES : 0;
+    x_col[i] = kl * ES - x_sh[i];
   }
-  Pack16 rdy[DYMAX], rx[XMAX];
-  float rmean[XMAX], rrstd[XMAX];
-  auto prefetch = [&](int64_t m0) {
+  auto shift_pack = [&](Pack16& q, int sh_bytes) {  // q >>= 8*sh_bytes over the 128-bit pack
+    const int dq = sh_bytes >> 2;
+    if (dq & 1) { q.w[0] = q.w[1]; q.w[1] = q.w[2]; q.w[2] = q.w[3]; }
+    if (dq & 2) { q.w[0] = q.w[2]; q.w[1] = q.w[3]; }
+    const uint32_t bs = (uint32_t)(sh_bytes & 3);
+    q.w[0] = __builtin_amdgcn_alignbyte(q.w[1], q.w[0], bs);
+    q.w[1] = __builtin_amdgcn_alignbyte(q.w[2], q.w[1], bs);
+    q.w[2] = __builtin_amdgcn_alignbyte(q.w[3], q.w[2], bs);
+    q.w[3] = __builtin_amdgcn_alignbyte(q.w[3], q.w[3], bs);
+  };
+  auto ld16 = [&](const char* base, uint32_t off) {
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(base + off);
+    Pack16 q;
+    q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
+    return q;
+  };
+  Pack16 rdy[PF][DYMAX], rx[PF][XMAX];
+  float rmean[PF][XMAX], rrstd[PF][XMAX];
+  const int64_t ldy_b = p.lddy * ES, ldx_b = p.ldx * ES;
+  auto prefetch = [&](int set, int64_t m0) {
+    const int left = (int)(m_end - m0 < WG_STRIPE ? m_end - m0 : WG_STRIPE);  // valid rows of the stripe (>= 1)
+    const char* dyb = reinterpret_cast<const char*>(p.dY) + m0 * ldy_b;  // wave-uniform bases
+    const char* xb = reinterpret_cast<const char*>(p.X) + m0 * ldx_b;
+    const float* stb = p.stats + 2 * m0;
 #pragma unroll
     for (int i = 0; i < DYMAX; ++i)
       if (dy_row[i] >= 0) {
-        const bool valid = m0 + dy_row[i] < m_end;
-        rdy[i] = load_pack<T>(p.dY + (valid ? (m0 + dy_row[i]) : 0) * p.lddy, dy_pk[i] * HP, p.N, valid);
+        const int row = dy_row[i] < left ? dy_row[i] : left - 1;  // rows past the range: any real row (their X rows are zeroed)
+        rdy[set][i] = ld16(dyb, (uint32_t)(row * (int)ldy_b + dy_col[i]));
       }
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
       if (x_row[i] >= 0) {
-        const int64_t m = m0 + x_row[i];
-        const bool valid = m < m_end;
-        rx[i] = load_pack<T>(p.X + (valid ? m : 0) * p.ldx, x_pk[i] * HP, p.K, valid);
-        if (p.lnw) {
-          rmean[i] = valid ? p.stats[2 * m] : 0.f;
-          rrstd[i] = valid ? p.stats[2 * m + 1] : 0.f;
+        const int row = x_row[i] < left ? x_row[i] : left - 1;
+        rx[set][i] = ld16(xb, (uint32_t)(row * (int)ldx_b + x_col[i]));
+        if (XF == 1) {
+          const float2 ms = *reinterpret_cast<const float2*>(stb + 2 * row);
+          rmean[set][i] = ms.x;
+          rrstd[set][i] = ms.y;
         }
       }
   };
-  if (m_begin < m_end) prefetch(m_begin);
-
-  for (int64_t m0 = m_begin; m0 < m_end; m0 += WG_STRIPE) {
-    __syncthreads();  // previous stripe's MFMAs are done with the LDS tiles
+  // registers -> LDS tile `b`, with the X-side transform (LayerNorm / activation / ones column)
+  auto stash = [&](int set, int64_t m0, int b) {
+    char* tile = smem + b * buf_bytes;
+    const int left = (int)(m_end - m0 < WG_STRIPE ? m_end - m0 : WG_STRIPE);
 #pragma unroll
     for (int i = 0; i < DYMAX; ++i)
-      if (dy_row[i] >= 0) *reinterpret_cast<Pack16*>(dYs + (size_t)dy_row[i] * p.ldn + dy_pk[i] * 16) = rdy[i];
+      if (dy_row[i] >= 0) {
+        Pack16 q = rdy[set][i];
+        if (dy_sh[i]) shift_pack(q, dy_sh[i]);
+        *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
+      }
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
       if (x_row[i] >= 0) {
-        const bool valid = m0 + x_row[i] < m_end;
-        const int k0 = x_pk[i] * HP;
-        float f[HP];
-        MM::unpack(rx[i], f);
-        if (p.lnw) {
+        const bool valid = x_row[i] < left;
+        const int k0 = x_k0[i];
+        Pack16 q = rx[set][i];
+        if (x_sh[i]) shift_pack(q, x_sh[i]);
+        if (XF != 0 || !valid || k0 + HP > p.K) {
+          float f[HP];
+          MM::unpack(q, f);
+          if (XF == 1) {
+            const float4* g4 = reinterpret_cast<const float4*>(gam + k0);
+            const float4* b4 = reinterpret_cast<const float4*>(bet + k0);
+            float gv[HP], bv[HP];
 #pragma unroll
-          for (int e = 0; e < HP; ++e)
-            f[e] = (k0 + e < p.K) ? (f[e] - rmean[i]) * rrstd[i] * p.lnw[k0 + e] + p.lnb[k0 + e] : 0.f;
-        } else if (p.in_act) {
+            for (int e4 = 0; e4 < HP / 4; ++e4) {
+              const float4 g = g4[e4], bb = b4[e4];
+              gv[4 * e4] = g.x; gv[4 * e4 + 1] = g.y; gv[4 * e4 + 2] = g.z; gv[4 * e4 + 3] = g.w;
+              bv[4 * e4] = bb.x; bv[4 * e4 + 1] = bb.y; bv[4 * e4 + 2] = bb.z; bv[4 * e4 + 3] = bb.w;
+            }
+            const float rs = rrstd[set][i], mu = rmean[set][i];
 #pragma unroll
-          for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+            for (int e = 0; e < HP; ++e) f[e] = (f[e] - mu) * rs * gv[e] + bv[e];
+          } else if (XF == 2) {
+#pragma unroll
+            for (int e = 0; e < HP; ++e) f[e] = gelu_erf(f[e]);
+          } else if (XF == 3) {
+#pragma unroll
+            for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+          }
+          if (!valid || k0 + HP > p.K) {
+#pragma unroll
+            for (int e = 0; e < HP; ++e) {
+              if (!valid || k0 + e > p.K) f[e] = 0.f;
+              else if (k0 + e == p.K) f[e] = 1.0f;  // ones column: dW[:, K] = sum_m dY = d(bias)
+            }
+          }
+          q = MM::pack(f);
         }
-#pragma unroll
-        for (int e = 0; e < HP; ++e) {
-          if (!valid) f[e] = 0.f;
-          else if (k0 + e == p.K) f[e] = 1.0f;  // ones column: dW[:, K] = sum_m dY = d(bias)
-        }
-        *reinterpret_cast<Pack16*>(Xs + (size_t)x_row[i] * p.ldk + x_pk[i] * 16) = MM::pack(f);
+        *reinterpret_cast<Pack16*>(tile + x_lds[i]) = q;
       }
-    __syncthreads();
-    if (m0 + WG_STRIPE < m_end) prefetch(m0 + WG_STRIPE);  // in flight while this stripe is multiplied
+  };
+  // per-wave tile list and per-lane fragment offsets (loop invariant)
+  int tA[WG_MAXT], tB[WG_MAXT];
+  {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int laneA = sizeof(T) == 2 ? (8 * h + q) * p.ldn + (16 * (g & 1) + 4 * pp) * 2 : h * p.ldn + r * 4;
+    const int laneB = sizeof(T) == 2 ? (8 * h + q) * p.ldk + (16 * (g & 1) + 4 * pp) * 2 : h * p.ldk + r * 4;
 #pragma unroll
     for (int j = 0; j < WG_MAXT; ++j) {
       const int ti = wave + WG_WAVES * j;
-      if (ti < ntiles) {
-        const int nt = ti / p.KT, kt = ti - nt * p.KT;
-        if constexpr (sizeof(T) == 2) {
-          // transposed fragment reads: 16-lane group g covers 16 columns, 4 token rows per read
-          const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-          const int colA = nt * 32 + 16 * (g & 1) + 4 * pp;
-          const int colB = kt * 32 + 16 * (g & 1) + 4 * pp;
+      const int nt = ti / p.KT, kt = ti - nt * p.KT;
+      tA[j] = laneA + nt * 32 * ES;
+      tB[j] = WG_STRIPE * p.ldn + laneB + kt * 32 * ES;
+    }
+  }
+  // number of tiles of this wave (tiles wave, wave+8, ...): a wave-uniform count keeps the tile guards scalar
+  const int my_tiles = __builtin_amdgcn_readfirstlane(ntiles > wave ? (ntiles - wave + WG_WAVES - 1) / WG_WAVES : 0);
+  auto multiply = [&](int b) {
+    const char* tile = smem + b * buf_bytes;
+    if constexpr (sizeof(T) == 2) {
+      // transposed fragment reads (a 16-lane group covers 16 columns, 4 token rows per read), software
+      // pipelined: the next tile's fragments are in flight while this tile's MFMAs issue
+      typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+      constexpr int NMS = WG_STRIPE / 16;
+      Pack16 fa[2][NMS], fb[2][NMS];
+      auto frags = [&](int j, Pack16 (&A)[NMS], Pack16 (&B)[NMS]) {
 #pragma unroll
-          for (int ms = 0; ms < WG_STRIPE / 16; ++ms) {
-            const int rowb = ms * 16 + 8 * h + q;
-            Pack16 a, b;
-            {
-              typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-              const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(dYs + (size_t)rowb * p.ldn + colA * 2));
-              const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(dYs + (size_t)(rowb + 4) * p.ldn + colA * 2));
-              const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + (size_t)rowb * p.ldk + colB * 2));
-              const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(Xs + (size_t)(rowb + 4) * p.ldk + colB * 2));
-              const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
-              const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
-              a.w[0] = ua0.x; a.w[1] = ua0.y; a.w[2] = ua1.x; a.w[3] = ua1.y;
-              b.w[0] = ub0.x; b.w[1] = ub0.y; b.w[2] = ub1.x; b.w[3] = ub1.y;
-            }
-            MM::mma(acc[j], a, b);
-          }
-        } else {
-          const float* dYf = reinterpret_cast<const float*>(dYs);
-          const float* Xf = reinterpret_cast<const float*>(Xs);
-          const int lda = p.ldn / 4, ldb = p.ldk / 4;
+        for (int ms = 0; ms < NMS; ++ms) {
+          const char* ta = tile + ms * 16 * p.ldn;  // wave uniform
+          const char* tb = tile + ms * 16 * p.ldk;
+          const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + tA[j]));
+          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + 4 * p.ldn + tA[j]));
+          const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + tB[j]));
+          const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + 4 * p.ldk + tB[j]));
+          const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
+          const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
+          A[ms].w[0] = ua0.x; A[ms].w[1] = ua0.y; A[ms].w[2] = ua1.x; A[ms].w[3] = ua1.y;
+          B[ms].w[0] = ub0.x; B[ms].w[1] = ub0.y; B[ms].w[2] = ub1.x; B[ms].w[3] = ub1.y;
+        }
+      };
+      if (my_tiles > 0) frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int j = 0; j < WG_MAXT; ++j) {
+        if (j < my_tiles) {
+          if (j + 1 < WG_MAXT && j + 1 < my_tiles) frags(j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+#pragma unroll
+          for (int ms = 0; ms < NMS; ++ms) MM::mma(acc[j], fa[j & 1][ms], fb[j & 1][ms]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < WG_MAXT; ++j) {
+        if (j < my_tiles) {
 #pragma unroll 8
           for (int s2 = 0; s2 < WG_STRIPE / 2; ++s2) {
-            const float av = dYf[(2 * s2 + h) * lda + nt * 32 + r];
-            const float bv = Xf[(2 * s2 + h) * ldb + kt * 32 + r];
+            const float av = *reinterpret_cast<const float*>(tile + 2 * s2 * p.ldn + tA[j]);
+            const float bv = *reinterpret_cast<const float*>(tile + 2 * s2 * p.ldk + tB[j]);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
           }
         }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (m_begin + (int64_t)s * WG_STRIPE < m_end) prefetch(s, m_begin + (int64_t)s * WG_STRIPE);
+  __syncthreads();  // gamma / beta staged
+  int b = 0;
+  for (int64_t mg = m_begin; mg < m_end; mg += (int64_t)PF * WG_STRIPE) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int64_t m0 = mg + (int64_t)s * WG_STRIPE;
+      if (m0 < m_end) {
+        // tile b was last read two stripes ago and every wave has passed the barrier in between
+        stash(s, m0, b);
+        __syncthreads();
+        const int64_t mn = m0 + (int64_t)PF * WG_STRIPE;
+        if (mn < m_end) prefetch(s, mn);  // PF stripes ahead, in flight while this and the next ones are multiplied
+        multiply(b);
+        b ^= 1;
       }
     }
   }
@@ -649,6 +768,10 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   p.slab = slab; p.M = M; p.K = K; p.N = N; p.Kx = K + 1;
   p.NT = (N + 31) / 32; p.KT = (p.Kx + 31) / 32;
   if (p.NT * p.KT > WG_WAVES * WG_MAXT || p.NT > 12 || p.KT > 8) return RDST_ENOTSUP;
+  // the kernel moves whole 16-B packs: dword-aligned rows and at least one pack per row
+  if (K < Mma<T>::HP || N < Mma<T>::HP || ((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || (ldx * sizeof(T)) % 4 ||
+      (lddy * sizeof(T)) % 4 || (K * sizeof(T)) % 4 || (N * sizeof(T)) % 4)
+    return RDST_ENOTSUP;
   // LDS row strides: bf16 rows are read by ds_read_b64_tr_b16 (4 token rows x 64 B per 32 lanes):
   // stride = 64 (mod 256) bytes puts the 4 rows on disjoint bank ranges; fp32 rows are read 32
   // consecutive floats at a time, any stride works.
@@ -659,15 +782,22 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   };
   p.ldn = stride(p.NT * 32);
   p.ldk = stride(p.KT * 32);
-  const size_t smem = (size_t)WG_STRIPE * (p.ldn + p.ldk);
+  const size_t smem = (size_t)2 * WG_STRIPE * (p.ldn + p.ldk) + (size_t)2 * p.KT * 32 * sizeof(float);
   if (smem > 160 * 1024) return RDST_ENOTSUP;
   int64_t nwg = (M + WG_STRIPE - 1) / WG_STRIPE;
   if (nwg > 256) nwg = 256;
   p.rows_per_wg = (((M + nwg - 1) / nwg + WG_STRIPE - 1) / WG_STRIPE) * WG_STRIPE;
   nwg = (M + p.rows_per_wg - 1) / p.rows_per_wg;
-  auto kern = lin_wgrad_mfma_kernel<T>;
-  if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WG_THREADS), smem, st, p);
+  constexpr int PF = sizeof(T) == 2 ? 2 : 1;  // register sets of prefetched stripes
+  const int xf = ln_w ? 1 : in_act == RDST_ACT_GELU ? 2 : in_act ? 3 : 0;
+#define RDST_WG_LAUNCH(XF)                                                                                            \
+  {                                                                                                                  \
+    auto kern = lin_wgrad_mfma_kernel<T, PF, XF>;                                                                    \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WG_THREADS), smem, st, p);                                    \
+  }
+  if (xf == 0) RDST_WG_LAUNCH(0) else if (xf == 1) RDST_WG_LAUNCH(1) else if (xf == 2) RDST_WG_LAUNCH(2) else RDST_WG_LAUNCH(3)
+#undef RDST_WG_LAUNCH
   if (int rc = rdst_launch_status("lin_wgrad_mfma")) return rc;
   const int tot = N * p.Kx;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
