@@ -469,6 +469,10 @@ int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* 
   if (dtype == RDST_F32)
     return launch_bwd<float>((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
                              scale, nslab, st);
+  {  // the compile-time-specialised kernel (6 heads of dim 10/15/20) where it applies
+    const int rc = wattn_bwd_mfma_hd(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   return launch_bwd<bf16>((const bf16*)qkv, ld, table, (const bf16*)dout, ldd, (bf16*)dqkv, ldq, slab, slab_rows, g, scale,
                           nslab, st);
 }

@@ -14,38 +14,11 @@
 //     P stays un-normalised; 1/l is applied while the head's rows are merged into the wave's output
 //     tile(s), which go to LDS once per window as 8-B stores (4 channels of one query);
 //   * cross-half reductions use v_permlane32_swap instead of ds_bpermute.
-#include "common.h"
-#include "wattn.h"
-#include "mfma.h"
+#include "wattn_hd.h"
 #include <stdlib.h>
 
 namespace {
-
-constexpr int TSX = 16;  // LDS row stride (floats) of a staged table row (15 used)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-template <int GRAN> struct Chunk;
-template <> struct Chunk<16> { typedef u32x4_t type; };
-typedef uint32_t u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
-template <> struct Chunk<12> { typedef u32x3_a4 type; };  // C = 90: sections are 15 x 12 B, rows only dword aligned
-template <> struct Chunk<8> { typedef u32x2_t type; };
-
-#define LDS_AS __attribute__((address_space(3)))
-typedef LDS_AS char* lds_cp;
-
-template <typename CH> __device__ __forceinline__ void chunk_to_lds(char* dst, const CH& v) { *reinterpret_cast<CH*>(dst) = v; }
-template <> __device__ __forceinline__ void chunk_to_lds<u32x3_a4>(char* dst, const u32x3_a4& v) {
-  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-  d[0] = v.x; d[1] = v.y; d[2] = v.z;
-}
-template <typename CH> __device__ __forceinline__ CH chunk_from_lds(const char* src) { return *reinterpret_cast<const CH*>(src); }
-template <> __device__ __forceinline__ u32x3_a4 chunk_from_lds<u32x3_a4>(const char* src) {
-  const uint32_t* d = reinterpret_cast<const uint32_t*>(src);
-  u32x3_a4 v;
-  v.x = d[0]; v.y = d[1]; v.z = d[2];
-  return v;
-}
+using namespace wahd;
 
 struct HdArgs {
   const bf16* qkv; int64_t ld;
@@ -75,26 +48,6 @@ struct Hd {
 };
 
 template <int D, int HEADS> struct TotT { f32x16 t[Hd<D, HEADS>::NT]; };
-
-__host__ __device__ constexpr uint32_t qmask_bits(int c0, int lo, int hi) {
-  return ((c0 >= lo && c0 < hi) ? 0x0000ffffu : 0u) | ((c0 + 1 >= lo && c0 + 1 < hi) ? 0xffff0000u : 0u);
-}
-
-__device__ __forceinline__ Pack16 lds_pack(lds_cp p) {
-  const u32x4_t v = *reinterpret_cast<const LDS_AS u32x4_t*>(p);
-  Pack16 r;
-  r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
-  return r;
-}
-
-__device__ __forceinline__ float half_swap_max(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float half_swap_sum(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 struct HdCtx {
   lds_cp Qp, Kp, Vp, Op;         // per-lane bases into the Q / K / V sections (O overwrites Q)
