@@ -40,7 +40,7 @@ E1 = dict(img_size=64, patch_size=1, in_chans=1, sr_scale=4, embed_dim=60, dense
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per K1 launch from the PMC counters (profiles/README.md: separate --pmc passes, FETCH_SIZE
 # doubled for wide loads as the guide prescribes), averaged over the step's 48 launches; None = not collected
-K1_TRAFFIC_BYTES_PER_LAUNCH = None
+K1_TRAFFIC_BYTES_PER_LAUNCH = 96272384   # profiles/r01p_pmc_wattn_fetch_write.json: (2*FETCH + WRITE) KiB averaged over C = 60/90/120
 
 
 def build_net(device, dtype):
