@@ -362,6 +362,279 @@ __global__ void __launch_bounds__(512) conv_wgrad_mfma_kernel(const ConvWgradArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad for 3x3 / pad 1 convs whose image width is a multiple of 32: the pipelined form.
+// A stripe is 32 consecutive pixels of ONE image row, so the inputs of all three kx taps are the 34
+// consecutive pixels x0-1 .. x0+32 of row y+ky-1: they are staged once and the tap is a row offset of
+// the transposed fragment reads.  Structure as the Linear wgrad (linear_mfma.hip): 8 waves x up to 6
+// accumulator tiles, PF stripes prefetched in registers, double-buffered LDS tiles (one barrier per
+// stripe), precomputed per-thread staging plan, software-pipelined fragment reads.  One workgroup per
+// (pixel range, ky); slab layout and reduction are those of the generic kernel above.
+// XF: 0 = no input activation, 3 = run-time activation.
+// ------------------------------------------------------------------------------------------------
+
+// SL = pixels per stripe (32, or 128 for shapes with at most 2x2 tiles per tap: fewer barriers per byte)
+template <typename T, int PF, int XF, int SL>
+__global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  constexpr int HP = MM::HP;
+  constexpr int ES = (int)sizeof(T);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const ConvGeom g = p.g;
+  const int ky = blockIdx.y;
+  constexpr int XR = SL + 2;   // rows of the X tile: pixels x0-1 .. x0+SL
+  const int buf_bytes = SL * p.ldn + XR * p.ldk;
+  f32x16 acc[CW_MAXT];
+#pragma unroll
+  for (int j = 0; j < CW_MAXT; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  const int ntiles = p.NT * 3 * p.KT;
+  const int64_t P = g.pixels();
+  const int64_t p_begin = (int64_t)blockIdx.x * p.pix_per_wg;
+  const int64_t p_end = (p_begin + p.pix_per_wg < P) ? p_begin + p.pix_per_wg : P;
+  const int npk = p.NT * 32 / HP, kpk = p.KT * 32 / HP;
+  const bool small_n = g.Cout < HP;   // e.g. the 60 -> 1 tail conv: dY rows are shorter than a pack
+
+  // per-thread staging plan (loop invariant)
+  constexpr int DYMAX = 16 / HP, XMAX = 24 / HP;   // 32 x 256 | 34 x 256 elements over 512 threads
+  int dy_row[DYMAX], dy_col[DYMAX], dy_sh[DYMAX], dy_lds[DYMAX];
+  int x_row[XMAX], x_col[XMAX], x_sh[XMAX], x_lds[XMAX], x_k0[XMAX];
+#pragma unroll
+  for (int i = 0; i < DYMAX; ++i) {
+    const int idx = tid + 512 * i;
+    const int row = idx / npk, pk = idx - row * npk;
+    int k0 = pk * HP;
+    dy_row[i] = (!small_n && idx < SL * npk) ? row : -1;
+    dy_lds[i] = row * p.ldn + pk * 16;
+    if (k0 >= g.Cout) k0 = 0;
+    dy_sh[i] = (k0 + HP > g.Cout) ? (k0 + HP - g.Cout) * ES : 0;
+    dy_col[i] = k0 * ES - dy_sh[i];
+  }
+#pragma unroll
+  for (int i = 0; i < XMAX; ++i) {
+    const int idx = tid + 512 * i;
+    const int row = idx / kpk, pk = idx - row * kpk;
+    const int k0 = pk * HP;
+    x_row[i] = idx < XR * kpk ? row : -1;
+    x_lds[i] = SL * p.ldn + row * p.ldk + pk * 16;
+    x_k0[i] = k0;
+    const int kl = k0 < g.Cin ? k0 : 0;
+    x_sh[i] = (kl + HP > g.Cin) ? (kl + HP - g.Cin) * ES : 0;
+    x_col[i] = kl * ES - x_sh[i];
+  }
+  // small-Cout mode: thread t < 32*Cout moves ONE element of dY per stripe
+  const int sm_row = tid / (g.Cout > 0 ? g.Cout : 1), sm_col = tid - sm_row * g.Cout;
+  const bool sm_act = small_n && tid < SL * g.Cout;
+  auto shift_pack = [&](Pack16& q, int sh_bytes) {
+    const int dq = sh_bytes >> 2;
+    if (dq & 1) { q.w[0] = q.w[1]; q.w[1] = q.w[2]; q.w[2] = q.w[3]; }
+    if (dq & 2) { q.w[0] = q.w[2]; q.w[1] = q.w[3]; }
+    const uint32_t bs = (uint32_t)(sh_bytes & 3);
+    q.w[0] = __builtin_amdgcn_alignbyte(q.w[1], q.w[0], bs);
+    q.w[1] = __builtin_amdgcn_alignbyte(q.w[2], q.w[1], bs);
+    q.w[2] = __builtin_amdgcn_alignbyte(q.w[3], q.w[2], bs);
+    q.w[3] = __builtin_amdgcn_alignbyte(q.w[3], q.w[3], bs);
+  };
+  auto ld16 = [&](const char* base, uint32_t off) {
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(base + off);
+    Pack16 q;
+    q.w[0] = v.x; q.w[1] = v.y; q.w[2] = v.z; q.w[3] = v.w;
+    return q;
+  };
+  // stripe geometry (wave uniform): rows of the X tile are pixels x0-1 .. x0+SL of image row y+ky-1.
+  // Positions advance incrementally (no divisions inside the loop).
+  struct Pos { int b, y, x0; int64_t p0; };
+  auto advance = [&](Pos& q, int nstripes) {
+    q.p0 += (int64_t)nstripes * SL;
+    q.x0 += nstripes * SL;
+    while (q.x0 >= g.W) { q.x0 -= g.W; if (++q.y == g.H) { q.y = 0; ++q.b; } }
+  };
+  struct Stripe { int left, lo, hi; bool row_ok; int64_t xpix; };
+  auto locate = [&](const Pos& q) {
+    Stripe s;
+    const int yy = q.y + ky - 1;
+    s.row_ok = yy >= 0 && yy < g.H;
+    s.lo = q.x0 == 0 ? 1 : 0;                        // first / last tile row that is inside the image
+    s.hi = q.x0 + SL == g.W ? SL : SL + 1;
+    s.left = (int)(p_end - q.p0 < SL ? p_end - q.p0 : SL);
+    s.xpix = s.row_ok ? ((int64_t)q.b * g.H + yy) * g.W + q.x0 - 1 : q.p0 - 1;   // any readable pixel when the row is outside
+    return s;
+  };
+  Pack16 rdy[PF][DYMAX], rx[PF][XMAX];
+  T rsm[PF];
+  const int64_t ldy_b = p.lddy * ES, ldx_b = p.ldx * ES;
+  auto prefetch = [&](int set, const Pos& pq) {
+    const Stripe s = locate(pq);
+    const int64_t p0 = pq.p0;
+    const char* dyb = reinterpret_cast<const char*>(p.dY) + p0 * ldy_b;
+    const char* xb = reinterpret_cast<const char*>(p.X) + s.xpix * ldx_b;
+#pragma unroll
+    for (int i = 0; i < DYMAX; ++i)
+      if (dy_row[i] >= 0) {
+        const int row = dy_row[i] < s.left ? dy_row[i] : s.left - 1;
+        rdy[set][i] = ld16(dyb, (uint32_t)(row * (int)ldy_b + dy_col[i]));
+      }
+    if (small_n) rsm[set] = sm_act && sm_row < s.left ? p.dY[(p0 + sm_row) * p.lddy + sm_col] : from_f32<T>(0.f);
+#pragma unroll
+    for (int i = 0; i < XMAX; ++i)
+      if (x_row[i] >= 0) {
+        int row = x_row[i] < s.lo ? s.lo : x_row[i];
+        row = row > s.hi ? s.hi : row;
+        rx[set][i] = ld16(xb, (uint32_t)(row * (int)ldx_b + x_col[i]));
+      }
+  };
+  auto stash = [&](int set, const Pos& pq, int b) {
+    char* tile = smem + b * buf_bytes;
+    const Stripe s = locate(pq);
+#pragma unroll
+    for (int i = 0; i < DYMAX; ++i)
+      if (dy_row[i] >= 0) {
+        Pack16 q = rdy[set][i];
+        if (dy_sh[i]) shift_pack(q, dy_sh[i]);
+        if (dy_row[i] >= s.left) { q.w[0] = 0u; q.w[1] = 0u; q.w[2] = 0u; q.w[3] = 0u; }   // pixels past the range add nothing
+        *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
+      }
+    if (sm_act) *reinterpret_cast<T*>(tile + sm_row * p.ldn + sm_col * ES) = rsm[set];
+#pragma unroll
+    for (int i = 0; i < XMAX; ++i)
+      if (x_row[i] >= 0) {
+        const bool valid = s.row_ok && x_row[i] >= s.lo && x_row[i] <= s.hi;
+        const int k0 = x_k0[i];
+        Pack16 q = rx[set][i];
+        if (x_sh[i]) shift_pack(q, x_sh[i]);
+        if (XF != 0 || !valid || (k0 <= g.Cin && k0 + HP > g.Cin)) {
+          float f[HP];
+          MM::unpack(q, f);
+          if (XF != 0) {
+#pragma unroll
+            for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+          }
+#pragma unroll
+          for (int e = 0; e < HP; ++e) {
+            if (!valid) f[e] = 0.f;                 // zero padding of the conv
+            if (k0 + e == g.Cin) f[e] = 1.0f;       // ones column: d(bias) on the centre tap
+          }
+          q = MM::pack(f);
+        }
+        *reinterpret_cast<Pack16*>(tile + x_lds[i]) = q;
+      }
+  };
+  // per-wave tile list and per-lane fragment offsets (loop invariant); tile = (nt, kx, kt)
+  int tA[CW_MAXT], tB[CW_MAXT];
+  {
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int laneA = sizeof(T) == 2 ? (8 * h + q) * p.ldn + (16 * (gq & 1) + 4 * pp) * 2 : h * p.ldn + r * 4;
+    const int laneB = sizeof(T) == 2 ? (8 * h + q) * p.ldk + (16 * (gq & 1) + 4 * pp) * 2 : h * p.ldk + r * 4;
+#pragma unroll
+    for (int j = 0; j < CW_MAXT; ++j) {
+      const int ti = wave + 8 * j;
+      const int nt = ti / (3 * p.KT);
+      const int rem = ti - nt * (3 * p.KT);
+      const int kx = rem / p.KT, kt = rem - kx * p.KT;
+      tA[j] = laneA + nt * 32 * ES;
+      tB[j] = SL * p.ldn + laneB + kx * p.ldk + kt * 32 * ES;   // tap = row offset into the 34-row tile
+    }
+  }
+  const int my_tiles = __builtin_amdgcn_readfirstlane(ntiles > wave ? (ntiles - wave + 7) / 8 : 0);
+  auto multiply = [&](int b) {
+#pragma unroll
+    for (int sub = 0; sub < SL / 32; ++sub) {
+      const char* tile = smem + b * buf_bytes;
+      const int offA = sub * 32 * p.ldn, offB = sub * 32 * p.ldk;
+      if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+        constexpr int NMS = 2;
+        Pack16 fa[2][NMS], fb[2][NMS];
+        auto frags = [&](int j, Pack16 (&A)[NMS], Pack16 (&B)[NMS]) {
+#pragma unroll
+          for (int ms = 0; ms < NMS; ++ms) {
+            const char* ta = tile + offA + ms * 16 * p.ldn;
+            const char* tb = tile + offB + ms * 16 * p.ldk;
+            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + tA[j]));
+            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + 4 * p.ldn + tA[j]));
+            const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + tB[j]));
+            const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + 4 * p.ldk + tB[j]));
+            const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
+            const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
+            A[ms].w[0] = ua0.x; A[ms].w[1] = ua0.y; A[ms].w[2] = ua1.x; A[ms].w[3] = ua1.y;
+            B[ms].w[0] = ub0.x; B[ms].w[1] = ub0.y; B[ms].w[2] = ub1.x; B[ms].w[3] = ub1.y;
+          }
+        };
+        if (my_tiles > 0) frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int j = 0; j < CW_MAXT; ++j) {
+          if (j < my_tiles) {
+            if (j + 1 < CW_MAXT && j + 1 < my_tiles) frags(j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+#pragma unroll
+            for (int ms = 0; ms < NMS; ++ms) MM::mma(acc[j], fa[j & 1][ms], fb[j & 1][ms]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CW_MAXT; ++j) {
+          if (j < my_tiles) {
+#pragma unroll 8
+            for (int s2 = 0; s2 < 16; ++s2) {
+              const float av = *reinterpret_cast<const float*>(tile + offA + 2 * s2 * p.ldn + tA[j]);
+              const float bv = *reinterpret_cast<const float*>(tile + offB + 2 * s2 * p.ldk + tB[j]);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  Pos cur, nxt;   // stripe being stashed / stripe being prefetched
+  {
+    int b0, y0, x00;
+    g.decode(p_begin < P ? p_begin : 0, b0, y0, x00);
+    cur.b = b0; cur.y = y0; cur.x0 = x00; cur.p0 = p_begin;
+    nxt = cur;
+  }
+  // every prefetch defines every staging register (past the range it re-reads the current stripe): a
+  // conditionally defined register would be live around the whole loop, get spilled, and the spill
+  // makes the wave wait for its load
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    prefetch(s, nxt.p0 < p_end ? nxt : cur);
+    advance(nxt, 1);
+  }
+  int b = 0;
+  while (cur.p0 < p_end) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      if (cur.p0 < p_end) {
+        stash(s, cur, b);   // tile b was last read two stripes ago; every wave has passed the barrier in between
+        __syncthreads();
+        prefetch(s, nxt.p0 < p_end ? nxt : cur);
+        multiply(b);
+        b ^= 1;
+      }
+      advance(cur, 1);
+      advance(nxt, 1);
+    }
+  }
+  // slab[m-block][ky][co][kx][CinP]
+  float* my = p.slab + (((int64_t)blockIdx.x * 3 + ky) * g.Cout) * 3 * p.CinP;
+#pragma unroll
+  for (int j = 0; j < CW_MAXT; ++j) {
+    const int ti = wave + 8 * j;
+    if (ti < ntiles) {
+      const int nt = ti / (3 * p.KT);
+      const int rem = ti - nt * (3 * p.KT);
+      const int kx = rem / p.KT, kt = rem - kx * p.KT;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int co = nt * 32 + acc_row(v, h);
+        if (co < g.Cout) my[((int64_t)co * 3 + kx) * p.CinP + kt * 32 + r] = acc[j][v];
+      }
+    }
+  }
+}
+
 // dW[co][ci][ky][kx] = s * sum_m slab[m][ky][co][kx][ci];  dbias[co] = s * sum_m slab[m][pad][co][pad][ones_col]
 __global__ void __launch_bounds__(256) conv_wgrad_reduce_kernel(const float* __restrict__ slab, int nm, ConvGeom g, int CinP,
                                                                 int ones_col, float s, float* __restrict__ dW,
@@ -448,9 +721,41 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
   };
   p.ldn = stride(p.NT * 32);
   p.ldk = stride(p.KT * 32);
+  const int64_t P = g.pixels();
+  {  // the pipelined kernel: 3x3 / pad 1, rows of 32-pixel stripes, packs loaded whole (dword-aligned rows)
+    constexpr int HP = Mma<T>::HP;
+    const bool small_n = g.Cout < HP;
+    const bool long_stripes = p.NT <= 2 && p.KT <= 2 && g.W % 128 == 0;
+    const int SLr = long_stripes ? 128 : CW_STRIPE;
+    const size_t smem2 = (size_t)2 * (SLr * p.ldn + (SLr + 2) * p.ldk);
+    const bool ok = g.ks == 3 && g.pad == 1 && g.W % CW_STRIPE == 0 && p.NT <= 8 && p.KT <= 8 && g.Cin >= HP &&
+                    !((uintptr_t)X & 3) && (ldx * sizeof(T)) % 4 == 0 && (g.Cin * sizeof(T)) % 4 == 0 &&
+                    (small_n ? CW_STRIPE * g.Cout <= 512
+                             : (!((uintptr_t)dYp & 3) && (lddyp * sizeof(T)) % 4 == 0 && (g.Cout * sizeof(T)) % 4 == 0)) &&
+                    smem2 <= 160 * 1024;
+    if (ok) {
+      int64_t nm = 85;   // x 3 kernel rows = 255 workgroups: one per CU
+      if (nm > (P + SLr - 1) / SLr) nm = (P + SLr - 1) / SLr;
+      p.pix_per_wg = (((P + nm - 1) / nm + SLr - 1) / SLr) * SLr;
+      nm = (P + p.pix_per_wg - 1) / p.pix_per_wg;
+      constexpr int PF = sizeof(T) == 2 ? 2 : 1;
+#define RDST_CR_LAUNCH(XF)                                                                                            \
+      {                                                                                                              \
+        auto kern = long_stripes ? conv_wgrad_rows_kernel<T, PF, XF, 128> : conv_wgrad_rows_kernel<T, PF, XF, 32>;  \
+        if (smem2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nm, 3u), dim3(512), smem2, st, p);                                   \
+      }
+      if (in_act) RDST_CR_LAUNCH(3) else RDST_CR_LAUNCH(0)
+#undef RDST_CR_LAUNCH
+      if (int rc = rdst_launch_status("conv_wgrad_rows")) return rc;
+      const int64_t per_m = (int64_t)g.ks * g.Cout * g.ks * p.CinP;
+      hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((per_m + 255) / 256)), dim3(256), 0, st, slab, (int)nm, g,
+                         p.CinP, p.ones_col, s, dW, dbias);
+      return rdst_launch_status("conv_wgrad_reduce");
+    }
+  }
   const size_t smem = (size_t)CW_STRIPE * (p.ldn + (size_t)g.ks * p.ldk);
   if (smem > 160 * 1024) return RDST_ENOTSUP;
-  const int64_t P = g.pixels();
   int64_t nm = (P + CW_STRIPE - 1) / CW_STRIPE;
   const int64_t cap = 128;
   if (nm > cap) nm = cap;

@@ -636,9 +636,13 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
     }
   };
 
+  // every prefetch defines every staging register (past the range it re-reads the first stripe): a
+  // conditionally defined register is live around the whole loop and invites spills
 #pragma unroll
-  for (int s = 0; s < PF; ++s)
-    if (m_begin + (int64_t)s * WG_STRIPE < m_end) prefetch(s, m_begin + (int64_t)s * WG_STRIPE);
+  for (int s = 0; s < PF; ++s) {
+    const int64_t ms = m_begin + (int64_t)s * WG_STRIPE;
+    if (m_begin < m_end) prefetch(s, ms < m_end ? ms : m_begin);
+  }
   __syncthreads();  // gamma / beta staged
   int b = 0;
   for (int64_t mg = m_begin; mg < m_end; mg += (int64_t)PF * WG_STRIPE) {
@@ -650,7 +654,7 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
         stash(s, m0, b);
         __syncthreads();
         const int64_t mn = m0 + (int64_t)PF * WG_STRIPE;
-        if (mn < m_end) prefetch(s, mn);  // PF stripes ahead, in flight while this and the next ones are multiplied
+        prefetch(s, mn < m_end ? mn : m0);  // PF stripes ahead, in flight while this and the next ones are multiplied
         multiply(b);
         b ^= 1;
       }
