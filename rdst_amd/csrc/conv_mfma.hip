@@ -68,21 +68,20 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
     // stage W[tap][col][ci-pack] for this chunk
-    for (int idx = tid; idx < ntap * ncp * 2 * Tn; idx += 512) {
-      const int ph = idx % (2 * Tn);
-      const int rest = idx / (2 * Tn);
-      const int n = rest % ncp, tap = rest / ncp;
-      const bool ok = n < nc;
-      Pack16 w;
-      if (MODE == CMODE_FWD) {
-        // B[k = ci][col = co] = Wc[co][ci][tap]: stride over ci is ks*ks
-        w = pack_from_f32<T>(p.Wc + ((int64_t)(n0 + n) * g.Cin) * ntap + tap, ph * HP, p.CA, ntap, ok);
-      } else {
-        // dgrad: contraction over co, output col = ci, mirrored tap: Wc[co][ci][ntap-1-tap]
-        w = pack_from_f32<T>(p.Wc + (int64_t)(n0 + n) * ntap + (ntap - 1 - tap), ph * HP, p.CA, (int64_t)g.Cin * ntap, ok);
-      }
-      *reinterpret_cast<Pack16*>(smem + ((size_t)tap * ncp + n) * p.ldw + ph * 16) = w;
-    }
+    stage_packs_batched<T, 4>(ntap * ncp * 2 * Tn, p.CA, MODE == CMODE_FWD ? (int64_t)ntap : (int64_t)g.Cin * ntap, tid, 512,
+                              [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
+                                const int ph = idx % (2 * Tn);
+                                const int rest = idx / (2 * Tn);
+                                const int n = rest % ncp, tap = rest / ncp;
+                                ok = n < nc;
+                                k0 = ph * HP;
+                                // fwd:   B[k = ci][col = co] = Wc[co][ci][tap]: stride over ci is ks*ks
+                                // dgrad: contraction over co, output col = ci, mirrored tap: Wc[co][ci][ntap-1-tap]
+                                src = MODE == CMODE_FWD
+                                          ? p.Wc + ((int64_t)(n0 + n) * g.Cin + k0) * ntap + tap
+                                          : p.Wc + ((int64_t)k0 * g.Cin + (n0 + n)) * ntap + (ntap - 1 - tap);
+                                dst = smem + ((size_t)tap * ncp + n) * p.ldw + ph * 16;
+                              });
     __syncthreads();
     const int nct = ncp / 32;
 

@@ -46,52 +46,167 @@ struct LinArgs {
   const T* Xa; int64_t ldxa;          // dgrad: pre-activation X for act'
   const T* Acc; int64_t ldacc;        // dgrad: + dX_add
   int64_t M; int Kc; int Nout; float s;
-  int Tn; int ldw; int nch;
+  int Tn; int ldw; int nch; int aoff;
+  int dbg;   // RDST_LIN_DEBUG ablation switches: 1 skip stores, 2 skip fused-add operand loads, 4 skip the column tiles
 };
 
+// The accumulators are kept TRANSPOSED (D^T = W . A^T: output column n in the registers, token on the lane):
+// a lane then owns 4 consecutive output columns of ITS OWN token row per register group, one
+// v_permlane32_swap per register turns two groups into 8 consecutive columns, and the row goes out
+// as 16-B stores straight from the registers — no LDS bounce, no second pass over the tile.  The
+// residual / activation-gradient / accumulate operands are read with the same 16-B row chunks and
+// added in fp32 before the single rounding.  The bias is the initial accumulator.  The next slab's
+// fragments are prefetched while the current one is multiplied.
 template <typename T, int TMAX, int MODE>
 __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using MM = Mma<T>;
   constexpr int KP = MM::KP, HP = MM::HP;
+  constexpr bool BF = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int Tn = p.Tn;
   char* Ws = smem;
   float* gam = reinterpret_cast<float*>(smem + (size_t)p.nch * p.ldw);
   float* bet = gam + Tn * KP;
-  float* eps = bet + Tn * KP + wave * 1024;  // wave-private 32x32 fp32 epilogue tile
+  float* biasL = bet + Tn * KP;  // [npad] (forward)
+  // wave-private staging tile for the coalesced slab loads: 32 rows x (128 B of the row + 16 B pad)
+  constexpr int ABUF_LD = 144;
+  char* abuf = smem + p.aoff + wave * (32 * ABUF_LD);
   const bool has_ln = (MODE == MODE_FWD) && p.lnw != nullptr;
   if (has_ln)
     for (int i = tid; i < Tn * KP; i += 512) {
       gam[i] = i < p.Kc ? p.lnw[i] : 0.f;
       bet[i] = i < p.Kc ? p.lnb[i] : 0.f;
     }
+  const int npad = ((p.Nout + 31) / 32) * 32;
+  if (MODE == MODE_FWD)
+    for (int i = tid; i < npad; i += 512) biasL[i] = (p.bias && i < p.Nout) ? p.bias[i] : 0.f;
   const int64_t nslabs = (p.M + 31) / 32;
   const float invK = 1.0f / (float)p.Kc;
 
+  // Slab loads.  A lane reading 16 B of ITS OWN row (fragment shape) makes every wave instruction touch
+  // 32 different rows for 32 B each: measured 0.8 TB/s.  Instead rows are read COALESCED — 8 lanes x
+  // 16 B = 128 B of one row, 8 rows per instruction — in 128-B column chunks, bounced through the
+  // wave-private LDS tile and re-read as fragments (ds_read_b128, odd 16-B-slot stride).  The raw chunks
+  // of the NEXT slab are prefetched while the current one is multiplied.  A row's last, shorter chunk is
+  // read as the row's last 16 B (overlapping), so nothing outside the row is touched.
+  constexpr int NKC = (TMAX + 3) / 4;                    // 128-B column chunks (4 k-steps each)
+  const int rowbytes = p.Kc * (int)sizeof(T);
+  const int crow = lane >> 3, cchk = lane & 7;           // row within a group of 8, 16-B chunk within the 128 B
+  // elements past the row's end inside the last k-step must be zero (they meet zero weight columns, but may be NaN bits)
+  auto zero_tail = [&](Pack16 (&a)[TMAX]) {
+    const int klast = (Tn - 1) * KP + h * HP;
+    if (klast + HP > p.Kc) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t)
+        if (t == Tn - 1) {
+          float f[HP];
+          MM::unpack(a[t], f);
+#pragma unroll
+          for (int e = 0; e < HP; ++e) f[e] = (klast + e < p.Kc) ? f[e] : 0.f;
+          a[t] = MM::pack(f);
+        }
+    }
+  };
+  auto issue_raw = [&](Pack16 (&raw)[NKC][4], int64_t slab) {
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      int off = kc * 128 + cchk * 16;
+      if (off + 16 > rowbytes) off = rowbytes - 16;      // the row's last chunk, or a lane past the row's end (re-reads it)
+      if (off < 0) off = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int64_t row = slab * 32 + 8 * i + crow;
+        row = row < p.M ? row : p.M - 1;
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.A + row * p.lda) + off);
+        raw[kc][i].w[0] = v.x; raw[kc][i].w[1] = v.y; raw[kc][i].w[2] = v.z; raw[kc][i].w[3] = v.w;
+      }
+    }
+  };
+  auto raw_to_frags = [&](const Pack16 (&raw)[NKC][4], Pack16 (&a)[TMAX]) {
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc * 128 < rowbytes) {
+        int off = kc * 128 + cchk * 16;
+        const bool act = off < rowbytes;
+        if (off + 16 > rowbytes) off = rowbytes - 16;
+        const int loc = off - kc * 128;                  // >= 0: a chunk's tail is at least 16 B (see `coal`)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (act) *reinterpret_cast<Pack16*>(abuf + (8 * i + crow) * ABUF_LD + loc) = raw[kc][i];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int t = 4 * kc + tt;
+          if (t < TMAX && t < Tn) a[t] = *reinterpret_cast<const Pack16*>(abuf + r * ABUF_LD + tt * 32 + h * 16);
+        }
+      }
+    }
+    zero_tail(a);
+  };
+  auto load_chunks = [&](Pack16 (&a)[TMAX], int64_t slab) {   // no prefetch: one 128-B column chunk at a time
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      if (kc * 128 < rowbytes) {
+        int off = kc * 128 + cchk * 16;
+        const bool act = off < rowbytes;
+        if (off + 16 > rowbytes) off = rowbytes - 16;
+        const int loc = off - kc * 128;
+        Pack16 rw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int64_t row = slab * 32 + 8 * i + crow;
+          row = row < p.M ? row : p.M - 1;
+          const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.A + row * p.lda) + off);
+          rw[i].w[0] = v.x; rw[i].w[1] = v.y; rw[i].w[2] = v.z; rw[i].w[3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (act) *reinterpret_cast<Pack16*>(abuf + (8 * i + crow) * ABUF_LD + loc) = rw[i];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int t = 4 * kc + tt;
+          if (t < TMAX && t < Tn) a[t] = *reinterpret_cast<const Pack16*>(abuf + r * ABUF_LD + tt * 32 + h * 16);
+        }
+      }
+    }
+    zero_tail(a);
+  };
+
+  constexpr bool PFETCH = TMAX <= 8;   // the next slab's raw chunks in registers; beyond that they do not fit
+  Pack16 a[TMAX], raw[PFETCH ? NKC : 1][4];
+  const int64_t slab0 = (int64_t)blockIdx.x * 8 + wave, sstep = (int64_t)gridDim.x * 8;
+  if constexpr (PFETCH) {
+    if (slab0 < nslabs) issue_raw(raw, slab0);   // in flight while the weights are staged
+  }
   for (int n0 = 0; n0 < p.Nout; n0 += p.nch) {
     __syncthreads();
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
-    for (int idx = tid; idx < ncp * 2 * Tn; idx += 512) {
-      const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
-      const bool ok = n < nc;
-      Pack16 w;
-      if (MODE == MODE_FWD) w = pack_from_f32<T>(p.Wt + (int64_t)(n0 + n) * p.wK, ph * HP, p.Kc, 1, ok);
-      else w = pack_from_f32<T>(p.Wt + (n0 + n), ph * HP, p.Kc, p.wK, ok);
-      *reinterpret_cast<Pack16*>(Ws + (size_t)n * p.ldw + ph * 16) = w;
-    }
+    stage_packs_batched<T, 8>(ncp * 2 * Tn, p.Kc, MODE == MODE_FWD ? 1 : p.wK, tid, 512,
+                              [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
+                                const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
+                                ok = n < nc;
+                                k0 = ph * HP;
+                                // forward: row n of W (N,K), k contiguous; dgrad: column n of W, k at stride K_lin
+                                src = MODE == MODE_FWD ? p.Wt + (int64_t)(n0 + n) * p.wK + k0 : p.Wt + (n0 + n) + (int64_t)k0 * p.wK;
+                                dst = Ws + (size_t)n * p.ldw + ph * 16;
+                              });
     __syncthreads();
     const int nct = ncp / 32;
 
-    for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < nslabs; slab += (int64_t)gridDim.x * 8) {
+    if constexpr (PFETCH) {
+      if (n0 != 0 && slab0 < nslabs) issue_raw(raw, slab0);
+    }
+    for (int64_t slab = slab0; slab < ((p.dbg & 8) ? 0 : nslabs); slab += sstep) {
+      if constexpr (PFETCH) {
+        raw_to_frags(raw, a);
+        // every iteration defines the whole prefetch set (past the end it re-reads this slab)
+        issue_raw(raw, slab + sstep < nslabs ? slab + sstep : slab);
+      } else {
+        load_chunks(a, slab);
+      }
       const int64_t row = slab * 32 + r;
       const bool valid = row < p.M;
-      const T* arow = p.A + (valid ? row : 0) * p.lda;
-      Pack16 a[TMAX];
-#pragma unroll
-      for (int t = 0; t < TMAX; ++t)
-        if (t < Tn) a[t] = load_pack<T>(arow, t * KP + h * HP, p.Kc, valid);
       if (MODE == MODE_FWD) {
         if (has_ln) {
           float sum = 0.f;
@@ -101,7 +216,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
               float f[HP];
               MM::unpack(a[t], f);
 #pragma unroll
-              for (int e = 0; e < HP; ++e) sum += f[e];
+              for (int e = 0; e < HP; ++e) sum += (t * KP + h * HP + e < p.Kc) ? f[e] : 0.f;
             }
           sum += __shfl_xor(sum, 32, 64);
           const float mean = sum * invK;
@@ -140,36 +255,127 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
               float f[HP];
               MM::unpack(a[t], f);
 #pragma unroll
-              for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+              for (int e = 0; e < HP; ++e) f[e] = apply_act<BF>(f[e], p.in_act);
               a[t] = MM::pack(f);
             }
         }
       }
-      for (int ct = 0; ct < nct; ++ct) {
+      for (int ct = 0; ct < ((p.dbg & 4) ? 0 : nct); ++ct) {
         f32x16 acc;
+        if (MODE == MODE_FWD) {   // bias = initial accumulator: register group g holds columns 8g + 4h .. +3
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bq = *reinterpret_cast<const float4*>(biasL + n0 + ct * 32 + 8 * g4 + 4 * h);
+            acc[4 * g4] = bq.x; acc[4 * g4 + 1] = bq.y; acc[4 * g4 + 2] = bq.z; acc[4 * g4 + 3] = bq.w;
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        }
         const char* wrow = Ws + (size_t)(ct * 32 + r) * p.ldw + h * 16;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)
           if (t < Tn) {
-            const Pack16 b = *reinterpret_cast<const Pack16*>(wrow + t * 32);
-            MM::mma(acc, a[t], b);
+            const Pack16 wa = *reinterpret_cast<const Pack16*>(wrow + t * 32);
+            MM::mma(acc, wa, a[t]);   // rows = output columns, cols = tokens
           }
-        const int col = n0 + ct * 32 + r;
-        const float bv = (MODE == MODE_FWD && p.bias && col < p.Nout) ? p.bias[col] : 0.f;
-        float vals[16];
+        // epilogue: two pairs of register groups -> two runs of 8 consecutive columns of the lane's row
 #pragma unroll
-        for (int v = 0; v < 16; ++v) vals[v] = (MODE == MODE_FWD) ? (acc[v] + bv) * p.s : acc[v] * p.s;
-        TileEpilogue ep{};
-        if (MODE == MODE_FWD) {
-          ep.R = p.R; ep.ldr = p.ldr; ep.Y = p.Y; ep.ldy = p.ldy;
-        } else if (p.dA) {
-          ep.Yf32 = p.dA; ep.ldf = p.Nout;
-        } else {
-          ep.Xa = p.Xa; ep.ldxa = p.ldxa; ep.act = p.in_act; ep.Y = p.Y; ep.ldy = p.ldy; ep.Acc = p.Acc; ep.ldacc = p.ldacc;
+        for (int gp = 0; gp < 2; ++gp) {
+          float c8[8];
+          int cb;   // first of the lane's 8 columns (bf16) / of each 4-column run (fp32)
+          if (BF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * gp + e] * p.s),
+                                                               __float_as_uint(acc[8 * gp + 4 + e] * p.s), false, false);
+              c8[e] = __uint_as_float(sw[0]);
+              c8[4 + e] = __uint_as_float(sw[1]);
+            }
+            cb = n0 + ct * 32 + 8 * (2 * gp + h);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c8[e] = acc[8 * gp + e] * p.s;
+            cb = n0 + ct * 32 + 16 * gp + 4 * h;   // c8[0..3] at cb, c8[4..7] at cb + 8
+          }
+          if (!valid) continue;
+          // operands of the fused adds: 8 columns as one (bf16) or two (fp32) 16-B row chunks
+          auto chunk8 = [&](const T* rowp, float (&g8)[8]) {
+            if (BF) {
+              if (cb + 8 <= p.Nout && (reinterpret_cast<uintptr_t>(rowp + cb) & 3) == 0) {
+                const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb);
+                g8[0] = bf16lo(u.x); g8[1] = bf16hi(u.x); g8[2] = bf16lo(u.y); g8[3] = bf16hi(u.y);
+                g8[4] = bf16lo(u.z); g8[5] = bf16hi(u.z); g8[6] = bf16lo(u.w); g8[7] = bf16hi(u.w);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g8[e] = cb + e < p.Nout ? to_f32<T>(rowp[cb + e]) : 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int c = cb + (e & 3) + 8 * (e >> 2);
+                g8[e] = c < p.Nout ? to_f32<T>(rowp[c]) : 0.f;
+              }
+            }
+          };
+          if (MODE == MODE_FWD) {
+            if (p.R && !(p.dbg & 2)) {
+              float g8[8];
+              chunk8(p.R + row * p.ldr, g8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c8[e] += g8[e];
+            }
+          } else if (!p.dA) {
+            if (p.Xa && p.in_act) {
+              float g8[8];
+              chunk8(p.Xa + row * p.ldxa, g8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c8[e] *= act_grad<BF>(g8[e], p.in_act);
+            }
+            if (p.Acc) {
+              float g8[8];
+              chunk8(p.Acc + row * p.ldacc, g8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c8[e] += g8[e];
+            }
+          }
+          if (MODE == MODE_DGRAD && p.dA) {  // fp32 destination (dgrad in front of a LayerNorm, generic path)
+            float* dst = p.dA + row * p.Nout;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int c = BF ? cb + e : cb + (e & 3) + 8 * (e >> 2);
+              if (c < p.Nout) dst[c] = c8[e];
+            }
+            continue;
+          }
+          if (p.dbg & 1) continue;
+          T* yrow = p.Y + row * p.ldy;
+          if (BF) {
+            if (cb + 8 <= p.Nout && (reinterpret_cast<uintptr_t>(yrow + cb) & 3) == 0) {
+              u32x4_a4 u;
+              u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+              u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+              *reinterpret_cast<u32x4_a4*>(yrow + cb) = u;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (cb + e < p.Nout) yrow[cb + e] = from_f32<T>(c8[e]);
+            }
+          } else {
+#pragma unroll
+            for (int q4 = 0; q4 < 2; ++q4) {
+              const int c = cb + 8 * q4;
+              if (c + 4 <= p.Nout && (reinterpret_cast<uintptr_t>(yrow + c) & 15) == 0) {
+                u32x4_a4 u;
+                u.x = __float_as_uint(c8[4 * q4]); u.y = __float_as_uint(c8[4 * q4 + 1]);
+                u.z = __float_as_uint(c8[4 * q4 + 2]); u.w = __float_as_uint(c8[4 * q4 + 3]);
+                *reinterpret_cast<u32x4_a4*>(yrow + c) = u;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (c + e < p.Nout) yrow[c + e] = from_f32<T>(c8[4 * q4 + e]);
+              }
+            }
+          }
         }
-        tile_store_rows<T>(eps, vals, lane, slab * 32, p.M, n0 + ct * 32, p.Nout, ep);
       }
     }
   }
@@ -204,11 +410,13 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln_kernel(const LnDgradArgs<T> 
   char* Ws = smem;                                                      // [kpad][ldw]: W^T rows (k), n-contiguous
   float* eps = reinterpret_cast<float*>(smem + (size_t)kpad * p.ldw) + wave * 1024;
   float* red = reinterpret_cast<float*>(smem + (size_t)kpad * p.ldw) + 8 * 1024;  // [8 waves][2][128]
-  for (int idx = tid; idx < kpad * 2 * Tn; idx += 512) {
+  stage_packs_batched<T, 4>(kpad * 2 * Tn, p.N, p.K, tid, 512, [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
     const int k = idx / (2 * Tn), ph = idx - k * (2 * Tn);
-    const Pack16 w = pack_from_f32<T>(p.Wt + k, ph * HP, p.N, p.K, k < K);  // element n at Wt[n*K + k]
-    *reinterpret_cast<Pack16*>(Ws + (size_t)k * p.ldw + ph * 16) = w;
-  }
+    ok = k < K;
+    k0 = ph * HP;                                  // contraction index n: element n at Wt[n*K + k]
+    src = p.Wt + k + (int64_t)k0 * p.K;
+    dst = Ws + (size_t)k * p.ldw + ph * 16;
+  });
   __syncthreads();
   const int chunk = lane & 7;
   float gam[4][4], dg[4][4], db[4][4];
@@ -368,16 +576,27 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   using MM = Mma<T>;
   p.Tn = (p.Kc + MM::KP - 1) / MM::KP;
   if (p.Tn > 32) return RDST_ENOTSUP;
+  { const char* e = getenv("RDST_LIN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  {  // the slab loads move whole 16-B chunks of dword-aligned rows (a chunk's tail is never shorter than 16 B)
+    const int64_t rowbytes = (int64_t)p.Kc * (int64_t)sizeof(T);
+    const bool coal = ((uintptr_t)p.A & 3) == 0 && (p.lda * sizeof(T)) % 4 == 0 && rowbytes % 4 == 0 && rowbytes >= 16 &&
+                      (rowbytes % 128 == 0 || rowbytes % 128 >= 16);
+    if (!coal) return RDST_ENOTSUP;
+  }
   p.ldw = lds_row_bytes(p.Kc, sizeof(T));
   const int npad = ((p.Nout + 31) / 32) * 32;
-  int nch = ((125 * 1024) / p.ldw) / 32 * 32;  // + 32 KB for the 8 epilogue tiles stays under 160 KB
+  const int abuf_bytes = 8 * 32 * 144;         // wave-private staging tiles of the coalesced slab loads
+  int nch = ((112 * 1024) / p.ldw) / 32 * 32;  // weights resident in LDS (+ staging, gamma/beta/bias) under 160 KB
   if (nch < 32) return RDST_ENOTSUP;
   if (nch > npad) nch = npad;
   p.nch = nch;
-  const size_t smem = (size_t)nch * p.ldw + (size_t)2 * p.Tn * MM::KP * sizeof(float) + 8 * 4096;
+  p.aoff = (int)(((size_t)nch * p.ldw + (size_t)(2 * p.Tn * MM::KP + npad) * sizeof(float) + 15) / 16 * 16);
+  const size_t smem = (size_t)p.aoff + abuf_bytes;
+  if (smem > 160 * 1024) return RDST_ENOTSUP;
   const int64_t nslabs = (p.M + 31) / 32;
   int64_t grid = (nslabs + 7) / 8;
-  const int64_t cap = smem <= 78 * 1024 ? 512 : 256;  // two co-resident 8-wave workgroups per CU when LDS allows
+  int64_t cap = 256;  // persistent: one 8-wave workgroup per CU (the kernel's register count admits no second one)
+  { const char* e = getenv("RDST_LIN_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
   if (grid > cap) grid = cap;
 #define RDST_LIN_LAUNCH(TM)                                                                                          \
   {                                                                                                                  \
@@ -556,7 +775,7 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
             for (int e = 0; e < HP; ++e) f[e] = (f[e] - mu) * rs * gv[e] + bv[e];
           } else if (XF == 2) {
 #pragma unroll
-            for (int e = 0; e < HP; ++e) f[e] = gelu_erf(f[e]);
+            for (int e = 0; e < HP; ++e) f[e] = sizeof(T) == 2 ? gelu_fast(f[e]) : gelu_erf(f[e]);
           } else if (XF == 3) {
 #pragma unroll
             for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);

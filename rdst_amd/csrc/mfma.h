@@ -104,6 +104,44 @@ __device__ __forceinline__ Pack16 pack_from_f32(const float* __restrict__ src, i
   return Mma<T>::pack(f);
 }
 
+// Stage converted fp32 parameters into an LDS image of lane packs, BATCHED: every thread issues the
+// loads of U items before it converts and stores any of them, so a workgroup pays U-fold fewer
+// global-load latencies (the one-item-at-a-time loop cost 10-25 us per launch, measured).
+//   item idx -> addr(idx, base, dst, ok):  base = pointer of element 0 of the item's pack (k0 = first k),
+//   element e of the pack is base[e * stride]; elements with k0 + e >= K (or !ok) are zero.
+// F: void(int idx, const float*& base, int& k0, char*& dst, bool& ok)
+template <typename T, int U, class F>
+__device__ __forceinline__ void stage_packs_batched(int total, int K, int64_t stride, int tid, int nthreads, F addr) {
+  constexpr int HP = Mma<T>::HP;
+  for (int base_idx = tid; base_idx < total; base_idx += nthreads * U) {
+    float f[U][HP];
+    char* dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base_idx + nthreads * u;
+      const float* src = nullptr;
+      int k0 = 0;
+      bool ok = false;
+      dst[u] = nullptr;
+      if (idx < total) addr(idx, src, k0, dst[u], ok);
+      if (ok && stride == 1 && k0 + HP <= K) {   // contiguous pack: 16-B loads (fp32 parameters are dword aligned)
+#pragma unroll
+        for (int q = 0; q < HP / 4; ++q) {
+          const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(src + 4 * q);
+          f[u][4 * q] = __uint_as_float(v.x); f[u][4 * q + 1] = __uint_as_float(v.y);
+          f[u][4 * q + 2] = __uint_as_float(v.z); f[u][4 * q + 3] = __uint_as_float(v.w);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < HP; ++e) f[u][e] = (ok && k0 + e < K) ? src[(int64_t)e * stride] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u]) *reinterpret_cast<Pack16*>(dst[u]) = Mma<T>::pack(f[u]);
+  }
+}
+
 // row of accumulator register v for lane half h (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
