@@ -24,3 +24,15 @@ template <typename T>
 int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
                          int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* slab, int* nslab,
                          int64_t M, int K, int N, float s, hipStream_t st);
+// LayerNorm-fused Linear, weight-gradient side finishing the LayerNorm parameters too: the wgrad pass runs on
+// x-hat, the reduction then forms dW = s (gamma G + beta db^T), dbias = s db, d(gamma)[k] = s sum_n W[n][k] G[n][k],
+// d(beta)[k] = s sum_n W[n][k] db[n].  G: N*(K+1) floats of scratch.
+template <typename T>
+int linear_wgrad_ln_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, const float* Wt,
+                         const T* dY, int64_t lddy, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab,
+                         float* G, int64_t M, int K, int N, float s, hipStream_t st);
+// dgrad + LayerNorm backward producing dX only, everything register resident (K <= 128)
+template <typename T>
+int linear_dgrad_ln2_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
+                          int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, int64_t M, int K, int N, float s,
+                          hipStream_t st);

@@ -286,6 +286,24 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
   float* small = slabW + slab_floats(M, K, N);
   LinIn<T> fin{X, ldx, stats, ln_w, ln_b, in_act};
   if (Wt) {
+    // LayerNorm-fused Linear with everything requested in one call: the weight-gradient pass runs on x-hat and
+    // its reduction also yields d(gamma)/d(beta); the data-gradient kernel then only produces dX.
+    if (ln_w && ln_b && dW && dbias && dln_w && dln_b && dX && K <= 128 && !getenv("RDST_LN_BWD_V1")) {
+      float* G = dA;   // the fp32 dA buffer of the generic path is unused here: N*(K+1) <= M*K floats of scratch
+      if ((int64_t)N * (K + 1) <= M * K) {
+        int rc = linear_wgrad_ln_mfma<T>(X, ldx, ln_w, ln_b, stats, Wt, dY, lddy, dW, dbias, dln_w, dln_b, slabW, G, M, K, N,
+                                         s, st);
+        if (rc == 0) {
+          rc = linear_dgrad_ln2_mfma<T>(X, ldx, stats, ln_w, Wt, dY, lddy, dX, lddx, acc, ldacc, M, K, N, s, st);
+          if (rc == 0) return 0;
+          if (rc != RDST_ENOTSUP) return rc;
+          // dX not covered: finish it below; dW / dbias / d(gamma) / d(beta) are done
+          dW = nullptr; dbias = nullptr; dln_w = nullptr; dln_b = nullptr;
+        } else if (rc != RDST_ENOTSUP) {
+          return rc;
+        }
+      }
+    }
     bool wgrad_done = false;
     if (dW || dbias) {
       const int rc = linear_wgrad_mfma<T>(X, ldx, ln_w, ln_b, stats, in_act, dY, lddy, dW, dbias, slabW, M, K, N, s, st);

@@ -609,6 +609,198 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   return rdst_launch_status(what);
 }
 
+// ---- dgrad + LayerNorm backward, register-resident form -------------------------------------------
+// Used when d(gamma) / d(beta) come from the weight-gradient side (linear_wgrad_ln_mfma), so this kernel
+// only produces dX.  dA^T = W^T-tiles . dY^T is kept TRANSPOSED (LayerNorm channel k in the registers,
+// token on the lane): all NCT <= 4 channel tiles of a 32-token slab stay in the accumulators, one
+// v_permlane32_swap per register turns them into runs of 8 consecutive channels of the lane's own row,
+// the row sums s1 = sum_k dA gamma, s2 = sum_k dA gamma xhat are in-lane sums plus one half swap, and
+//   dX = rstd * (gamma dA - s1/K - xhat s2/K) (+ dX_add)
+// leaves as 16-B row stores.  No LDS bounce, no second pass over the MFMAs.  dY streams in coalesced
+// 128-B column chunks through the wave's LDS tile (next chunk prefetched while this one is multiplied).
+template <typename T, int NCT>
+__global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  constexpr int KP = MM::KP, HP = MM::HP;
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int ABUF_LD = 144;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int Tn = p.Tn, K = p.K;
+  constexpr int kpad = NCT * 32;
+  char* Ws = smem;                                                       // [kpad][ldw]: W^T rows (k), n-contiguous packs
+  float* gamL = reinterpret_cast<float*>(smem + (size_t)kpad * p.ldw);   // [kpad]
+  char* abuf = reinterpret_cast<char*>(gamL + kpad) + wave * (32 * ABUF_LD);
+  const int rowbytes = p.N * (int)sizeof(T);
+  const int nkc = (rowbytes + 127) / 128;
+  const int crow = lane >> 3, cchk = lane & 7;
+  const int64_t nslabs = (p.M + 31) / 32;
+  const int64_t slab0 = (int64_t)blockIdx.x * 8 + wave, sstep = (int64_t)gridDim.x * 8;
+
+  auto issue_chunk = [&](Pack16 (&rw)[4], int64_t slab, int kc) {
+    int off = kc * 128 + cchk * 16;
+    if (off + 16 > rowbytes) off = rowbytes - 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = slab * 32 + 8 * i + crow;
+      row = row < p.M ? row : p.M - 1;
+      const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.dY + row * p.lddy) + off);
+      rw[i].w[0] = v.x; rw[i].w[1] = v.y; rw[i].w[2] = v.z; rw[i].w[3] = v.w;
+    }
+  };
+  Pack16 raw[4];
+  if (slab0 < nslabs) issue_chunk(raw, slab0, 0);   // in flight while the weights are staged
+  stage_packs_batched<T, 8>(kpad * 2 * Tn, p.N, p.K, tid, 512, [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
+    const int k = idx / (2 * Tn), ph = idx - k * (2 * Tn);
+    ok = k < K;
+    k0 = ph * HP;                                  // contraction index n: element n at Wt[n*K + k]
+    src = p.Wt + k + (int64_t)k0 * p.K;
+    dst = Ws + (size_t)k * p.ldw + ph * 16;
+  });
+  for (int i = tid; i < kpad; i += 512) gamL[i] = i < K ? p.gamma[i] : 0.f;
+  __syncthreads();
+  const float invK = 1.0f / (float)K;
+
+  for (int64_t slab = slab0; slab < nslabs; slab += sstep) {
+    f32x16 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+      // raw chunk kc -> wave tile -> fragments; the next chunk (or the next slab's first) goes in flight
+      int off = kc * 128 + cchk * 16;
+      const bool act = off < rowbytes;
+      if (off + 16 > rowbytes) off = rowbytes - 16;
+      const int loc = off - kc * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (act) *reinterpret_cast<Pack16*>(abuf + (8 * i + crow) * ABUF_LD + loc) = raw[i];
+      {
+        const bool last = kc + 1 == nkc;
+        const int64_t ns = last ? (slab + sstep < nslabs ? slab + sstep : slab) : slab;
+        issue_chunk(raw, ns, last ? 0 : kc + 1);   // always (re)defines the whole prefetch set
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int t = 4 * kc + tt;
+        if (t < Tn) {
+          Pack16 a = *reinterpret_cast<const Pack16*>(abuf + r * ABUF_LD + tt * 32 + h * 16);
+          if (t == Tn - 1) {   // elements past the row's end inside the last k-step: zero (may be NaN bits)
+            const int kl = t * KP + h * HP;
+            if (kl + HP > p.N) {
+              float f[HP];
+              MM::unpack(a, f);
+#pragma unroll
+              for (int e = 0; e < HP; ++e) f[e] = (kl + e < p.N) ? f[e] : 0.f;
+              a = MM::pack(f);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) {
+            const Pack16 wa = *reinterpret_cast<const Pack16*>(Ws + (size_t)(c * 32 + r) * p.ldw + t * 32 + h * 16);
+            MM::mma(acc[c], wa, a);   // rows = LayerNorm channels, cols = tokens
+          }
+        }
+      }
+    }
+    const int64_t row = slab * 32 + r;
+    const bool valid = row < p.M;
+    const int64_t rs_ = valid ? row : p.M - 1;
+    const float2 st = *reinterpret_cast<const float2*>(p.stats + 2 * rs_);
+    const float mean = st.x, rstd = st.y;
+    const T* xrow = p.X + rs_ * p.ldx;
+    // 8-channel runs of the lane's row: run (c, gp) starts at channel c*32 + 16*gp + 8*h (bf16) /
+    // two 4-channel runs at c*32 + 16*gp + 4*h and + 8 (fp32)
+    auto col_of = [&](int c, int gp, int e) { return BF ? c * 32 + 16 * gp + 8 * h + e : c * 32 + 16 * gp + 4 * h + (e & 3) + 8 * (e >> 2); };
+    auto load8 = [&](const T* rowp, int c, int gp, float (&g8)[8]) {
+      const int cb = col_of(c, gp, 0);
+      if (BF && cb + 8 <= K && (reinterpret_cast<uintptr_t>(rowp + cb) & 3) == 0) {
+        const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb);
+        g8[0] = bf16lo(u.x); g8[1] = bf16hi(u.x); g8[2] = bf16lo(u.y); g8[3] = bf16hi(u.y);
+        g8[4] = bf16lo(u.z); g8[5] = bf16hi(u.z); g8[6] = bf16lo(u.w); g8[7] = bf16hi(u.w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cc = col_of(c, gp, e);
+          g8[e] = cc < K ? to_f32<T>(rowp[cc]) : 0.f;
+        }
+      }
+    };
+    float G[NCT][2][8];   // gamma * dA in run layout; x-hat is rebuilt from a second (cache-hit) read of the row
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float c8[8];
+        if (BF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][8 * gp + e]),
+                                                             __float_as_uint(acc[c][8 * gp + 4 + e]), false, false);
+            c8[e] = __uint_as_float(sw[0]);
+            c8[4 + e] = __uint_as_float(sw[1]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) c8[e] = acc[c][8 * gp + e];
+        }
+        float x8[8];
+        load8(xrow, c, gp, x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cc = col_of(c, gp, e);
+          const float g = c8[e] * p.s * gamL[cc];           // gamma = 0 past K
+          const float xh = cc < K ? (x8[e] - mean) * rstd : 0.f;
+          G[c][gp][e] = g;
+          s1 += g;
+          s2 = fmaf(g, xh, s2);
+        }
+      }
+    {
+      const auto a1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+      s1 = (__uint_as_float(a1[0]) + __uint_as_float(a1[1])) * invK;
+      const auto a2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+      s2 = (__uint_as_float(a2[0]) + __uint_as_float(a2[1])) * invK;
+    }
+    if (!valid) continue;
+    T* drow = p.dX + row * p.lddx;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int cb = col_of(c, gp, 0);
+        if (cb >= K) continue;
+        float o8[8], x8[8];
+        load8(xrow, c, gp, x8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (x8[e] - mean) * rstd;   // channels past K are never stored
+          o8[e] = rstd * (G[c][gp][e] - s1 - xh * s2);
+        }
+        if (p.Acc) {
+          float a8[8];
+          load8(p.Acc + row * p.ldacc, c, gp, a8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] += a8[e];
+        }
+        if (BF && cb + 8 <= K && (reinterpret_cast<uintptr_t>(drow + cb) & 3) == 0) {
+          u32x4_a4 u;
+          u.x = pack_bf16x2(o8[0], o8[1]); u.y = pack_bf16x2(o8[2], o8[3]);
+          u.z = pack_bf16x2(o8[4], o8[5]); u.w = pack_bf16x2(o8[6], o8[7]);
+          *reinterpret_cast<u32x4_a4*>(drow + cb) = u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int cc = col_of(c, gp, e);
+            if (cc < K) drow[cc] = from_f32<T>(o8[e]);
+          }
+        }
+      }
+  }
+}
+
 template <typename T> bool rows_ok(const void*, int64_t) { return true; }  // load_pack checks alignment per access
 
 // ------------------------------------------------------------------------------------------------
@@ -636,7 +828,8 @@ struct WgradArgs {
 // before it is bandwidth bound).  PF stripes are prefetched into registers ahead of the one being
 // multiplied, the LDS tiles are double buffered (one barrier per stripe), LayerNorm's gamma/beta sit
 // in LDS, and every address is a precomputed per-thread offset plus a wave-uniform base.
-// XF: transform of X while it is staged — 0 none, 1 LayerNorm, 2 GELU, 3 any other activation
+// XF: transform of X while it is staged — 0 none, 1 LayerNorm, 2 GELU, 3 any other activation,
+//     4 x-hat = (x - mean) * rstd only (the affine part and d(gamma)/d(beta) are finished by the reduction)
 template <typename T, int PF, int XF>
 __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -732,7 +925,7 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
       if (x_row[i] >= 0) {
         const int row = x_row[i] < left ? x_row[i] : left - 1;
         rx[set][i] = ld16(xb, (uint32_t)(row * (int)ldx_b + x_col[i]));
-        if (XF == 1) {
+        if (XF == 1 || XF == 4) {
           const float2 ms = *reinterpret_cast<const float2*>(stb + 2 * row);
           rmean[set][i] = ms.x;
           rrstd[set][i] = ms.y;
@@ -773,6 +966,10 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
             const float rs = rrstd[set][i], mu = rmean[set][i];
 #pragma unroll
             for (int e = 0; e < HP; ++e) f[e] = (f[e] - mu) * rs * gv[e] + bv[e];
+          } else if (XF == 4) {
+            const float rs = rrstd[set][i], mu = rmean[set][i];
+#pragma unroll
+            for (int e = 0; e < HP; ++e) f[e] = (f[e] - mu) * rs;
           } else if (XF == 2) {
 #pragma unroll
             for (int e = 0; e < HP; ++e) f[e] = sizeof(T) == 2 ? gelu_fast(f[e]) : gelu_erf(f[e]);
@@ -919,6 +1116,57 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// LayerNorm-fused Linear, weight-gradient side.  The wgrad kernel ran on x-hat, so its slabs hold
+// G[n][k] = sum_m dY[m][n] xhat[m][k] (k < K) and db[n] = sum_m dY[m][n] (column K).  Step 1 sums the slabs.
+__global__ void __launch_bounds__(256) wgrad_sum_kernel(const float* __restrict__ slab, int nwg, int tot, float* __restrict__ G) {
+  __shared__ float part[8][33];
+  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
+  float a = 0.f;
+  if (i < tot)
+    for (int w = sg; w < nwg; w += 8) a += slab[(int64_t)w * tot + i];
+  part[sg][o] = a;
+  __syncthreads();
+  if (sg != 0 || i >= tot) return;
+  a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a += part[k][o];
+  G[i] = a;
+}
+// Step 2, one block per 32 LayerNorm channels:  dW[n][k] = s (gamma_k G[n][k] + beta_k db[n]),  dbias[n] = s db[n],
+//   d(gamma)[k] = s sum_n W[n][k] G[n][k],   d(beta)[k] = s sum_n W[n][k] db[n]      (fixed summation order)
+__global__ void __launch_bounds__(256) wgrad_ln_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int N, int K, int Kx, float s, float* __restrict__ dW,
+                                                              float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ float pg[8][33], pb[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + tx;
+  const float gk = k < K ? gamma[k] : 0.f, bk = k < K ? beta[k] : 0.f;
+  float ag = 0.f, ab = 0.f;
+  for (int n = ty; n < N; n += 8) {
+    const float db = G[(int64_t)n * Kx + K];
+    if (k < K) {
+      const float g = G[(int64_t)n * Kx + k], w = Wt[(int64_t)n * K + k];
+      if (dW) dW[(int64_t)n * K + k] = s * fmaf(gk, g, bk * db);
+      ag = fmaf(w, g, ag);
+      ab = fmaf(w, db, ab);
+    }
+    if (blockIdx.x == 0 && tx == 0 && dbias) dbias[n] = s * db;
+  }
+  pg[ty][tx] = ag;
+  pb[ty][tx] = ab;
+  __syncthreads();
+  if (ty == 0 && k < K) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a += pg[j][tx]; b += pb[j][tx]; }
+    if (dgamma) dgamma[k] = s * a;
+    if (dbeta) dbeta[k] = s * b;
+  }
+}
+
 }  // namespace
 
 template <typename T>
@@ -962,7 +1210,7 @@ int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const floa
   if (smem > 160 * 1024) return RDST_ENOTSUP;
   const int64_t nslabs = (M + 31) / 32;
   int64_t grid = (nslabs + 7) / 8;
-  const int64_t cap = smem <= 78 * 1024 ? 512 : 256;
+  const int64_t cap = 256;   // persistent, one workgroup per CU (185+ VGPRs: a second one would not be resident anyway)
   if (grid > cap) grid = cap;
   *nslab = (int)grid;
 #define RDST_LND_LAUNCH(TM)                                                                                          \
@@ -981,10 +1229,12 @@ size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N) {
   return (size_t)256 * N * (K + 1);
 }
 
+namespace {
 template <typename T>
-int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
-                      const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
-                      hipStream_t st) {
+int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
+               const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
+               const float* Wt_fin, float* G, float* dln_w, float* dln_b, hipStream_t st) {
+  const bool lnfin = G != nullptr;   // LayerNorm finish: x-hat slabs, then dW/dbias/d(gamma)/d(beta) from G
   if (mfma_disabled() || !rows_ok<T>(X, ldx) || !rows_ok<T>(dY, lddy)) return RDST_ENOTSUP;
   WgradArgs<T> p{};
   p.X = X; p.ldx = ldx; p.lnw = ln_w; p.lnb = ln_b; p.stats = stats; p.in_act = in_act; p.dY = dY; p.lddy = lddy;
@@ -1012,19 +1262,77 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   p.rows_per_wg = (((M + nwg - 1) / nwg + WG_STRIPE - 1) / WG_STRIPE) * WG_STRIPE;
   nwg = (M + p.rows_per_wg - 1) / p.rows_per_wg;
   constexpr int PF = sizeof(T) == 2 ? 2 : 1;  // register sets of prefetched stripes
-  const int xf = ln_w ? 1 : in_act == RDST_ACT_GELU ? 2 : in_act ? 3 : 0;
+  const int xf = lnfin ? 4 : ln_w ? 1 : in_act == RDST_ACT_GELU ? 2 : in_act ? 3 : 0;
 #define RDST_WG_LAUNCH(XF)                                                                                            \
   {                                                                                                                  \
     auto kern = lin_wgrad_mfma_kernel<T, PF, XF>;                                                                    \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WG_THREADS), smem, st, p);                                    \
   }
-  if (xf == 0) RDST_WG_LAUNCH(0) else if (xf == 1) RDST_WG_LAUNCH(1) else if (xf == 2) RDST_WG_LAUNCH(2) else RDST_WG_LAUNCH(3)
+  if (xf == 0) RDST_WG_LAUNCH(0) else if (xf == 1) RDST_WG_LAUNCH(1) else if (xf == 2) RDST_WG_LAUNCH(2) else if (xf == 4) RDST_WG_LAUNCH(4) else RDST_WG_LAUNCH(3)
 #undef RDST_WG_LAUNCH
   if (int rc = rdst_launch_status("lin_wgrad_mfma")) return rc;
   const int tot = N * p.Kx;
+  if (lnfin) {
+    hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, tot, G);
+    if (int rc = rdst_launch_status("wgrad_sum")) return rc;
+    hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 31) / 32), dim3(256), 0, st, G, Wt_fin, ln_w, ln_b, N, K, p.Kx, s, dW,
+                       dbias, dln_w, dln_b);
+    return rdst_launch_status("wgrad_ln_finish");
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
   return rdst_launch_status("wgrad_reduce");
+}
+}  // namespace
+
+template <typename T>
+int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act,
+                      const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
+                      hipStream_t st) {
+  return wgrad_impl<T>(X, ldx, ln_w, ln_b, stats, in_act, dY, lddy, dW, dbias, slab, M, K, N, s, nullptr, nullptr, nullptr,
+                       nullptr, st);
+}
+
+// LayerNorm-fused Linear: dW, dbias AND d(gamma), d(beta) from one pass over (x-hat, dY).  G: N*(K+1) floats of scratch.
+template <typename T>
+int linear_wgrad_ln_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, const float* Wt,
+                         const T* dY, int64_t lddy, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab,
+                         float* G, int64_t M, int K, int N, float s, hipStream_t st) {
+  if (!ln_w || !ln_b || !stats || !Wt || !G) return RDST_ENOTSUP;
+  return wgrad_impl<T>(X, ldx, ln_w, ln_b, stats, 0, dY, lddy, dW, dbias, slab, M, K, N, s, Wt, G, dln_w, dln_b, st);
+}
+
+// dgrad + LayerNorm backward, dX only (d(gamma)/d(beta) come from linear_wgrad_ln_mfma); K <= 128
+template <typename T>
+int linear_dgrad_ln2_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
+                          int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, int64_t M, int K, int N, float s,
+                          hipStream_t st) {
+  using MM = Mma<T>;
+  if (mfma_disabled() || K > 128 || !dX) return RDST_ENOTSUP;
+  const int64_t rowbytes = (int64_t)N * (int64_t)sizeof(T);
+  if (((uintptr_t)dY & 3) || (lddy * sizeof(T)) % 4 || rowbytes % 4 || rowbytes < 16 || !(rowbytes % 128 == 0 || rowbytes % 128 >= 16))
+    return RDST_ENOTSUP;
+  LnDgradArgs<T> p{};
+  p.dY = dY; p.lddy = lddy; p.Wt = Wt; p.N = N; p.K = K; p.X = X; p.ldx = ldx; p.stats = stats; p.gamma = gamma;
+  p.dX = dX; p.lddx = lddx; p.Acc = acc; p.ldacc = ldacc; p.slab = nullptr; p.M = M; p.s = s;
+  p.Tn = (N + MM::KP - 1) / MM::KP;
+  if (p.Tn > 32) return RDST_ENOTSUP;
+  p.ldw = lds_row_bytes(N, sizeof(T));
+  const int nct = (K + 31) / 32, kpad = nct * 32;
+  const size_t smem = (size_t)kpad * p.ldw + (size_t)kpad * sizeof(float) + 8 * 32 * 144;
+  if (smem > 160 * 1024) return RDST_ENOTSUP;
+  const int64_t nslabs = (M + 31) / 32;
+  int64_t grid = (nslabs + 7) / 8;
+  if (grid > 256) grid = 256;   // persistent, one workgroup per CU
+#define RDST_LND2_LAUNCH(NC)                                                                                          \
+  {                                                                                                                  \
+    auto kern = lin_dgrad_ln2_kernel<T, NC>;                                                                         \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);                                          \
+  }
+  if (nct == 1) RDST_LND2_LAUNCH(1) else if (nct == 2) RDST_LND2_LAUNCH(2) else if (nct == 3) RDST_LND2_LAUNCH(3) else RDST_LND2_LAUNCH(4)
+#undef RDST_LND2_LAUNCH
+  return rdst_launch_status("lin_dgrad_ln2_mfma");
 }
 
 #define INST(T)                                                                                                        \
@@ -1036,6 +1344,11 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
   template int linear_dgrad_mfma<T>(const T*, int64_t, bool, int, const float*, const T*, int64_t, T*, int64_t,       \
                                     const T*, int64_t, float*, int64_t, int, int, float, hipStream_t);                \
   template int linear_wgrad_mfma<T>(const T*, int64_t, const float*, const float*, const float*, int, const T*,       \
-                                    int64_t, float*, float*, float*, int64_t, int, int, float, hipStream_t);
+                                    int64_t, float*, float*, float*, int64_t, int, int, float, hipStream_t);         \
+  template int linear_wgrad_ln_mfma<T>(const T*, int64_t, const float*, const float*, const float*, const float*,     \
+                                       const T*, int64_t, float*, float*, float*, float*, float*, float*, int64_t,    \
+                                       int, int, float, hipStream_t);                                                 \
+  template int linear_dgrad_ln2_mfma<T>(const T*, int64_t, const float*, const float*, const float*, const T*, int64_t, \
+                                        T*, int64_t, const T*, int64_t, int64_t, int, int, float, hipStream_t);
 INST(float)
 INST(bf16)

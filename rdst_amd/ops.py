@@ -88,7 +88,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 # and each under-fills the chip, so they run concurrently: wgrad on a side HIP stream, dgrad on the
 # current one, joined before the op returns (fork/join is capturable into a HIP graph).
 _side_streams: dict = {}
-TWO_STREAM_BACKWARD = os.environ.get("RDST_TWO_STREAM", "1") != "0"   # env switch: profiling with clean kernel durations
+TWO_STREAM_BACKWARD = os.environ.get("RDST_TWO_STREAM", "0") != "0"   # env switch: profiling with clean kernel durations
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
