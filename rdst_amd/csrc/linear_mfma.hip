@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
     __syncthreads();
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
-    stage_packs_batched<T, 8>(ncp * 2 * Tn, p.Kc, MODE == MODE_FWD ? 1 : p.wK, tid, 512,
+    stage_packs_batched<T, 12>(ncp * 2 * Tn, p.Kc, MODE == MODE_FWD ? 1 : p.wK, tid, 512,
                               [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
                                 const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
                                 ok = n < nc;
@@ -1135,17 +1135,18 @@ __global__ void __launch_bounds__(256) wgrad_sum_kernel(const float* __restrict_
 }
 // Step 2, one block per 32 LayerNorm channels:  dW[n][k] = s (gamma_k G[n][k] + beta_k db[n]),  dbias[n] = s db[n],
 //   d(gamma)[k] = s sum_n W[n][k] G[n][k],   d(beta)[k] = s sum_n W[n][k] db[n]      (fixed summation order)
-__global__ void __launch_bounds__(256) wgrad_ln_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              int N, int K, int Kx, float s, float* __restrict__ dW,
-                                                              float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
-  __shared__ float pg[8][33], pb[8][33];
+__global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int N, int K, int Kx, float s, float* __restrict__ dW,
+                                                               float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  __shared__ float pg[32][33], pb[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int k = blockIdx.x * 32 + tx;
   const float gk = k < K ? gamma[k] : 0.f, bk = k < K ? beta[k] : 0.f;
   float ag = 0.f, ab = 0.f;
-  for (int n = ty; n < N; n += 8) {
+#pragma unroll 4
+  for (int n = ty; n < N; n += 32) {
     const float db = G[(int64_t)n * Kx + K];
     if (k < K) {
       const float g = G[(int64_t)n * Kx + k], w = Wt[(int64_t)n * K + k];
@@ -1161,7 +1162,7 @@ __global__ void __launch_bounds__(256) wgrad_ln_finish_kernel(const float* __res
   if (ty == 0 && k < K) {
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { a += pg[j][tx]; b += pb[j][tx]; }
+    for (int j = 0; j < 32; ++j) { a += pg[j][tx]; b += pb[j][tx]; }
     if (dgamma) dgamma[k] = s * a;
     if (dbeta) dbeta[k] = s * b;
   }
@@ -1276,7 +1277,7 @@ int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, co
   if (lnfin) {
     hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, tot, G);
     if (int rc = rdst_launch_status("wgrad_sum")) return rc;
-    hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 31) / 32), dim3(256), 0, st, G, Wt_fin, ln_w, ln_b, N, K, p.Kx, s, dW,
+    hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 31) / 32), dim3(1024), 0, st, G, Wt_fin, ln_w, ln_b, N, K, p.Kx, s, dW,
                        dbias, dln_w, dln_b);
     return rdst_launch_status("wgrad_ln_finish");
   }
