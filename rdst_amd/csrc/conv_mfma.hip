@@ -48,6 +48,7 @@ struct ConvArgs {
   float s;
   int Tn, ldw, nch;
   int eps_off;
+  int dbg;   // RDST_CONV_DEBUG ablation: 1 skip tile loads, 2 skip MFMAs, 4 skip stores, 8 skip the slab loop
 };
 
 template <typename T, int TMAX, int MODE>
@@ -176,9 +177,323 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad for 3x3 / pad 1 convs whose image width is a multiple of 32: the row-stripe form.
+// A slab is 32 consecutive pixels of ONE image row.  For each kernel row ky the 34 neighbour pixels
+// x0-1 .. x0+32 of image row y+ky-1 are read ONCE, coalesced (8 lanes x 16 B of a pixel, 8 pixels per
+// instruction), in 128-B channel chunks, into a wave-private LDS tile; the three kx taps are row offsets
+// of the fragment reads (the generic kernel above re-reads every neighbour row per tap in fragment
+// shape: 9x the load instructions at 32 B per row).  Accumulators are kept TRANSPOSED (output channel in
+// the registers, pixel on the lane) and leave as 16-B row stores straight from the registers; for
+// PixelShuffle(2) the four sub-pixels of a lane are 8-B runs of 4 consecutive output channels.
+// The next tile's chunks are prefetched while the current one is multiplied.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, int PF>
+__global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using MM = Mma<T>;
+  constexpr int KP = MM::KP, HP = MM::HP;
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int TLD = 144;          // tile row: 128 B of the pixel's channels + 16 B pad (odd 16-B slots)
+  constexpr int TROWS = 34;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int Tn = p.Tn;
+  const ConvGeom g = p.g;
+  const int64_t P = g.pixels();
+  const int64_t nslabs = P / 32;    // W % 32 == 0
+  char* tile = smem + p.eps_off + wave * (TROWS * TLD);
+  float* biasL = reinterpret_cast<float*>(smem + p.eps_off + 8 * TROWS * TLD);
+  const int npad = ((p.Nout + 31) / 32) * 32;
+  if (MODE == CMODE_FWD)
+    for (int i = tid; i < npad; i += 512) biasL[i] = (p.bias && i < p.Nout) ? p.bias[i] : 0.f;
+  const int rowbytes = p.CA * (int)sizeof(T);
+  const int nkc = (rowbytes + 127) / 128;
+  const int crow = lane >> 3, cchk = lane & 7;
+
+  // raw chunk (ky, kc) of the slab at (b, y, x0): 5 instructions x 8 tile rows
+  auto issue = [&](Pack16 (&rw)[5], int b, int y, int x0, int ky, int kc) {
+    if (p.dbg & 1) return;
+    int yy = y + ky - 1;
+    yy = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);        // rows outside the image are skipped by the consumer
+    int off = kc * 128 + cchk * 16;
+    if (off + 16 > rowbytes) off = rowbytes - 16;
+    const T* rowbase = p.A + (((int64_t)b * g.H + yy) * g.W) * p.lda;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int j = 8 * i + crow;                               // tile row: pixel x0 - 1 + j
+      j = j > TROWS - 1 ? TROWS - 1 : j;
+      int xx = x0 - 1 + j;
+      xx = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);      // the image's edge columns are zeroed when the tile is written
+      const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(rowbase + (int64_t)xx * p.lda) + off);
+      rw[i].w[0] = v.x; rw[i].w[1] = v.y; rw[i].w[2] = v.z; rw[i].w[3] = v.w;
+    }
+  };
+
+  for (int n0 = 0; n0 < p.Nout; n0 += p.nch) {
+    __syncthreads();
+    const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
+    const int ncp = ((nc + 31) / 32) * 32;
+    // weights of this column chunk: LDS image [tap][column n][contraction k], k contiguous; the tap stride is
+    // padded by one 16-B slot so the nine taps of the scattered stores fall on different banks
+    const int tapst = ncp * p.ldw + 16;
+    if (!(p.dbg & 32)) lds_zero16(smem, 9 * tapst, tid, 512);
+    __syncthreads();
+    if (p.dbg & 16) {
+    } else if (MODE == CMODE_FWD) {
+      // Wc[co][ci][tap]: rows co = n0 .. n0+nc-1 are one contiguous block of nc * Cin * 9 floats
+      stage_scatter<T>(p.Wc + (int64_t)n0 * g.Cin * 9, nc, g.Cin * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int n, int j) {
+        const int ci = j / 9, tap = j - ci * 9;
+        return tap * tapst + n * p.ldw + ci * (int)sizeof(T);
+      });
+    } else {
+      // dgrad: contraction over co, output column = ci, mirrored tap: per co the segment ci = n0 .. n0+nc-1
+      stage_scatter<T>(p.Wc + (int64_t)n0 * 9, g.Cout, nc * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int co, int j) {
+        const int n = j / 9, tap = j - n * 9;
+        return (8 - tap) * tapst + n * p.ldw + co * (int)sizeof(T);
+      });
+    }
+    __syncthreads();
+    const int nct = ncp / 32;
+
+    for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < ((p.dbg & 8) ? 0 : nslabs); slab += (int64_t)gridDim.x * 8) {
+      int b, y, x0;
+      g.decode(slab * 32, b, y, x0);
+      f32x16 acc[CV_MAXCT];
+#pragma unroll
+      for (int c = 0; c < CV_MAXCT; ++c) {
+        if (MODE == CMODE_FWD && c < nct) {  // bias = initial accumulator: register group g4 holds channels 8 g4 + 4h .. +3
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bq = *reinterpret_cast<const float4*>(biasL + n0 + c * 32 + 8 * g4 + 4 * h);
+            acc[c][4 * g4] = bq.x; acc[c][4 * g4 + 1] = bq.y; acc[c][4 * g4 + 2] = bq.z; acc[c][4 * g4 + 3] = bq.w;
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+        }
+      }
+      // PF chunks are in flight ahead of the one being multiplied (a step's MFMAs are short against the load
+      // latency and only two waves share a SIMD)
+      const int nsteps = 3 * nkc;
+      Pack16 raw[PF][5];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int st0 = u < nsteps ? u : nsteps - 1;
+        const int k0y = st0 / nkc;
+        issue(raw[u], b, y, x0, k0y, st0 - k0y * nkc);
+      }
+      for (int sg = 0; sg < nsteps; sg += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int step = sg + u;
+          if (step >= nsteps) break;
+          const int ky = step / nkc, kc = step - ky * nkc;
+          // raw -> tile (edge columns zeroed, input activation applied once), then the chunk PF steps ahead goes in flight
+          {
+            int off = kc * 128 + cchk * 16;
+            const bool act = off < rowbytes;
+            if (off + 16 > rowbytes) off = rowbytes - 16;
+            const int loc = off - kc * 128;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              const int j = 8 * i + crow;
+              if (j < TROWS && act) {
+                const int xx = x0 - 1 + j;
+                Pack16 q = raw[u][i];
+                if (xx < 0 || xx >= g.W) { q.w[0] = 0u; q.w[1] = 0u; q.w[2] = 0u; q.w[3] = 0u; }
+                else if (MODE == CMODE_FWD && p.in_act) {
+                  float f[HP];
+                  MM::unpack(q, f);
+#pragma unroll
+                  for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);
+                  q = MM::pack(f);
+                }
+                *reinterpret_cast<Pack16*>(tile + j * TLD + loc) = q;
+              }
+            }
+          }
+          {
+            const int ns = step + PF < nsteps ? step + PF : step;   // always redefines the whole set
+            const int nky = ns / nkc;
+            issue(raw[u], b, y, x0, nky, ns - nky * nkc);
+          }
+          const int yy = y + ky - 1;
+          if (yy < 0 || yy >= g.H) continue;                       // zero padding: this kernel row adds nothing
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int tap = ky * 3 + kx;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+              const int t = 4 * kc + tt;
+              if (t < Tn) {
+                Pack16 a = *reinterpret_cast<const Pack16*>(tile + (r + kx) * TLD + tt * 32 + h * 16);
+                if (t == Tn - 1) {   // elements past the last channel inside the last k-step: zero (may be NaN bits)
+                  const int kl = t * KP + h * HP;
+                  if (kl + HP > p.CA) {
+                    float f[HP];
+                    MM::unpack(a, f);
+#pragma unroll
+                    for (int e = 0; e < HP; ++e) f[e] = (kl + e < p.CA) ? f[e] : 0.f;
+                    a = MM::pack(f);
+                  }
+                }
+                const char* wrow = smem + (size_t)tap * tapst + (size_t)r * p.ldw + t * 32 + h * 16;
+#pragma unroll
+                for (int c = 0; c < CV_MAXCT; ++c)
+                  if (c < nct) {
+                    const Pack16 wa = *reinterpret_cast<const Pack16*>(wrow + (size_t)c * 32 * p.ldw);
+                    if (!(p.dbg & 2)) MM::mma(acc[c], wa, a);   // rows = output channels, cols = pixels
+                  }
+              }
+            }
+          }
+        }
+      }
+      // epilogue
+      if (p.dbg & 4) continue;
+      const int64_t pix = slab * 32 + r;
+      const int x = x0 + r;
+#pragma unroll
+      for (int c = 0; c < CV_MAXCT; ++c)
+        if (c < nct) {
+          if (MODE == CMODE_FWD && g.r == 2) {
+            // PixelShuffle(2): conv channel n = 4 c' + 2 i + j -> channel c' of output pixel (2y+i, 2x+j).  Register
+            // v holds n = 8 (v>>2) + 4h + (v&3): for q = v & 3 = 2i + j the lane owns c' = 2 (v>>2) + h; one swap per
+            // register gives each lane half 4 consecutive c' of that sub-pixel.
+            const int cq = (n0 + c * 32) / 4 + 4 * h;            // first of the lane's 4 output channels
+            const int Co = g.Cout / 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][q] * p.s), __float_as_uint(acc[c][8 + q] * p.s), false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][4 + q] * p.s), __float_as_uint(acc[c][12 + q] * p.s), false, false);
+              const float o0 = __uint_as_float(s0[0]), o1 = __uint_as_float(s0[1]), o2 = __uint_as_float(s1[0]), o3 = __uint_as_float(s1[1]);
+              const int i = q >> 1, j = q & 1;
+              const int64_t orow = ((int64_t)b * (2 * g.H) + 2 * y + i) * (int64_t)(2 * g.W) + 2 * x + j;
+              T* dst = p.Y + orow * p.ldy + cq;
+              if (cq + 4 <= Co && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+                if (BF) {
+                  u32x2_a4 u;
+                  u.x = pack_bf16x2(o0, o1); u.y = pack_bf16x2(o2, o3);
+                  *reinterpret_cast<u32x2_a4*>(dst) = u;
+                } else {
+                  dst[0] = from_f32<T>(o0); dst[1] = from_f32<T>(o1); dst[2] = from_f32<T>(o2); dst[3] = from_f32<T>(o3);
+                }
+              } else {
+                const float o[4] = {o0, o1, o2, o3};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (cq + e < Co) dst[e] = from_f32<T>(o[e]);
+              }
+            }
+            continue;
+          }
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            float c8[8];
+            int cb;
+            if (BF) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[c][8 * gp + e] * p.s),
+                                                                 __float_as_uint(acc[c][8 * gp + 4 + e] * p.s), false, false);
+                c8[e] = __uint_as_float(sw[0]);
+                c8[4 + e] = __uint_as_float(sw[1]);
+              }
+              cb = n0 + c * 32 + 8 * (2 * gp + h);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c8[e] = acc[c][8 * gp + e] * p.s;
+              cb = n0 + c * 32 + 16 * gp + 4 * h;
+            }
+            auto colof = [&](int e) { return BF ? cb + e : cb + (e & 3) + 8 * (e >> 2); };
+            auto chunk8 = [&](const T* rowp, float (&g8)[8]) {
+              if (BF && cb + 8 <= p.Nout && (reinterpret_cast<uintptr_t>(rowp + cb) & 3) == 0) {
+                const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb);
+                g8[0] = bf16lo(u.x); g8[1] = bf16hi(u.x); g8[2] = bf16lo(u.y); g8[3] = bf16hi(u.y);
+                g8[4] = bf16lo(u.z); g8[5] = bf16hi(u.z); g8[6] = bf16lo(u.w); g8[7] = bf16hi(u.w);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g8[e] = colof(e) < p.Nout ? to_f32<T>(rowp[colof(e)]) : 0.f;
+              }
+            };
+            if (MODE == CMODE_FWD) {
+              if (p.R) {
+                float g8[8];
+                chunk8(p.R + pix * p.ldr, g8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c8[e] += g8[e];
+              }
+            } else {
+              if (p.in_act) {
+                float g8[8];
+                chunk8(p.Xa + pix * p.ldxa, g8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c8[e] *= act_grad(g8[e], p.in_act);
+              }
+              if (p.Acc) {
+                float g8[8];
+                chunk8(p.Acc + pix * p.ldacc, g8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c8[e] += g8[e];
+              }
+            }
+            T* yrow = p.Y + pix * p.ldy;
+            if (BF && cb + 8 <= p.Nout && (reinterpret_cast<uintptr_t>(yrow + cb) & 3) == 0) {
+              u32x4_a4 u;
+              u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+              u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+              *reinterpret_cast<u32x4_a4*>(yrow + cb) = u;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) if (colof(e) < p.Nout) yrow[colof(e)] = from_f32<T>(c8[e]);
+            }
+          }
+        }
+    }
+  }
+}
+
+// row-stripe kernel: 3x3 / pad 1, W % 32 == 0, PixelShuffle factor 1 or 2 (2: forward, no residual),
+// dword-aligned rows of at least 16 B whose last 128-B chunk is not shorter than 16 B
+template <typename T, int MODE>
+int launch_conv_rows(ConvArgs<T>& p, hipStream_t st, const char* what) {
+  using MM = Mma<T>;
+  const ConvGeom& g = p.g;
+  if (g.ks != 3 || g.pad != 1 || g.W % 32 != 0 || getenv("RDST_CONV_V1")) return RDST_ENOTSUP;
+  if (MODE == CMODE_FWD && !(g.r == 1 || (g.r == 2 && !p.R && g.Cout % 4 == 0))) return RDST_ENOTSUP;
+  const int64_t rowbytes = (int64_t)p.CA * (int64_t)sizeof(T);
+  if (((uintptr_t)p.A & 3) || (p.lda * sizeof(T)) % 4 || rowbytes % 4 || rowbytes < 16 || !(rowbytes % 128 == 0 || rowbytes % 128 >= 16))
+    return RDST_ENOTSUP;
+  p.Tn = (p.CA + MM::KP - 1) / MM::KP;
+  if (p.Tn > 16) return RDST_ENOTSUP;
+  p.ldw = lds_row_bytes(p.CA, sizeof(T));
+  const int npad = ((p.Nout + 31) / 32) * 32;
+  const size_t extra = (size_t)8 * 34 * 144 + (size_t)npad * sizeof(float);
+  int nch = (int)((160 * 1024 - extra - 9 * 16) / ((size_t)9 * p.ldw)) / 32 * 32;
+  if (nch > 32 * CV_MAXCT) nch = 32 * CV_MAXCT;
+  if (nch < 32) return RDST_ENOTSUP;
+  if (nch > npad) nch = npad;
+  p.nch = nch;
+  p.eps_off = 9 * (nch * p.ldw + 16);   // here: offset of the wave tiles
+  { const char* e = getenv("RDST_CONV_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  const size_t smem = (size_t)p.eps_off + extra;
+  const int64_t nslabs = g.pixels() / 32;
+  int64_t grid = (nslabs + 7) / 8;
+  if (grid > 256) grid = 256;
+  static int pf = -1;
+  if (pf < 0) { const char* e = getenv("RDST_CONV_PF"); pf = e ? atoi(e) : 3; }
+  auto kern = pf == 1 ? conv_rows_kernel<T, MODE, 1> : pf == 2 ? conv_rows_kernel<T, MODE, 2> : conv_rows_kernel<T, MODE, 3>;
+  if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);
+  return rdst_launch_status(what);
+}
+
 template <typename T, int MODE>
 int launch_conv(ConvArgs<T>& p, hipStream_t st, const char* what) {
   using MM = Mma<T>;
+  {
+    const int rc = launch_conv_rows<T, MODE>(p, st, what);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   p.Tn = (p.CA + MM::KP - 1) / MM::KP;
   if (p.Tn > 16) return RDST_ENOTSUP;
   p.ldw = lds_row_bytes(p.CA, sizeof(T));

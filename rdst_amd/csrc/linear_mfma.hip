@@ -182,15 +182,21 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
     __syncthreads();
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
-    stage_packs_batched<T, 12>(ncp * 2 * Tn, p.Kc, MODE == MODE_FWD ? 1 : p.wK, tid, 512,
-                              [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
-                                const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
-                                ok = n < nc;
-                                k0 = ph * HP;
-                                // forward: row n of W (N,K), k contiguous; dgrad: column n of W, k at stride K_lin
-                                src = MODE == MODE_FWD ? p.Wt + (int64_t)(n0 + n) * p.wK + k0 : p.Wt + (n0 + n) + (int64_t)k0 * p.wK;
-                                dst = Ws + (size_t)n * p.ldw + ph * 16;
-                              });
+    if (MODE == MODE_FWD) {
+      stage_packs_batched<T, 12>(ncp * 2 * Tn, p.Kc, 1, tid, 512, [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
+        const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
+        ok = n < nc;
+        k0 = ph * HP;
+        src = p.Wt + (int64_t)(n0 + n) * p.wK + k0;   // row n of W (N,K), k contiguous
+        dst = Ws + (size_t)n * p.ldw + ph * 16;
+      });
+    } else {
+      // dgrad: output column n = K_lin index, contraction k = N_lin index: W (N_lin, K_lin) read row-wise
+      // (coalesced), scattered transposed into the LDS image [n][k]
+      lds_zero16(Ws, ncp * p.ldw, tid, 512);
+      __syncthreads();
+      stage_scatter<T>(p.Wt + n0, p.Kc, nc, (int64_t)p.wK, tid, 512, Ws, [&](int k, int n) { return n * p.ldw + k * (int)sizeof(T); });
+    }
     __syncthreads();
     const int nct = ncp / 32;
 
@@ -650,13 +656,10 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T>
   };
   Pack16 raw[4];
   if (slab0 < nslabs) issue_chunk(raw, slab0, 0);   // in flight while the weights are staged
-  stage_packs_batched<T, 8>(kpad * 2 * Tn, p.N, p.K, tid, 512, [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
-    const int k = idx / (2 * Tn), ph = idx - k * (2 * Tn);
-    ok = k < K;
-    k0 = ph * HP;                                  // contraction index n: element n at Wt[n*K + k]
-    src = p.Wt + k + (int64_t)k0 * p.K;
-    dst = Ws + (size_t)k * p.ldw + ph * 16;
-  });
+  lds_zero16(Ws, kpad * p.ldw, tid, 512);
+  __syncthreads();
+  // W (N, K) read row-wise (coalesced), scattered transposed: LDS row = LayerNorm channel k, columns n contiguous
+  stage_scatter<T>(p.Wt, p.N, K, (int64_t)K, tid, 512, Ws, [&](int n, int k) { return k * p.ldw + n * (int)sizeof(T); });
   for (int i = tid; i < kpad; i += 512) gamL[i] = i < K ? p.gamma[i] : 0.f;
   __syncthreads();
   const float invK = 1.0f / (float)K;

@@ -142,6 +142,105 @@ __device__ __forceinline__ void stage_packs_batched(int total, int K, int64_t st
   }
 }
 
+// Stage a strided-transposed view of fp32 parameters into LDS with COALESCED global reads: the source is
+// read as R rows of L contiguous floats (row stride S floats; consecutive lanes read consecutive floats,
+// 16-B loads when the geometry allows), every element is converted and written on its own to
+// lds + dst(rr, j) (negative = dropped).  A gather with one pack per lane made every lane touch its own
+// cache line (measured: 40-90 us of prologue per conv launch, 7-12 us per Linear dgrad launch).
+// The destination region must have been zero-filled (padding rows / columns) before.
+template <typename T, class F>
+__device__ __forceinline__ void stage_scatter(const float* __restrict__ src, int R, int L, int64_t S, int tid, int nthreads,
+                                              char* lds, F dst) {
+  auto put = [&](int rr, int j, float v) {
+    const int off = dst(rr, j);
+    if (off >= 0) *reinterpret_cast<T*>(lds + off) = from_f32<T>(v);
+  };
+  if (S == L && (L & 3) != 0) {
+    // contiguous block whose rows are not whole float4s: read it flat, 16 B per lane, and split each group over
+    // the (at most two) rows it touches — one division per group instead of the scalar path's 4x more loads
+    const int64_t tot = (int64_t)R * L;
+    const int n4 = (int)(tot >> 2);
+    constexpr int U = 8;
+    for (int base = tid; base < n4; base += nthreads * U) {
+      u32x4_a4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + nthreads * u;
+        v[u] = *reinterpret_cast<const u32x4_a4*>(src + 4 * (int64_t)(i < n4 ? i : n4 - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + nthreads * u;
+        if (i < n4) {
+          const int f = 4 * i;
+          int rr = f / L, j = f - rr * L;
+          const float e4[4] = {__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            put(rr, j, e4[e]);
+            if (++j == L) { j = 0; ++rr; }
+          }
+        }
+      }
+    }
+    for (int64_t f = 4 * (int64_t)n4 + tid; f < tot; f += nthreads) put((int)(f / L), (int)(f % L), src[f]);
+    return;
+  }
+  // thread -> (row, column group) by shift / mask (no integer divisions): a row is padded to a power of two of groups
+  const bool vec = (L & 3) == 0;
+  const int G = vec ? (L >> 2) : L;            // column groups per row (of 4 floats / of 1 float)
+  int sh = 0;
+  while ((1 << sh) < G) ++sh;
+  const int total = R << sh;
+  if (vec) {
+    constexpr int U = 16;   // loads in flight per thread before the first conversion (the loop is latency bound)
+    for (int base = tid; base < total; base += nthreads * U) {
+      u32x4_a4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + nthreads * u;
+        int rr = i >> sh, j4 = i & ((1 << sh) - 1);
+        rr = rr < R ? rr : R - 1;
+        j4 = j4 < G ? j4 : G - 1;
+        v[u] = *reinterpret_cast<const u32x4_a4*>(src + (int64_t)rr * S + 4 * j4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + nthreads * u;
+        const int rr = i >> sh, j4 = i & ((1 << sh) - 1);
+        if (rr < R && j4 < G) {
+          put(rr, 4 * j4, __uint_as_float(v[u].x));
+          put(rr, 4 * j4 + 1, __uint_as_float(v[u].y));
+          put(rr, 4 * j4 + 2, __uint_as_float(v[u].z));
+          put(rr, 4 * j4 + 3, __uint_as_float(v[u].w));
+        }
+      }
+    }
+  } else {
+    constexpr int U = 16;
+    for (int base = tid; base < total; base += nthreads * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + nthreads * u;
+        int rr = i >> sh, j = i & ((1 << sh) - 1);
+        rr = rr < R ? rr : R - 1;
+        j = j < G ? j : G - 1;
+        v[u] = src[(int64_t)rr * S + j];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + nthreads * u;
+        const int rr = i >> sh, j = i & ((1 << sh) - 1);
+        if (rr < R && j < G) put(rr, j, v[u]);
+      }
+    }
+  }
+}
+__device__ __forceinline__ void lds_zero16(char* lds, int bytes, int tid, int nthreads) {   // bytes % 16 == 0
+  for (int i = tid * 16; i < bytes; i += nthreads * 16) *reinterpret_cast<float4*>(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // row of accumulator register v for lane half h (32x32 C/D layout)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 

@@ -146,3 +146,40 @@ def test_flat_adam_state_dict_layout_and_cpu_refusal():
     assert opt.bucket.check_views()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         opt.step()
+
+
+def test_trainer_checkpoint_layout_and_resume_from_reference_style_checkpoint(tmp_path):
+    """DPTrainStep writes the reference's checkpoint keys (models/basic_trainer.py:187-208) and resumes from a
+    checkpoint assembled the way the reference trainer does (model + torch.optim.Adam + MultiStepLR state dicts)."""
+    from rdst_amd.trainer import DPTrainStep
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(4, 6), nn.Linear(6, 2))
+    ref_opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.99), eps=1e-8)
+    ref_sch = torch.optim.lr_scheduler.MultiStepLR(ref_opt, milestones=[2, 4], gamma=0.5)
+    for _ in range(3):
+        ref_opt.zero_grad()
+        net(torch.randn(5, 4)).abs().mean().backward()
+        ref_opt.step()
+        ref_sch.step()
+    ref_ck = {"Time": "x", "model_g": {k: v.clone() for k, v in net.state_dict().items()}, "optimizer_g": ref_opt.state_dict(),
+              "scheduler_g": ref_sch.state_dict(), "loss": {}, "training_loss_names": ["L1"],
+              "training_loss_records": {"L1": [0.3, 0.2, 0.1]}, "quick_validation_reports": [],
+              "current_training_state_id": 0, "current_epoch": 3, "training_epoch_costs": [0.1, 0.1, 0.1]}
+    path = str(tmp_path / "checkpoint.tar")
+    torch.save(ref_ck, path)
+
+    net2 = nn.Sequential(nn.Linear(4, 6), nn.Linear(6, 2))
+    tr = DPTrainStep(net2, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, milestones=[2, 4], gamma=0.5)
+    tr.load_checkpoint(path)
+    for k, v in ref_ck["model_g"].items():
+        assert torch.equal(net2.state_dict()[k], v)
+    assert net2[0].weight.data_ptr() == tr.optimizer.flat_param.data_ptr()      # still views of the flat buffer
+    assert tr.current_epoch == 3 and tr.training_loss_records["L1"] == [0.3, 0.2, 0.1]
+    assert tr.optimizer.param_groups[0]["lr"] == ref_opt.param_groups[0]["lr"] == 1e-4 * 0.5   # past milestone 2
+    ck = tr.checkpoint()
+    assert set(ref_ck) <= set(ck)                                                # every reference key is written
+    for k in ref_opt.state_dict()["state"]:
+        assert torch.equal(ck["optimizer_g"]["state"][k]["exp_avg"], ref_opt.state_dict()["state"][k]["exp_avg"])
+    tr.save_checkpoint(str(tmp_path / "ck2.tar"))
+    back = torch.load(str(tmp_path / "ck2.tar"), weights_only=False)
+    assert back["current_epoch"] == 3 and "scheduler_g" in back
