@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
   };
   int win = blockIdx.x;
   WinPos cur = locate(win < nwin ? win : 0);
-  if (win < nwin) fetch(cur);   // in flight while the table is staged
+  fetch(cur);   // in flight while the table is staged
   // table, x-reversed: A[u] = T(dy, 14-u) so that u = xj - xi + 7 ascends with the key column;
   // B[u] = A[u+1] serves the lanes whose first u is odd with the same aligned 8-B reads.
   // Coalesced loads, all issued before the first store (one latency, not one per element).
@@ -356,11 +356,11 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
     __syncthreads();
     stamp();  // 2 + 3k: window k staged in LDS
     const WinPos w = cur;
+    // every fetch defines every staging register (past the last window it re-reads this one): a conditionally
+    // defined register stays live around the loop and costs registers / invites spills
     const int nxt = win + gridDim.x;
-    if (nxt < nwin) {
-      cur = locate(nxt);
-      fetch(cur);
-    }
+    cur = locate(nxt < nwin ? nxt : win);
+    fetch(cur);
 
     c.mrow = g.shift > 0 && w.wr == g.nWh - 1;
     c.mcol = g.shift > 0 && w.wc == g.nWw - 1;
@@ -481,7 +481,12 @@ int wattn_fwd_mfma_hd(const void* qkv, int64_t ld, const float* table, void* out
   { const char* e = getenv("RDST_K1_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const int d = g.C / 6;
   const int64_t lb = ld * 2, lob = ldo * 2;
-  if (d == 10 && aligned_to(qkv, out, lb, lob, 8)) return launch_hd<10, 6, 8, 1, 3>(p, st);
+  static int minb = -1;
+  if (minb < 0) {
+    const char* e = getenv("RDST_K1_MINB");
+    minb = e ? atoi(e) : 0;
+  }
+  if (d == 10 && aligned_to(qkv, out, lb, lob, 8)) return minb == 4 ? launch_hd<10, 6, 8, 1, 4>(p, st) : launch_hd<10, 6, 8, 1, 3>(p, st);
   if (d == 15 && aligned_to(qkv, out, lb, lob, 4)) return launch_hd<15, 6, 12, 1, 3>(p, st);
   if (d == 20 && aligned_to(qkv, out, lb, lob, 16)) return launch_hd<20, 6, 16, 1, 2>(p, st);
   return RDST_ENOTSUP;
