@@ -48,6 +48,7 @@ struct LinArgs {
   int64_t M; int Kc; int Nout; float s;
   int Tn; int ldw; int nch; int aoff;
   int dbg;   // RDST_LIN_DEBUG ablation switches: 1 skip stores, 2 skip fused-add operand loads, 4 skip the column tiles
+  unsigned long long* stamps;   // RDST_LIN_STAMPS=n (debug): [grid][16] s_memtime stamps of thread 0
 };
 
 // The accumulators are kept TRANSPOSED (D^T = W . A^T: output column n in the registers, token on the lane):
@@ -73,14 +74,21 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
   constexpr int ABUF_LD = 144;
   char* abuf = smem + p.aoff + wave * (32 * ABUF_LD);
   const bool has_ln = (MODE == MODE_FWD) && p.lnw != nullptr;
-  if (has_ln)
-    for (int i = tid; i < Tn * KP; i += 512) {
-      gam[i] = i < p.Kc ? p.lnw[i] : 0.f;
-      bet[i] = i < p.Kc ? p.lnb[i] : 0.f;
-    }
+  int nst = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+  };
+  stamp();  // 0: start
   const int npad = ((p.Nout + 31) / 32) * 32;
-  if (MODE == MODE_FWD)
-    for (int i = tid; i < npad; i += 512) biasL[i] = (p.bias && i < p.Nout) ? p.bias[i] : 0.f;
+  // The small parameter vectors are LOADED here (one value per thread: Tn*KP <= 512, npad <= 512) but written to
+  // LDS only after the weight staging has issued its loads: every dependent global-load wait in the prologue
+  // costs ~2 us of a 25-50 us kernel, so all prologue loads go out before the first wait.
+  float pre_g = 0.f, pre_b = 0.f, pre_bias = 0.f;
+  if (has_ln && tid < p.Kc) {
+    pre_g = p.lnw[tid];
+    pre_b = p.lnb[tid];
+  }
+  if (MODE == MODE_FWD && p.bias && tid < p.Nout) pre_bias = p.bias[tid];
   const int64_t nslabs = (p.M + 31) / 32;
   const float invK = 1.0f / (float)p.Kc;
 
@@ -182,14 +190,51 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
     __syncthreads();
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
-    if (MODE == MODE_FWD) {
-      stage_packs_batched<T, 12>(ncp * 2 * Tn, p.Kc, 1, tid, 512, [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
-        const int n = idx / (2 * Tn), ph = idx - n * (2 * Tn);
-        ok = n < nc;
-        k0 = ph * HP;
-        src = p.Wt + (int64_t)(n0 + n) * p.wK + k0;   // row n of W (N,K), k contiguous
-        dst = Ws + (size_t)n * p.ldw + ph * 16;
-      });
+    if (p.dbg & 16) {
+    } else if (MODE == MODE_FWD) {
+      // rows n of W (N,K), k contiguous -> packs of the LDS image.  Lean on purpose: thread -> (row, pack) by
+      // shift / mask, 4 items of a thread in flight, 16-B loads (a 12-deep batch with integer
+      // divisions and a scalar path per slot cost 5 us of instruction issue per launch, measured)
+      int shp = 0;
+      while ((1 << shp) < 2 * Tn) ++shp;
+      const int total = ncp << shp;
+      constexpr int U = 4;    // deeper batches do not help: the staging is bound by L2 bandwidth (256 workgroups each read all of W)
+      for (int base = tid; base < total; base += 512 * U) {
+        u32x4_a4 v[U][HP / 4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + 512 * u;
+          const int n = idx >> shp, ph = idx & ((1 << shp) - 1);
+          const bool ok = idx < total && n < nc && ph < 2 * Tn;
+          const float* src = p.Wt + (int64_t)(n0 + (ok ? n : 0)) * p.wK;
+#pragma unroll
+          for (int q = 0; q < HP / 4; ++q) {
+            const int kq = ph * HP + 4 * q;
+            if (ok && kq + 4 <= p.Kc) {
+              v[u][q] = *reinterpret_cast<const u32x4_a4*>(src + kq);
+            } else {
+              v[u][q].x = (ok && kq < p.Kc) ? __float_as_uint(src[kq]) : 0u;
+              v[u][q].y = (ok && kq + 1 < p.Kc) ? __float_as_uint(src[kq + 1]) : 0u;
+              v[u][q].z = (ok && kq + 2 < p.Kc) ? __float_as_uint(src[kq + 2]) : 0u;
+              v[u][q].w = 0u;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + 512 * u;
+          const int n = idx >> shp, ph = idx & ((1 << shp) - 1);
+          if (idx < total && ph < 2 * Tn) {
+            float f[HP];
+#pragma unroll
+            for (int q = 0; q < HP / 4; ++q) {
+              f[4 * q] = __uint_as_float(v[u][q].x); f[4 * q + 1] = __uint_as_float(v[u][q].y);
+              f[4 * q + 2] = __uint_as_float(v[u][q].z); f[4 * q + 3] = __uint_as_float(v[u][q].w);
+            }
+            *reinterpret_cast<Pack16*>(Ws + (size_t)n * p.ldw + ph * 16) = MM::pack(f);
+          }
+        }
+      }
     } else {
       // dgrad: output column n = K_lin index, contraction k = N_lin index: W (N_lin, K_lin) read row-wise
       // (coalesced), scattered transposed into the LDS image [n][k]
@@ -197,7 +242,12 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
       __syncthreads();
       stage_scatter<T>(p.Wt + n0, p.Kc, nc, (int64_t)p.wK, tid, 512, Ws, [&](int k, int n) { return n * p.ldw + k * (int)sizeof(T); });
     }
+    if (n0 == 0) {
+      if (has_ln && tid < Tn * KP) { gam[tid] = pre_g; bet[tid] = pre_b; }
+      if (MODE == MODE_FWD && tid < npad) biasL[tid] = pre_bias;
+    }
     __syncthreads();
+    stamp();  // 1: weights staged
     const int nct = ncp / 32;
 
     if constexpr (PFETCH) {
@@ -211,6 +261,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
       } else {
         load_chunks(a, slab);
       }
+      stamp();  // 2+: slab's fragments ready
       const int64_t row = slab * 32 + r;
       const bool valid = row < p.M;
       if (MODE == MODE_FWD) {
@@ -596,6 +647,7 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   if (nch < 32) return RDST_ENOTSUP;
   if (nch > npad) nch = npad;
   p.nch = nch;
+  if (p.Tn * MM::KP > 512 || npad > 512) return RDST_ENOTSUP;   // one parameter value per thread in the prologue
   p.aoff = (int)(((size_t)nch * p.ldw + (size_t)(2 * p.Tn * MM::KP + npad) * sizeof(float) + 15) / 16 * 16);
   const size_t smem = (size_t)p.aoff + abuf_bytes;
   if (smem > 160 * 1024) return RDST_ENOTSUP;
@@ -604,6 +656,13 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   int64_t cap = 256;  // persistent: one 8-wave workgroup per CU (the kernel's register count admits no second one)
   { const char* e = getenv("RDST_LIN_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
   if (grid > cap) grid = cap;
+  static int want_stamps = -1;
+  if (want_stamps < 0) { const char* e = getenv("RDST_LIN_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  unsigned long long* hst = nullptr;
+  if (want_stamps > 0) {
+    (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
+    (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);
+  }
 #define RDST_LIN_LAUNCH(TM)                                                                                          \
   {                                                                                                                  \
     auto kern = lin_mfma_kernel<T, TM, MODE>;                                                                        \
@@ -612,6 +671,23 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   }
   if (p.Tn <= 8) RDST_LIN_LAUNCH(8) else if (p.Tn <= 16) RDST_LIN_LAUNCH(16) else RDST_LIN_LAUNCH(32)
 #undef RDST_LIN_LAUNCH
+  if (want_stamps > 0) {
+    (void)hipStreamSynchronize(st);
+    hst = (unsigned long long*)malloc((size_t)grid * 16 * 8);
+    (void)hipMemcpy(hst, p.stamps, (size_t)grid * 16 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(p.stamps);
+    if (--want_stamps == 0) {
+      double sum[16] = {0}; int cnt[16] = {0};
+      for (int64_t w = 0; w < grid; ++w)
+        for (int k = 1; k < 16; ++k) {
+          if (!hst[w * 16 + k]) continue;
+          sum[k] += (double)(hst[w * 16 + k] - hst[w * 16 + k - 1]); cnt[k]++;
+        }
+      fprintf(stderr, "[lin stamps %s Kc=%d Nout=%d grid=%lld] mean ticks between consecutive stamps\n", what, p.Kc, p.Nout, (long long)grid);
+      for (int k = 1; k < 16; ++k) if (cnt[k]) fprintf(stderr, "  %2d: %9.0f (n=%d)\n", k, sum[k] / cnt[k], cnt[k]);
+    }
+    free(hst);
+  }
   return rdst_launch_status(what);
 }
 

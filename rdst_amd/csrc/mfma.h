@@ -111,19 +111,25 @@ __device__ __forceinline__ Pack16 pack_from_f32(const float* __restrict__ src, i
 //   element e of the pack is base[e * stride]; elements with k0 + e >= K (or !ok) are zero.
 // F: void(int idx, const float*& base, int& k0, char*& dst, bool& ok)
 template <typename T, int U, class F>
-__device__ __forceinline__ void stage_packs_batched(int total, int K, int64_t stride, int tid, int nthreads, F addr) {
+__device__ __forceinline__ void stage_packs_batched(int total, int K, int64_t stride, int tid, int nthreads, F addr, int rot = 0) {
   constexpr int HP = Mma<T>::HP;
+  // `rot` rotates the item order per workgroup: every workgroup stages the SAME parameters at the same moment, and
+  // without it all of them hit the same few L2 channels in lockstep
   for (int base_idx = tid; base_idx < total; base_idx += nthreads * U) {
     float f[U][HP];
     char* dst[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int idx = base_idx + nthreads * u;
+      int idx = base_idx + nthreads * u;
       const float* src = nullptr;
       int k0 = 0;
       bool ok = false;
       dst[u] = nullptr;
-      if (idx < total) addr(idx, src, k0, dst[u], ok);
+      if (idx < total) {
+        idx += rot;
+        if (idx >= total) idx -= total;
+        addr(idx, src, k0, dst[u], ok);
+      }
       if (ok && stride == 1 && k0 + HP <= K) {   // contiguous pack: 16-B loads (fp32 parameters are dword aligned)
 #pragma unroll
         for (int q = 0; q < HP / 4; ++q) {
