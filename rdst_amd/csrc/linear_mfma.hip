@@ -266,45 +266,97 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
       const bool valid = row < p.M;
       if (MODE == MODE_FWD) {
         if (has_ln) {
-          float sum = 0.f;
+          // LayerNorm on the fragments: the row is spread over the two lane halves.  Elements past Kc are zero in
+          // `a` (zero_tail), so the sums need no masks; the (x - mean)^2 sum is corrected for them analytically.
+          const int klast = (Tn - 1) * KP + h * HP;
+          const int npadl = klast + HP > p.Kc ? (klast + HP - p.Kc < HP ? klast + HP - p.Kc : HP) : 0;
+          if constexpr (TMAX <= 8) {
+            float f[TMAX][HP];   // unpacked once, kept across the three passes
+            float sum = 0.f;
 #pragma unroll
-          for (int t = 0; t < TMAX; ++t)
-            if (t < Tn) {
-              float f[HP];
-              MM::unpack(a[t], f);
+            for (int t = 0; t < TMAX; ++t)
+              if (t < Tn) {
+                MM::unpack(a[t], f[t]);
 #pragma unroll
-              for (int e = 0; e < HP; ++e) sum += (t * KP + h * HP + e < p.Kc) ? f[e] : 0.f;
-            }
-          sum += __shfl_xor(sum, 32, 64);
-          const float mean = sum * invK;
-          float var = 0.f;
-#pragma unroll
-          for (int t = 0; t < TMAX; ++t)
-            if (t < Tn) {
-              float f[HP];
-              MM::unpack(a[t], f);
-#pragma unroll
-              for (int e = 0; e < HP; ++e) {
-                const float d = (t * KP + h * HP + e < p.Kc) ? f[e] - mean : 0.f;
-                var = fmaf(d, d, var);
+                for (int e = 0; e < HP; ++e) sum += f[t][e];
               }
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * invK;
+            float var = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+              if (t < Tn) {
+#pragma unroll
+                for (int e = 0; e < HP; ++e) {
+                  f[t][e] -= mean;
+                  var = fmaf(f[t][e], f[t][e], var);
+                }
+              }
+            var -= (float)npadl * mean * mean;
+            var += __shfl_xor(var, 32, 64);
+            const float rstd = 1.0f / sqrtf(var * invK + kLnEps);
+            if (n0 == 0 && h == 0 && valid && p.stats) {
+              p.stats[2 * row] = mean;
+              p.stats[2 * row + 1] = rstd;
             }
-          var += __shfl_xor(var, 32, 64);
-          const float rstd = 1.0f / sqrtf(var * invK + kLnEps);
-          if (n0 == 0 && h == 0 && valid && p.stats) {
-            p.stats[2 * row] = mean;
-            p.stats[2 * row + 1] = rstd;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+              if (t < Tn) {
+                const int k0 = t * KP + h * HP;
+                float gq[HP], bq[HP];
+#pragma unroll
+                for (int q = 0; q < HP / 4; ++q) {
+                  const float4 g4 = *reinterpret_cast<const float4*>(gam + k0 + 4 * q);
+                  const float4 b4 = *reinterpret_cast<const float4*>(bet + k0 + 4 * q);
+                  gq[4 * q] = g4.x; gq[4 * q + 1] = g4.y; gq[4 * q + 2] = g4.z; gq[4 * q + 3] = g4.w;
+                  bq[4 * q] = b4.x; bq[4 * q + 1] = b4.y; bq[4 * q + 2] = b4.z; bq[4 * q + 3] = b4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < HP; ++e) f[t][e] = fmaf(f[t][e] * rstd, gq[e], bq[e]);   // gamma = beta = 0 past Kc
+                a[t] = MM::pack(f[t]);
+              }
+          } else {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+              if (t < Tn) {
+                float f[HP];
+                MM::unpack(a[t], f);
+#pragma unroll
+                for (int e = 0; e < HP; ++e) sum += f[e];
+              }
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * invK;
+            float var = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+              if (t < Tn) {
+                float f[HP];
+                MM::unpack(a[t], f);
+#pragma unroll
+                for (int e = 0; e < HP; ++e) {
+                  const float d = f[e] - mean;
+                  var = fmaf(d, d, var);
+                }
+              }
+            var -= (float)npadl * mean * mean;
+            var += __shfl_xor(var, 32, 64);
+            const float rstd = 1.0f / sqrtf(var * invK + kLnEps);
+            if (n0 == 0 && h == 0 && valid && p.stats) {
+              p.stats[2 * row] = mean;
+              p.stats[2 * row + 1] = rstd;
+            }
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+              if (t < Tn) {
+                float f[HP];
+                MM::unpack(a[t], f);
+                const int k0 = t * KP + h * HP;
+#pragma unroll
+                for (int e = 0; e < HP; ++e) f[e] = fmaf((f[e] - mean) * rstd, gam[k0 + e], bet[k0 + e]);
+                a[t] = MM::pack(f);
+              }
           }
-#pragma unroll
-          for (int t = 0; t < TMAX; ++t)
-            if (t < Tn) {
-              float f[HP];
-              MM::unpack(a[t], f);
-              const int k0 = t * KP + h * HP;
-#pragma unroll
-              for (int e = 0; e < HP; ++e) f[e] = (f[e] - mean) * rstd * gam[k0 + e] + bet[k0 + e];
-              a[t] = MM::pack(f);
-            }
         } else if (p.in_act) {
 #pragma unroll
           for (int t = 0; t < TMAX; ++t)
@@ -344,10 +396,14 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
           if (BF) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * gp + e] * p.s),
-                                                               __float_as_uint(acc[8 * gp + 4 + e] * p.s), false, false);
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * gp + e]),
+                                                               __float_as_uint(acc[8 * gp + 4 + e]), false, false);
               c8[e] = __uint_as_float(sw[0]);
               c8[4 + e] = __uint_as_float(sw[1]);
+            }
+            if (p.s != 1.0f) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) c8[e] *= p.s;
             }
             cb = n0 + ct * 32 + 8 * (2 * gp + h);
           } else {
