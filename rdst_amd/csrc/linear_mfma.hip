@@ -965,7 +965,9 @@ struct WgradArgs {
 // in LDS, and every address is a precomputed per-thread offset plus a wave-uniform base.
 // XF: transform of X while it is staged — 0 none, 1 LayerNorm, 2 GELU, 3 any other activation,
 //     4 x-hat = (x - mean) * rstd only (the affine part and d(gamma)/d(beta) are finished by the reduction)
-template <typename T, int PF, int XF>
+// SZ: staging-plan size — 0: up to 384 x 256 columns, 2 stripes in flight; 1: N <= 256, K+1 <= 128, 3 stripes;
+//     2: N <= 128, K+1 <= 128, 5 stripes (narrow layers are bound by bytes in flight, not by bandwidth)
+template <typename T, int PFX, int XF, int SZ = 0>
 __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using MM = Mma<T>;
@@ -996,18 +998,22 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
   // shifted down in registers (never reads outside the row); what is shifted in above the row's end is
   // don't-care: it only reaches accumulator rows / columns that are never stored, or is overwritten by
   // the X transform (zeros, ones column).  Rows are dword aligned (checked by the launcher).
-  constexpr int DYMAX = (24 + HP - 1) / HP, XMAX = 16 / HP;
-  int dy_row[DYMAX], x_row[XMAX];       // stripe row, -1 = slot unused
+  constexpr int DYMAX = SZ == 0 ? (24 + HP - 1) / HP : SZ == 1 ? 16 / HP : 8 / HP;
+  constexpr int XMAX = SZ == 0 ? 16 / HP : 8 / HP;
+  constexpr int PF = sizeof(T) == 2 ? (SZ == 0 ? PFX : SZ == 1 ? 3 : 5) : PFX;
+  int dy_row[DYMAX], x_row[XMAX];       // stripe row
   int dy_col[DYMAX], x_col[XMAX];       // byte offset of the 16-B load inside the global row
   int dy_sh[DYMAX], x_sh[XMAX];         // right shift in bytes after the load (0 = full pack)
   int dy_lds[DYMAX], x_lds[XMAX];       // byte offset inside the LDS tile
   int x_k0[XMAX];
 #pragma unroll
   for (int i = 0; i < DYMAX; ++i) {
-    const int idx = tid + WG_THREADS * i;
+    // a slot past the stripe's pack count repeats an earlier item (same loads, same LDS stores): no per-slot
+    // predicate survives into the loop (each one was an exec-mask region and a live SGPR pair per stripe)
+    const int idx = (tid + WG_THREADS * i) % (WG_STRIPE * npk);
     const int row = idx / npk, pk = idx - row * npk;
     int k0 = pk * HP;
-    dy_row[i] = idx < WG_STRIPE * npk ? row : -1;
+    dy_row[i] = row;
     dy_lds[i] = row * p.ldn + pk * 16;
     if (k0 >= p.N) k0 = 0;  // slot entirely past the row: any in-row pack will do (feeds unstored rows)
     dy_sh[i] = (k0 + HP > p.N) ? (k0 + HP - p.N) * ES : 0;
@@ -1015,10 +1021,10 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
   }
 #pragma unroll
   for (int i = 0; i < XMAX; ++i) {
-    const int idx = tid + WG_THREADS * i;
+    const int idx = (tid + WG_THREADS * i) % (WG_STRIPE * kpk);
     const int row = idx / kpk, pk = idx - row * kpk;
     const int k0 = pk * HP;
-    x_row[i] = idx < WG_STRIPE * kpk ? row : -1;
+    x_row[i] = row;
     x_lds[i] = WG_STRIPE * p.ldn + row * p.ldk + pk * 16;
     x_k0[i] = k0;
     const int kl = k0 < p.K ? k0 : 0;
@@ -1051,13 +1057,13 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
     const float* stb = p.stats + 2 * m0;
 #pragma unroll
     for (int i = 0; i < DYMAX; ++i)
-      if (dy_row[i] >= 0) {
+      {
         const int row = dy_row[i] < left ? dy_row[i] : left - 1;  // rows past the range: any real row (their X rows are zeroed)
         rdy[set][i] = ld16(dyb, (uint32_t)(row * (int)ldy_b + dy_col[i]));
       }
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
-      if (x_row[i] >= 0) {
+      {
         const int row = x_row[i] < left ? x_row[i] : left - 1;
         rx[set][i] = ld16(xb, (uint32_t)(row * (int)ldx_b + x_col[i]));
         if (XF == 1 || XF == 4) {
@@ -1073,14 +1079,14 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
     const int left = (int)(m_end - m0 < WG_STRIPE ? m_end - m0 : WG_STRIPE);
 #pragma unroll
     for (int i = 0; i < DYMAX; ++i)
-      if (dy_row[i] >= 0) {
+      {
         Pack16 q = rdy[set][i];
         if (dy_sh[i]) shift_pack(q, dy_sh[i]);
         *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
       }
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
-      if (x_row[i] >= 0) {
+      {
         const bool valid = x_row[i] < left;
         const int k0 = x_k0[i];
         Pack16 q = rx[set][i];
@@ -1114,9 +1120,9 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
           }
           if (!valid || k0 + HP > p.K) {
 #pragma unroll
-            for (int e = 0; e < HP; ++e) {
-              if (!valid || k0 + e > p.K) f[e] = 0.f;
-              else if (k0 + e == p.K) f[e] = 1.0f;  // ones column: dW[:, K] = sum_m dY = d(bias)
+            for (int e = 0; e < HP; ++e) {   // selects, not branches; ones column: dW[:, K] = sum_m dY = d(bias)
+              const int kk = k0 + e;
+              f[e] = !valid ? 0.f : (kk > p.K ? 0.f : (kk == p.K ? 1.0f : f[e]));
             }
           }
           q = MM::pack(f);
@@ -1399,9 +1405,12 @@ int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, co
   nwg = (M + p.rows_per_wg - 1) / p.rows_per_wg;
   constexpr int PF = sizeof(T) == 2 ? 2 : 1;  // register sets of prefetched stripes
   const int xf = lnfin ? 4 : ln_w ? 1 : in_act == RDST_ACT_GELU ? 2 : in_act ? 3 : 0;
+  // plan size: packs per stripe over 512 threads (bf16 only; the fp32 parity mode keeps the general plan)
+  const int sz = sizeof(T) != 2 ? 0 : (p.NT * 32 <= 128 && p.KT * 32 <= 128) ? 2 : (p.NT * 32 <= 256 && p.KT * 32 <= 128) ? 1 : 0;
 #define RDST_WG_LAUNCH(XF)                                                                                            \
   {                                                                                                                  \
-    auto kern = lin_wgrad_mfma_kernel<T, PF, XF>;                                                                    \
+    auto kern = sz == 2 ? lin_wgrad_mfma_kernel<T, PF, XF, 2> : sz == 1 ? lin_wgrad_mfma_kernel<T, PF, XF, 1>        \
+                                                                         : lin_wgrad_mfma_kernel<T, PF, XF, 0>;      \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WG_THREADS), smem, st, p);                                    \
   }
