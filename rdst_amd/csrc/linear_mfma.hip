@@ -91,6 +91,9 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
   if (MODE == MODE_FWD && p.bias && tid < p.Nout) pre_bias = p.bias[tid];
   const int64_t nslabs = (p.M + 31) / 32;
   const float invK = 1.0f / (float)p.Kc;
+  // 16-B row chunks need dword-aligned rows: decided once per kernel, not per store
+  auto rows_vec = [](const void* base, int64_t ld) { return (reinterpret_cast<uintptr_t>(base) & 3) == 0 && (ld * (int64_t)sizeof(T)) % 4 == 0; };
+  const bool y_vec = rows_vec(p.Y, p.ldy), r_vec = rows_vec(p.R, p.ldr), xa_vec = rows_vec(p.Xa, p.ldxa), ac_vec = rows_vec(p.Acc, p.ldacc);
 
   // Slab loads.  A lane reading 16 B of ITS OWN row (fragment shape) makes every wave instruction touch
   // 32 different rows for 32 B each: measured 0.8 TB/s.  Instead rows are read COALESCED — 8 lanes x
@@ -413,9 +416,9 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
           }
           if (!valid) continue;
           // operands of the fused adds: 8 columns as one (bf16) or two (fp32) 16-B row chunks
-          auto chunk8 = [&](const T* rowp, float (&g8)[8]) {
+          auto chunk8 = [&](const T* rowp, bool vec, float (&g8)[8]) {
             if (BF) {
-              if (cb + 8 <= p.Nout && (reinterpret_cast<uintptr_t>(rowp + cb) & 3) == 0) {
+              if (vec && cb + 8 <= p.Nout) {
                 const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb);
                 g8[0] = bf16lo(u.x); g8[1] = bf16hi(u.x); g8[2] = bf16lo(u.y); g8[3] = bf16hi(u.y);
                 g8[4] = bf16lo(u.z); g8[5] = bf16hi(u.z); g8[6] = bf16lo(u.w); g8[7] = bf16hi(u.w);
@@ -434,20 +437,20 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
           if (MODE == MODE_FWD) {
             if (p.R && !(p.dbg & 2)) {
               float g8[8];
-              chunk8(p.R + row * p.ldr, g8);
+              chunk8(p.R + row * p.ldr, r_vec, g8);
 #pragma unroll
               for (int e = 0; e < 8; ++e) c8[e] += g8[e];
             }
           } else if (!p.dA) {
             if (p.Xa && p.in_act) {
               float g8[8];
-              chunk8(p.Xa + row * p.ldxa, g8);
+              chunk8(p.Xa + row * p.ldxa, xa_vec, g8);
 #pragma unroll
               for (int e = 0; e < 8; ++e) c8[e] *= act_grad<BF>(g8[e], p.in_act);
             }
             if (p.Acc) {
               float g8[8];
-              chunk8(p.Acc + row * p.ldacc, g8);
+              chunk8(p.Acc + row * p.ldacc, ac_vec, g8);
 #pragma unroll
               for (int e = 0; e < 8; ++e) c8[e] += g8[e];
             }
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
           if (p.dbg & 1) continue;
           T* yrow = p.Y + row * p.ldy;
           if (BF) {
-            if (cb + 8 <= p.Nout && (reinterpret_cast<uintptr_t>(yrow + cb) & 3) == 0) {
+            if (y_vec && cb + 8 <= p.Nout) {
               u32x4_a4 u;
               u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
               u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
