@@ -66,9 +66,11 @@ struct BwCtx {
   lds_cp idp;     // the lane's 0/1 operand packs of the d(table) MFMA (2 x 16 B)
   const LDS_AS f32x2* tb;
   int h;
-  bool masked, mrow, mcol, fyi, fxi;
+  bool masked, mrow, mcol;
   int thr;
-  float negs, scale2, scale;
+  float scale2, scale;
+  int yi, xi;        // the lane's query row / column inside the window (key row of tile kt: 4 kt + (yi & 3))
+  uint32_t cbits;    // bf16(100 / scale)
 };
 
 // phase A of one (query tile, head): leaves P^T / dS^T packs in pP / pdS and the dQ^T tile in dq
@@ -111,15 +113,23 @@ __device__ __forceinline__ void bw_phase_a(const BwCtx& c, Pack16 (&pP)[2][2], P
       Mma<bf16>::mma(Y[kt], va, gb);   // dP^T  = V . dO^T
     }
   }
-  if (c.masked) {  // wave-uniform: only the last window row / column of a shifted block
+  if (c.masked) {
+    // shifted-window mask as one more k-step (see wattn_mfma_hd.hip): +100/scale where the regions of query and
+    // key AGREE is the reference's -100 where they differ up to a per-row constant, which softmax ignores
+    // (the one-hot packs are rebuilt here, a dozen vector instructions, instead of living in registers)
+    auto onehot = [&](int reg, uint32_t v) {   // elements 0..3 of lane half 0 (k = 0..3 of the k-step)
+      Pack16 q;
+      q.w[0] = h ? 0u : ((reg == 0 ? v : 0u) | (reg == 1 ? v << 16 : 0u));
+      q.w[1] = h ? 0u : ((reg == 2 ? v : 0u) | (reg == 3 ? v << 16 : 0u));
+      q.w[2] = 0u;
+      q.w[3] = 0u;
+      return q;
+    };
+    const int rx = (c.mcol && c.xi >= c.thr) ? 1 : 0;   // xi = lane & 7 is also the key column of row r of a key tile
+    const Pack16 mQ = onehot(2 * ((c.mrow && c.yi >= c.thr) ? 1 : 0) + rx, c.cbits);
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
-        const bool dyf = c.mrow & (c.fyi != (yj < c.thr)), dxf = c.mcol & (c.fxi != (xj < c.thr));
-        X[kt][v] += (dyf | dxf) ? c.negs : 0.f;
-      }
+      Mma<bf16>::mma(X[kt], onehot(2 * ((c.mrow && kt * 4 + (c.yi & 3) >= c.thr) ? 1 : 0) + rx, 0x3f80u), mQ);
   }
   float m = X[0][0];
 #pragma unroll
@@ -270,10 +280,10 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
     c.tb = (const LDS_AS f32x2*)tb;
   }
-  c.fyi = yi < thr;
-  c.fxi = xi < thr;
   c.thr = thr;
-  c.negs = -100.0f * rscale;
+  c.cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
+  c.yi = yi;
+  c.xi = xi;
   c.scale2 = p.scale * LOG2E;
   c.scale = p.scale;
   if (tid < 64) {  // 0/1 operand of the d(table) MFMA: A[m][8h + jj] = 1 where m is the key of pack element jj

@@ -53,9 +53,10 @@ struct HdCtx {
   lds_cp Qp, Kp, Vp, Op;         // per-lane bases into the Q / K / V sections (O overwrites Q)
   const LDS_AS f32x2* tb;        // per-lane base into the staged table (copy chosen by parity)
   int h;                         // lane half
-  bool masked, mrow, mcol, fyi, fxi;
+  bool masked, mrow, mcol;
   int thr;
-  float negs, scale2;
+  float scale2;
+  Pack16 mK[2], mQ;   // one-hot region operands of the mask k-step (rebuilt per masked window)
 };
 
 // One head of one wave: 32 queries (lane & 31) x 64 keys.
@@ -94,15 +95,13 @@ __device__ __forceinline__ void hd_head(TotT<D, HEADS>& tot, const HdCtx& c) {
       Mma<bf16>::mma(X[kt], ka, qb);
     }
   }
-  if (c.masked) {  // wave-uniform: only the last window row / column of a shifted block
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
-        const bool dyf = c.mrow & (c.fyi != (yj < c.thr)), dxf = c.mcol & (c.fxi != (xj < c.thr));
-        X[kt][v] += (dyf | dxf) ? c.negs : 0.f;
-      }
+  if (c.masked) {
+    // Shifted-window mask (wave-uniform: only the last window row / column of a shifted block) as ONE more
+    // k-step: the reference adds -100 where the regions of query and key differ; a softmax row is invariant to a
+    // constant, so +100 where they AGREE is the same thing, and [region_j == region_i] is a rank-4 product of
+    // one-hot vectors — no vector-ALU work per logit at all.
+    Mma<bf16>::mma(X[0], c.mK[0], c.mQ);
+    Mma<bf16>::mma(X[1], c.mK[1], c.mQ);
   }
   float m = X[0][0];
 #pragma unroll
@@ -264,10 +263,8 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
     const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
     c.tb = (const LDS_AS f32x2*)tb;
   }
-  c.fyi = yi < thr;
-  c.fxi = xi < thr;
   c.thr = thr;
-  c.negs = -100.0f * rscale;
+  const uint32_t cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));   // bf16(100 / scale)
   c.scale2 = p.scale * LOG2E;
 
   // Software pipeline over the workgroup's windows: the NEXT window's token rows are in flight (in
@@ -365,6 +362,18 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
     c.mrow = g.shift > 0 && w.wr == g.nWh - 1;
     c.mcol = g.shift > 0 && w.wc == g.nWw - 1;
     c.masked = __builtin_amdgcn_readfirstlane((int)(c.mrow || c.mcol)) != 0;
+    if (c.masked) {   // region id = 2 [row >= thr] + [col >= thr] (a flag only counts on the block's last window row / column)
+      auto onehot = [&](int reg, uint32_t v, Pack16& q) {   // elements 0..3 of lane half 0 (k = 0..3 of the k-step)
+        q.w[0] = h ? 0u : ((reg == 0 ? v : 0u) | (reg == 1 ? v << 16 : 0u));
+        q.w[1] = h ? 0u : ((reg == 2 ? v : 0u) | (reg == 3 ? v << 16 : 0u));
+        q.w[2] = 0u;
+        q.w[3] = 0u;
+      };
+      const int rx = (c.mcol && xi >= thr) ? 1 : 0;          // xi = r & 7 is also the key column of row r of a key tile
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) onehot(2 * ((c.mrow && kt * 4 + (r >> 3) >= thr) ? 1 : 0) + rx, 0x3f80u, c.mK[kt]);
+      onehot(2 * ((c.mrow && yi >= thr) ? 1 : 0) + rx, cbits, c.mQ);
+    }
     if (!(p.dbg & 1)) {
       if (hg == 0) hd_group<D, HEADS, 0>(c);
       else hd_group<D, HEADS, 1>(c);
