@@ -966,7 +966,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_reduce_kernel(const float* __r
   const bool is_b = (ci == ones_col && ky == g.pad && kx == g.pad);
   if (!is_w && !is_b) return;
   float a = 0.f;
-  for (int m = 0; m < nm; ++m) a += slab[(int64_t)m * per_m + i];
+  for (int m0 = 0; m0 < nm; m0 += 16) {   // 16 loads in flight, summed in the same fixed order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (m0 + u < nm) ? slab[(int64_t)(m0 + u) * per_m + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a += v[u];
+  }
   if (is_w) {
     if (dW) dW[(((int64_t)co * g.Cin + ci) * ks + ky) * ks + kx] = a * s;
   } else if (dbias) {

@@ -1245,7 +1245,13 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   const int tot = N * Kx;
   float a = 0.f;
   if (i < tot)
-    for (int w = sg; w < nwg; w += 8) a += slab[(int64_t)w * tot + i];
+    for (int w0 = sg; w0 < nwg; w0 += 8 * 8) {   // 8 loads in flight, summed in the same fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < nwg) ? slab[(int64_t)(w0 + 8 * u) * tot + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
   part[sg][o] = a;
   __syncthreads();
   if (sg != 0 || i >= tot) return;
@@ -1268,7 +1274,13 @@ __global__ void __launch_bounds__(256) wgrad_sum_kernel(const float* __restrict_
   const int i = blockIdx.x * 32 + o;
   float a = 0.f;
   if (i < tot)
-    for (int w = sg; w < nwg; w += 8) a += slab[(int64_t)w * tot + i];
+    for (int w0 = sg; w0 < nwg; w0 += 8 * 8) {   // 8 loads in flight, summed in the same fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < nwg) ? slab[(int64_t)(w0 + 8 * u) * tot + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
   part[sg][o] = a;
   __syncthreads();
   if (sg != 0 || i >= tot) return;

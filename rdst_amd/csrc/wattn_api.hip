@@ -33,7 +33,13 @@ dtable_reduce(const float* __restrict__ slab, float* __restrict__ dtable, int nw
   const int h = blockIdx.x / chunks, t = (blockIdx.x % chunks) * 64 + lane;
   float s = 0.f;
   if (t < T)
-    for (int w = grp; w < nwin; w += 16) s += slab[((int64_t)w * heads + h) * T + t];
+    for (int w0 = grp; w0 < nwin; w0 += 16 * 8) {   // 8 loads in flight, summed in the same fixed order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (w0 + 16 * u < nwin) ? slab[((int64_t)(w0 + 16 * u) * heads + h) * T + t] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
   part[grp][lane] = s;
   __syncthreads();
   if (grp == 0 && t < T) {
