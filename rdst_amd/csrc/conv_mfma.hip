@@ -543,6 +543,36 @@ __global__ void __launch_bounds__(256) unshuffle_kernel(const T* __restrict__ dY
   out[i] = dY[row * ld + c];
 }
 
+// PixelShuffle(2), bf16, even channel counts: one thread builds 8 consecutive conv channels of one input pixel
+// (channels 4c .. 4c+7 = output channels c, c+1 of the four sub-pixels) from four 4-B reads and writes them with one
+// 16-B store (the element-wise kernel above moves 2 B per load and per store).
+__global__ void __launch_bounds__(256) unshuffle2_bf16_kernel(const bf16* __restrict__ dY, int64_t ld, bf16* __restrict__ out,
+                                                              ConvGeom g) {
+  const int Co = g.Cout / 4;                       // channels of the shuffled tensor
+  const int groups = g.Cout / 8;                   // 8-channel groups per input pixel
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.pixels() * groups) return;
+  const int gi = (int)(i % groups);
+  const int64_t pix = i / groups;
+  int b, y, x;
+  g.decode(pix, b, y, x);
+  const int c0 = 2 * gi;                           // output channels c0, c0 + 1
+  uint32_t v[4];                                   // sub-pixel q = 2 i + j: {c0, c0 + 1}
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t row = ((int64_t)b * (2 * g.H) + 2 * y + (q >> 1)) * (int64_t)(2 * g.W) + 2 * x + (q & 1);
+    v[q] = *reinterpret_cast<const uint32_t*>(dY + row * ld + c0);
+  }
+  (void)Co;
+  // conv channel 4c + q: [c0: q0 q1 q2 q3][c0+1: q0 q1 q2 q3]
+  u32x4_a4 o;
+  o.x = (v[0] & 0xffffu) | (v[1] << 16);
+  o.y = (v[2] & 0xffffu) | (v[3] << 16);
+  o.z = (v[0] >> 16) | (v[1] & 0xffff0000u);
+  o.w = (v[2] >> 16) | (v[3] & 0xffff0000u);
+  *reinterpret_cast<u32x4_a4*>(out + pix * g.Cout + 8 * gi) = o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dW[co][ci][ky][kx] = s * sum_p dY[p][co] * in_act(X)[p + (ky,kx) - pad][ci]
 // ------------------------------------------------------------------------------------------------
@@ -1006,7 +1036,13 @@ const T* plain_dy(const T* dY, int64_t lddy, const ConvGeom& g, void* scratch, i
   if (g.r == 1) { ld_out = lddy; return dY; }
   T* tmp = reinterpret_cast<T*>(scratch);
   const int64_t tot = g.pixels() * g.Cout;
-  hipLaunchKernelGGL((unshuffle_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dY, lddy, tmp, g);
+  if (sizeof(T) == 2 && g.r == 2 && g.Cout % 8 == 0 && (lddy % 2) == 0 && ((uintptr_t)dY & 3) == 0) {
+    const int64_t n8 = g.pixels() * (g.Cout / 8);
+    hipLaunchKernelGGL(unshuffle2_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const bf16*)dY, lddy,
+                       (bf16*)tmp, g);
+  } else {
+    hipLaunchKernelGGL((unshuffle_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dY, lddy, tmp, g);
+  }
   rc = rdst_launch_status("unshuffle");
   ld_out = g.Cout;
   return tmp;
