@@ -16,6 +16,16 @@ import torch
 import torch.distributed as dist
 
 
+# data_ptr of a parameter -> its bucket view, while a detach_grads()/gather() bracket is open (see FlatGradBucket)
+_OFFERED: dict = {}
+
+
+def take_grad_view(param: torch.Tensor):
+    """The bucket view that should receive this parameter's gradient, or None.  Each view is handed out once per
+    backward pass (a parameter used twice gets a fresh tensor the second time and autograd accumulates)."""
+    return _OFFERED.pop(param.data_ptr(), None) if _OFFERED else None
+
+
 class FlatGradBucket:
     """Owns one contiguous fp32 buffer; ``p.grad`` of every trainable parameter is a view of it.
 
@@ -49,21 +59,33 @@ class FlatGradBucket:
         self.flat.zero_()
 
     def detach_grads(self) -> None:
-        """Forget the views: the next backward() assigns new gradient tensors instead of accumulating."""
+        """Forget the views: the next backward() assigns new gradient tensors instead of accumulating.
+        The bucket views are offered to the HIP ops as the destination of those gradients (``take_grad_view``):
+        a weight-gradient kernel then writes straight into the bucket and ``gather()`` has nothing to copy."""
+        global _OFFERED
+        offered = {}
+        off = 0
         for p in self.params:
             p.grad = None
+            offered[p.data_ptr()] = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        _OFFERED = offered
 
     def gather(self) -> None:
         """Flatten the freshly assigned gradients into the bucket (parameters the loss does not reach get
         zeros) and make ``p.grad`` the bucket views again."""
-        pieces = []
-        for p in self.params:
-            g = p.grad
-            pieces.append(torch.zeros_like(p).reshape(-1) if g is None else g.reshape(-1))
-        torch.cat(pieces, out=self.flat)
+        global _OFFERED
+        _OFFERED = {}
+        base = self.flat.data_ptr()
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            view = self.flat[off:off + p.numel()].view_as(p)
+            g = p.grad
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() != base + 4 * off:     # not written in place by the op: copy it in
+                view.copy_(g)
+            p.grad = view
             off += p.numel()
 
     def check_views(self) -> bool:

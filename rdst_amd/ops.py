@@ -80,6 +80,16 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _grad_like(param: torch.Tensor) -> torch.Tensor:
+    """Destination of a parameter gradient: the flat-bucket view when rdst_amd.dp offers one (the kernel then
+    writes straight into the all-reduce / Adam buffer), else a fresh tensor."""
+    from . import dp
+    v = dp.take_grad_view(param)
+    if v is not None and v.shape == param.shape and v.dtype == param.dtype and v.device == param.device:
+        return v
+    return torch.empty_like(param)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -212,7 +222,7 @@ class _WindowAttention(torch.autograd.Function):
         lib = _lib.load()
         dout_r, ldd = _rows(dout)
         dqkv = torch.empty(qkv.shape[:-1] + (3 * C,), dtype=qkv.dtype, device=qkv.device)
-        dtable = torch.empty_like(tab)
+        dtable = _grad_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, qkv.device)
         kt = _kernel_timer
@@ -293,6 +303,7 @@ class _LnLinear(torch.autograd.Function):
                                           _ptr(r_r), ldr, y.data_ptr(), N, _ptr(stats), M, K, N, float(out_scale),
                                           _dtype_code(x), _stream()), "rdst_ln_linear_fwd")
         ctx.save_for_backward(x_r, lw, lb, w, stats)
+        ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.meta = (M, K, N, ldx, int(in_act), float(out_scale), bias is not None, residual is not None)
         return y
 
@@ -305,10 +316,11 @@ class _LnLinear(torch.autograd.Function):
         need = ctx.needs_input_grad
         dev = x.device
         dx = torch.empty(x.shape[:-1] + (K,), dtype=x.dtype, device=dev) if need[0] else None
-        dlw = torch.empty_like(lw) if (lw is not None and need[1]) else None
-        dlb = torch.empty_like(lb) if (lb is not None and need[2]) else None
-        dw = torch.empty_like(w) if (w is not None and need[3]) else None
-        db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[4]) else None
+        dlw = _grad_like(lw) if (lw is not None and need[1]) else None
+        dlb = _grad_like(lb) if (lb is not None and need[2]) else None
+        dw = _grad_like(w) if (w is not None and need[3]) else None
+        db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(N, dtype=torch.float32, device=dev)) \
+            if (has_bias and need[4]) else None
         _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy_r, lddy, dx, K, None, 0, dw, db, dlw, dlb, M, K, N,
                          out_scale, _dtype_code(x), dev)
         dres = dy if (has_res and need[5]) else None
@@ -391,7 +403,7 @@ class _SwinBlock(torch.autograd.Function):
         dy_r, lddy = _rows(dy)
 
         def g(t, flag):
-            return torch.empty_like(t) if (t is not None and flag) else None
+            return _grad_like(t) if (t is not None and flag) else None
 
         dn1w, dn1b, dqkvw, dqkvb = g(n1w, need[1]), g(n1b, need[2]), g(qkvw, need[3]), g(qkvb, need[4])
         dprojw, dprojb = g(projw, need[6]), g(projb, need[7])
@@ -415,7 +427,7 @@ class _SwinBlock(torch.autograd.Function):
                          M, C, C, 1.0, code, dev, join=False, keep=keep)
         # window attention
         dqkv = torch.empty_like(qkv)
-        dtab = torch.empty_like(tab)
+        dtab = _grad_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, dev)
         kt = _kernel_timer
@@ -476,6 +488,7 @@ class _ConvRows(torch.autograd.Function):
         _lib.check(lib.rdst_conv_fwd(x_r.data_ptr(), ldx, int(in_act), w.data_ptr(), _ptr(b), _ptr(r_r), ldr,
                                      y.data_ptr(), cy, B, H, W, Cin, Cout, k, float(out_scale), r, _dtype_code(x),
                                      _stream()), "rdst_conv_fwd")
+        ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.save_for_backward(x_r, w)
         ctx.meta = (B, H, W, Cin, Cout, k, ldx, int(in_act), float(out_scale), r, bias is not None,
                     residual is not None)
@@ -490,8 +503,9 @@ class _ConvRows(torch.autograd.Function):
         need = ctx.needs_input_grad
         dev = x.device
         dx = torch.empty((B, H, W, Cin), dtype=x.dtype, device=dev) if need[0] else None
-        dw = torch.empty_like(w) if need[1] else None
-        db = torch.empty(Cout, dtype=torch.float32, device=dev) if (has_bias and need[2]) else None
+        dw = _grad_like(w) if need[1] else None
+        db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(Cout, dtype=torch.float32, device=dev)) \
+            if (has_bias and need[2]) else None
         nbytes = lib.rdst_conv_bwd_workspace(B, H, W, Cin, Cout, k)
         code = _dtype_code(x)
 
