@@ -162,6 +162,24 @@ class KernelTimer:
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / (reps * len(calls))
 
+    def bracket_overhead(self, which="fwd", replay_ms=None):
+        """What an event pair around ONE launch adds to its duration (ms): the same captured launches, replayed
+        eagerly with a pair around each, against their back-to-back replay average."""
+        calls = getattr(self, which + "_calls")
+        if not calls:
+            return None
+        if replay_ms is None:
+            replay_ms = self.replay(which, 1)
+        torch.cuda.synchronize()
+        pairs = []
+        for f, _keep in calls:
+            a = _event()
+            f()
+            pairs.append((a, _event()))
+        torch.cuda.synchronize()
+        single = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+        return max(0.0, single - replay_ms)
+
     @staticmethod
     def _ms(pairs):
         return [a.elapsed_time(b) for a, b, _ in pairs]
@@ -174,6 +192,8 @@ class KernelTimer:
 
 
 _kernel_timer: Optional[KernelTimer] = None
+# measurement only (bench.py): the block forward leaves K1 out, so (step with K1) - (step without) = K1's time in the step
+SKIP_K1_FOR_TIMING = False
 
 
 def set_kernel_timer(t: Optional[KernelTimer]) -> None:
@@ -376,7 +396,10 @@ class _SwinBlock(torch.autograd.Function):
         def k1():
             _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
                                           heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
-        k1()
+        if SKIP_K1_FOR_TIMING:
+            a.zero_()      # keep the data finite for the kernels behind it; a memset, not an attention
+        else:
+            k1()
         if kt is not None:
             kt.fwd.append((e0, _event(), M * 4 * C * x.element_size()))
             if kt.capture:
