@@ -108,6 +108,23 @@ int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const flo
                        size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
                        void* stream);
 
+/* ---- K7: the Mlp half of a Swin block, fused (bf16 throughput mode) ---------------------------------
+ * y = x + fc2(GELU(fc1(LayerNorm(x))))   (Mlp.forward swin_transformer_sr.py:23-29 behind norm2 and the
+ * second residual add, :272).  rdst_mlp_fused_supported() says whether the fused kernels cover (C, hid,
+ * dtype): bf16, C+1 <= 128, hid+1 <= 2*ceil32(C+1); everything else returns RDST_ENOTSUP and the caller
+ * composes the same function from rdst_ln_linear_fwd / rdst_ln_linear_bwd (K3).
+ * Backward: ONE pass over (x, dY): the hidden activations are recomputed on the matrix cores, never read.
+ *   X, stats : the block input rows (M, C) and the forward's LayerNorm statistics (M, 2) {mean, rstd}
+ *   W1 (hid, C), b1 (hid) or NULL, W2 (C, hid) : fc1 / fc2 as nn.Linear stores them (fp32)
+ *   dY (M, C) -> dX (M, C) = dY + LayerNorm'(fc1'(GELU'(fc2'(dY))));  dW1, db1, dW2, db2, dln_w, dln_b overwritten.
+ */
+int rdst_mlp_fused_supported(int C, int hid, int dtype);
+size_t rdst_mlp_bwd_workspace(int64_t M, int C, int hid);
+int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
+                 const float* W1, const float* b1, const float* W2, const void* dY, int64_t ld_dy, void* dX,
+                 int64_t ld_dx, float* dW1, float* db1, float* dW2, float* db2, float* dln_w, float* dln_b,
+                 void* workspace, size_t workspace_bytes, int64_t M, int C, int hid, int dtype, void* stream);
+
 /* ---- K4/K5/K6: k x k convolution (k = 1 or 3, stride 1, zero padding k/2) on token-major rows ----
  * Y[b,y,x,:] = ( sum_{ky,kx} in_act(X)[b,y+ky-p,x+kx-p,:] @ Wc[:, :, ky, kx]^T + bias ) * out_scale + R
  * with an optional PixelShuffle(r) folded into the store: out channel c*r*r + i*r + j of pixel (y,x)

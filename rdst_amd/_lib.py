@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librdst_hip.so")
 
 F32, BF16 = 0, 1
+EINVAL, ENOTSUP = -10001, -10002
 ACT_NONE, ACT_GELU, ACT_LEAKY02, ACT_LEAKY001 = 0, 1, 2, 3
 
 _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -24,6 +25,10 @@ SIGNATURES = {
     "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
                                 _l, _i, _i, _f, _i, _p]),
+    "rdst_mlp_fused_supported": (_i, [_i, _i, _i]),
+    "rdst_mlp_bwd_workspace": (_z, [_l, _i, _i]),
+    "rdst_mlp_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p, _z, _l, _i, _i, _i,
+                          _p]),
     "rdst_conv_fwd": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
     "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,

@@ -36,3 +36,6 @@ template <typename T>
 int linear_dgrad_ln2_mfma(const T* X, int64_t ldx, const float* stats, const float* gamma, const float* Wt, const T* dY,
                           int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, int64_t M, int K, int N, float s,
                           hipStream_t st);
+// finish of a LayerNorm-fused weight gradient from G (N, K+1) = [dY^T x-hat | colsum(dY)] (see linear_wgrad_ln_mfma)
+int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
+                           float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st);

@@ -1326,6 +1326,14 @@ __global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __re
 
 }  // namespace
 
+// launcher of the LayerNorm finish for other translation units (mlp_mfma.hip)
+int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
+                           float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 31) / 32), dim3(1024), 0, st, G, Wt, ln_w, ln_b, N, K, K + 1, s, dW, dbias,
+                     dln_w, dln_b);
+  return rdst_launch_status("wgrad_ln_finish");
+}
+
 template <typename T>
 int linear_fwd_mfma(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt,
                     const float* bias, const T* R, int64_t ldr, T* Y, int64_t ldy, float* stats, int64_t M, int K,

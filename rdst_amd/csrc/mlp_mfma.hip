@@ -1,0 +1,441 @@
+// K7: the Mlp half of a Swin block — y = x + fc2(GELU(fc1(LayerNorm(x)))) (swin_transformer_sr.py:24-27, :272) —
+// fused END TO END in the bf16 throughput mode: the backward is ONE kernel that reads x and dY and writes dX.
+//
+// Why: unfused, the Mlp backward moves 16 row-widths of HBM traffic per token (dH written and read twice, the
+// fc1 pre-activation read twice, x and dY read three times) through four kernels plus their slab reductions.
+// Fused it moves 3 (x, dY in; dX out): the hidden activations are RECOMPUTED from x on the matrix cores (cheap:
+// the kernel stays far from the MFMA roof) and live only in registers / LDS.
+//
+// One workgroup per CU, NJ = hid/32 waves; wave w owns hidden units j in [32w, 32w+32).  Per 32-token tile:
+//   stash    every thread moves one 16-B chunk of x (normalised with the forward's statistics -> x-hat) and dY
+//            into token-major LDS tiles (the next tile's chunks are already in flight in registers)
+//   phase 1  H  = x-hat (W1 gamma)^T + b1'   and   dH = dY W2     for the wave's 32 hidden units, accumulators in the
+//            NON-transposed orientation (hidden unit on the lane, tokens in the registers): after GELU / GELU'
+//            they are, as they stand, the A operands of the two weight-gradient products (contraction over tokens)
+//   phase 2  G1[j, c] += dHp^T x-hat,  dW2^T[j, c] += h^T dY    (x-hat / dY read transposed from the tiles, in the
+//            token order the accumulator registers hold); a ones column of x-hat / a ones row of h make d(bias)
+//            fall out of the same MFMAs.  The accumulators stay in registers for the whole kernel.
+//   phase 3  waves 0..C/32: dX-hat^T = (W1 gamma)^T dHp^T (contraction over all hidden units: dHp goes through a
+//            [hidden][token] LDS image, W1 gamma is read transposed from its one LDS image), LayerNorm backward
+//            with the two row sums exchanged through LDS, + dY (the residual branch), 16-B row stores.
+// The LayerNorm is handled as in linear_mfma.hip's re-cut: the kernel works on x-hat with gamma folded into W1
+// and beta into the bias; the reduction forms dW1 = gamma G + beta db^T, d(gamma), d(beta) from G.
+#include "linear.h"
+#include "mfma.h"
+#include "wattn_hd.h"
+#include <stdlib.h>
+
+namespace {
+using namespace wahd;
+using MM = Mma<bf16>;
+
+struct MlpArgs {
+  const bf16* X; int64_t ldx; const float* stats; const float* lnw; const float* lnb;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx;
+  float* slab; int64_t slab_stride;   // per-workgroup partials: G1 [hid][C+1], then dW2^T [hid+1][C]
+  int64_t M; int C; int hid; int64_t ntiles; int tiles_per_wg;
+};
+
+template <int NCT> struct MlpCfg {
+  static constexpr int NJ = 2 * NCT, NT = 64 * NJ, CP = 32 * NCT, JP = 32 * NJ;
+  static constexpr int KC = CP / 16, KJ = JP / 16, PK = CP / 8;   // PK: 16-B chunk slots per row = NT / 32
+  static constexpr int LDW = CP * 2 + 16, LDX = CP * 2 + 16, LDH = 64;
+  static constexpr int OFF_W1 = 0, OFF_XH = OFF_W1 + JP * LDW, OFF_DY = OFF_XH + 32 * LDX, OFF_DH = OFF_DY + 32 * LDX,
+                       OFF_B1 = OFF_DH + JP * LDH, OFF_SM = OFF_B1 + JP * 4, OFF_RED = OFF_SM + 32 * 4,
+                       SMEM = OFF_RED + NCT * 32 * 8;
+};
+
+__device__ __forceinline__ void unpack8(const u32x4_a4& v, float (&f)[8]) {
+  f[0] = bf16lo(v.x); f[1] = bf16hi(v.x); f[2] = bf16lo(v.y); f[3] = bf16hi(v.y);
+  f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
+}
+
+template <int NCT>
+__global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
+  using CF = MlpCfg<NCT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = CF::NT, JP = CF::JP, LDW = CF::LDW, LDX = CF::LDX, PK = CF::PK, NJ = CF::NJ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
+  const int C = p.C, hid = p.hid;
+  const int j = 32 * wave + r;   // the lane's hidden unit
+  float* b1s = reinterpret_cast<float*>(smem + CF::OFF_B1);
+  float* sm = reinterpret_cast<float*>(smem + CF::OFF_SM);
+  float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
+
+  // ---- prologue ------------------------------------------------------------------------------------
+  // W2^T tile of the wave, in registers for the whole kernel: pack t, element e = W2[16t + 8hh + e][j]
+  Pack16 w2b[CF::KC];
+  {
+    float f[CF::KC][8];
+#pragma unroll
+    for (int t = 0; t < CF::KC; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 16 * t + 8 * hh + e;
+        f[t][e] = (c < C && j < hid) ? p.W2[(int64_t)c * hid + j] : 0.f;
+      }
+#pragma unroll
+    for (int t = 0; t < CF::KC; ++t) w2b[t] = MM::pack(f[t]);
+  }
+  lds_zero16(smem + CF::OFF_W1, CF::OFF_DH - CF::OFF_W1, tid, NT);   // W1 image and both tiles: padding rows / columns
+  // W1 (hid, C) -> bf16 image of W1*gamma, and the per-pack partial dot products with beta (b1' = b1 + W1 beta)
+  const int pk = tid % PK, jr = tid / PK, c0 = 8 * pk;
+  {
+    float gq[8], bq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gq[e] = c0 + e < C ? p.lnw[c0 + e] : 0.f;
+      bq[e] = c0 + e < C ? p.lnb[c0 + e] : 0.f;
+    }
+    float w[NJ][8];
+#pragma unroll
+    for (int ps = 0; ps < NJ; ++ps) {
+      const int jj = jr + 32 * ps;
+      const bool ok = jj < hid;
+      const float* src = p.W1 + (int64_t)(ok ? jj : 0) * C + c0;
+      if (ok && c0 + 8 <= C) {
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src), b = *reinterpret_cast<const u32x4_a4*>(src + 4);
+        w[ps][0] = __uint_as_float(a.x); w[ps][1] = __uint_as_float(a.y); w[ps][2] = __uint_as_float(a.z); w[ps][3] = __uint_as_float(a.w);
+        w[ps][4] = __uint_as_float(b.x); w[ps][5] = __uint_as_float(b.y); w[ps][6] = __uint_as_float(b.z); w[ps][7] = __uint_as_float(b.w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[ps][e] = (ok && c0 + e < C) ? src[e] : 0.f;
+      }
+    }
+    __syncthreads();   // zero fill done
+    float* part = reinterpret_cast<float*>(smem + CF::OFF_DH);
+#pragma unroll
+    for (int ps = 0; ps < NJ; ++ps) {
+      const int jj = jr + 32 * ps;
+      if (jj < hid) {
+        float f[8], dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f[e] = w[ps][e] * gq[e];
+          dot = fmaf(w[ps][e], bq[e], dot);
+        }
+        *reinterpret_cast<Pack16*>(smem + CF::OFF_W1 + jj * LDW + c0 * 2) = MM::pack(f);
+        part[jj * PK + pk] = dot;
+      }
+    }
+    if (tid < 32) *reinterpret_cast<uint16_t*>(smem + CF::OFF_XH + tid * LDX + C * 2) = 0x3f80;   // ones column of x-hat
+  }
+  __syncthreads();
+  {
+    const float* part = reinterpret_cast<const float*>(smem + CF::OFF_DH);
+    for (int jj = tid; jj < JP; jj += NT) {
+      float v = 0.f;
+      if (jj < hid) {
+        v = p.b1 ? p.b1[jj] : 0.f;
+#pragma unroll
+        for (int k = 0; k < PK; ++k) v += part[jj * PK + k];
+      }
+      b1s[jj] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- the loader's plan: one 16-B chunk of one row of x and of dY per thread ---------------------------
+  const int lrow = tid / PK, lchk = tid - lrow * PK;
+  const int rowbytes = C * 2;
+  const bool lact = lchk * 16 < rowbytes;
+  int loff = lchk * 16;
+  if (loff + 16 > rowbytes) loff = rowbytes - 16;   // the row's last chunk overlaps its neighbour
+  if (!lact) loff = 0;
+  const bool laligned = (loff & 15) == 0;
+  u32x4_a4 rx, rdy;
+  float2 rst;
+  auto fetch = [&](int64_t tile) {
+    int64_t row = tile * 32 + lrow;
+    row = row < p.M ? row : p.M - 1;
+    rx = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.X + row * p.ldx) + loff);
+    rdy = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.dY + row * p.lddy) + loff);
+    rst = *reinterpret_cast<const float2*>(p.stats + 2 * row);
+  };
+  auto put16 = [&](char* dst, const Pack16& v) {
+    if (laligned) *reinterpret_cast<Pack16*>(dst) = v;
+    else {
+      uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+      d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];
+    }
+  };
+  auto stash = [&](int64_t tile) {
+    const bool valid = tile * 32 + lrow < p.M;
+    if (lact) {
+      float f[8];
+      unpack8(rx, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = valid ? (f[e] - rst.x) * rst.y : 0.f;
+      put16(smem + CF::OFF_XH + lrow * LDX + loff, MM::pack(f));
+      Pack16 d;
+      d.w[0] = valid ? rdy.x : 0u; d.w[1] = valid ? rdy.y : 0u; d.w[2] = valid ? rdy.z : 0u; d.w[3] = valid ? rdy.w : 0u;
+      put16(smem + CF::OFF_DY + lrow * LDX + loff, d);
+    }
+    if (lchk == 0) sm[lrow] = rst.y;
+  };
+
+  // ---- per-lane LDS positions (loop invariant) ------------------------------------------------------------
+  const int q = (lane & 15) >> 2, pp = lane & 3, gq1 = (lane >> 4) & 1;
+  const lds_cp xrow = (lds_cp)(smem + CF::OFF_XH + r * LDX + hh * 16);
+  const lds_cp yrow = (lds_cp)(smem + CF::OFF_DY + r * LDX + hh * 16);
+  const lds_cp wrow = (lds_cp)(smem + CF::OFF_W1 + j * LDW + hh * 16);
+  const lds_cp dhw = (lds_cp)(smem + CF::OFF_DH + j * CF::LDH + 8 * hh);
+  // transposed reads: token order of the accumulator registers (rows 4hh+q, then +8) for the weight gradients,
+  // natural k order (rows 8hh+q, then +4) for the data gradient
+  const lds_cp xtr = (lds_cp)(smem + CF::OFF_XH + (4 * hh + q) * LDX + (16 * gq1 + 4 * pp) * 2);
+  const lds_cp ytr = (lds_cp)(smem + CF::OFF_DY + (4 * hh + q) * LDX + (16 * gq1 + 4 * pp) * 2);
+  const lds_cp wtr = (lds_cp)(smem + CF::OFF_W1 + (8 * hh + q) * LDW + (16 * gq1 + 4 * pp) * 2 + wave * 64);
+  const lds_cp dtr = (lds_cp)(smem + CF::OFF_DH + (8 * hh + q) * CF::LDH + (16 * gq1 + 4 * pp) * 2);
+
+  f32x16 G1[NCT], W2g[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { G1[ct][v] = 0.f; W2g[ct][v] = 0.f; }
+
+  const int64_t t0 = (int64_t)blockIdx.x * p.tiles_per_wg;
+  const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
+  const float invC = 1.0f / (float)C;
+  if (t0 < t1) fetch(t0);
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    stash(tile);
+    fetch(tile + 1 < t1 ? tile + 1 : tile);   // every iteration defines the whole prefetch set
+    __syncthreads();   // B1: tiles staged
+    // ---- phase 1
+    Pack16 hA[2], dA[2];
+    {
+      f32x16 ah, ad;
+      const float bj = b1s[j];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { ah[v] = bj; ad[v] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < CF::KC; ++t) {
+        const Pack16 xa = lds_pack(xrow + 32 * t), wb = lds_pack(wrow + 32 * t), ya = lds_pack(yrow + 32 * t);
+        MM::mma(ah, xa, wb);        // rows (registers) = tokens, columns (lanes) = hidden units
+        MM::mma(ad, ya, w2b[t]);
+      }
+      const bool ones = j == hid;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float hv[8], dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = ah[8 * s + e];
+          float er, ex;
+          erf_as(x * 0.70710678118654752440f, er, ex);
+          const float cdf = 0.5f * (1.0f + er);
+          hv[e] = ones ? 1.0f : x * cdf;
+          dv[e] = ad[8 * s + e] * fmaf(x * 0.39894228040143267794f, ex, cdf);
+        }
+        hA[s] = MM::pack(hv);
+        dA[s] = MM::pack(dv);
+        // dHp -> [hidden][token] image: registers 8s..8s+3 are tokens 16s+4hh.., 8s+4..8s+7 tokens 16s+8+4hh..
+        u32x2_t lo, hi;
+        lo.x = dA[s].w[0]; lo.y = dA[s].w[1]; hi.x = dA[s].w[2]; hi.y = dA[s].w[3];
+        *reinterpret_cast<LDS_AS u32x2_t*>(dhw + 32 * s) = lo;
+        *reinterpret_cast<LDS_AS u32x2_t*>(dhw + 32 * s + 16) = hi;
+      }
+    }
+    __syncthreads();   // B2: dHp image complete
+    // ---- phase 2: weight gradients (contraction over the tile's 32 tokens, 2 k-steps)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const Pack16 xb = lds_tr_pack(xtr + 16 * s * LDX + ct * 64, xtr + (16 * s + 8) * LDX + ct * 64);
+        const Pack16 yb = lds_tr_pack(ytr + 16 * s * LDX + ct * 64, ytr + (16 * s + 8) * LDX + ct * 64);
+        MM::mma(G1[ct], dA[s], xb);    // rows = hidden units, columns = channels (column C = d(bias))
+        MM::mma(W2g[ct], hA[s], yb);
+      }
+    // ---- phase 3: data gradient + LayerNorm backward on waves 0..NCT-1 (channel tile = wave)
+    f32x16 dx;
+    float rstd = 0.f;
+    if (wave < NCT) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) dx[v] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < CF::KJ; ++kk) {
+        const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
+        const Pack16 db = lds_tr_pack(dtr + 16 * kk * CF::LDH, dtr + (16 * kk + 4) * CF::LDH);
+        MM::mma(dx, wa, db);   // rows = channels, columns = tokens
+      }
+      rstd = sm[r];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_XH + r * LDX) + (32 * wave + 8 * g4 + 4 * hh) * 2);
+        const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1 += dx[4 * g4 + e];
+          s2 = fmaf(dx[4 * g4 + e], xh[e], s2);
+        }
+      }
+      s1 = half_swap_sum(s1);
+      s2 = half_swap_sum(s2);
+      if (hh == 0) *reinterpret_cast<float2*>(red + (wave * 32 + r) * 2) = make_float2(s1, s2);
+    }
+    __syncthreads();   // B3: row sums exchanged
+    if (wave < NCT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NCT; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(red + (w * 32 + r) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+      s1 *= invC; s2 *= invC;
+      float o[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cb = (32 * wave + 8 * g4 + 4 * hh) * 2;
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_XH + r * LDX) + cb);
+        const u32x2_t yv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_DY + r * LDX) + cb);
+        const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
+        const float dy[4] = {bf16lo(yv.x), bf16hi(yv.x), bf16lo(yv.y), bf16hi(yv.y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * g4 + e] = fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, dy[e]);
+      }
+      const int64_t row = tile * 32 + r;
+      if (row < p.M) {
+        bf16* drow = p.dX + row * p.lddx;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float c8[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * gp + e]), __float_as_uint(o[8 * gp + 4 + e]), false, false);
+            c8[e] = __uint_as_float(sw[0]);
+            c8[4 + e] = __uint_as_float(sw[1]);
+          }
+          const int cb = 32 * wave + 8 * (2 * gp + hh);
+          if (cb + 8 <= C) {
+            u32x4_a4 u;
+            u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+            u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+            *reinterpret_cast<u32x4_a4*>(drow + cb) = u;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (cb + e < C) drow[cb + e] = __float2bfloat16(c8[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // B4: tiles free for the next stash
+  }
+  // ---- epilogue: the workgroup's partial weight gradients
+  float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
+  float* my2 = my + (int64_t)hid * (C + 1);
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int c = 32 * ct + r;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int jj = 32 * wave + acc_row(v, hh);
+      if (jj < hid && c <= C) my[(int64_t)jj * (C + 1) + c] = G1[ct][v];
+      if (jj <= hid && c < C) my2[(int64_t)jj * C + c] = W2g[ct][v];
+    }
+  }
+}
+
+// sum of the per-workgroup partials in fixed order: G (hid, C+1) for the LayerNorm finish, dW2 (C, hid), db2 (C)
+__global__ void __launch_bounds__(256) mlp_sum_kernel(const float* __restrict__ slab, int nwg, int64_t stride, int C, int hid,
+                                                      float* __restrict__ G, float* __restrict__ dW2, float* __restrict__ db2) {
+  __shared__ float part[8][33];
+  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
+  const int tot = (int)stride;
+  float a = 0.f;
+  if (i < tot)
+    for (int w0 = sg; w0 < nwg; w0 += 8 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < nwg) ? slab[(int64_t)(w0 + 8 * u) * stride + i] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += v[u];
+    }
+  part[sg][o] = a;
+  __syncthreads();
+  if (sg != 0 || i >= tot) return;
+  a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a += part[k][o];
+  const int n1 = hid * (C + 1);
+  if (i < n1) {
+    G[i] = a;
+  } else {
+    const int i2 = i - n1, jj = i2 / C, c = i2 - jj * C;
+    if (jj < hid) dW2[(int64_t)c * hid + jj] = a;
+    else db2[c] = a;
+  }
+}
+
+int mlp_nct(int C, int hid) {
+  const int nct = (C + 1 + 31) / 32;
+  if (nct < 2 || nct > 4) return 0;
+  if (hid + 1 > 64 * nct || hid < 32) return 0;
+  if ((C & 1) || C * 2 < 16) return 0;
+  return nct;
+}
+
+}  // namespace
+
+int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
+                           float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st);
+
+extern "C" int rdst_mlp_fused_supported(int C, int hid, int dtype) {
+  static int off = -1;
+  if (off < 0) {
+    const char* e = getenv("RDST_MLP_V1");
+    off = (e && e[0] == '1') ? 1 : 0;
+  }
+  return (!off && dtype == RDST_BF16 && mlp_nct(C, hid) != 0) ? 1 : 0;
+}
+
+extern "C" size_t rdst_mlp_bwd_workspace(int64_t M, int C, int hid) {
+  (void)M;
+  if (C <= 0 || hid <= 0) return 0;
+  const size_t per = (size_t)hid * (C + 1) + (size_t)(hid + 1) * C;
+  return sizeof(float) * (256 * per + (size_t)hid * (C + 1) + 64);
+}
+
+extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
+                            const float* W1, const float* b1, const float* W2, const void* dY, int64_t ld_dy, void* dX,
+                            int64_t ld_dx, float* dW1, float* db1, float* dW2, float* db2, float* dln_w, float* dln_b,
+                            void* workspace, size_t workspace_bytes, int64_t M, int C, int hid, int dtype, void* stream) {
+  if (!X || !ln_w || !ln_b || !stats || !W1 || !W2 || !dY || !dX || !dW1 || !db1 || !dW2 || !db2 || !dln_w || !dln_b || !workspace)
+    return rdst_fail(RDST_EINVAL, "rdst_mlp_bwd: null pointer");
+  if (M < 0 || C <= 0 || hid <= 0 || ld_x < C || ld_dy < C || ld_dx < C) return rdst_fail(RDST_EINVAL, "rdst_mlp_bwd: bad dimensions");
+  if (!rdst_mlp_fused_supported(C, hid, dtype)) return RDST_ENOTSUP;
+  if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || (ld_x & 1) || (ld_dy & 1) || (ld_dx & 1)) return RDST_ENOTSUP;
+  if (workspace_bytes < rdst_mlp_bwd_workspace(M, C, hid)) return rdst_fail(RDST_EINVAL, "rdst_mlp_bwd: workspace too small");
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nct = mlp_nct(C, hid);
+  MlpArgs p{};
+  p.X = (const bf16*)X; p.ldx = ld_x; p.stats = stats; p.lnw = ln_w; p.lnb = ln_b; p.W1 = W1; p.b1 = b1; p.W2 = W2;
+  p.dY = (const bf16*)dY; p.lddy = ld_dy; p.dX = (bf16*)dX; p.lddx = ld_dx;
+  p.M = M; p.C = C; p.hid = hid;
+  p.ntiles = (M + 31) / 32;
+  int64_t grid = p.ntiles < 256 ? p.ntiles : 256;
+  p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
+  grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  p.slab = (float*)workspace;
+  p.slab_stride = (int64_t)hid * (C + 1) + (int64_t)(hid + 1) * C;
+  float* G = p.slab + 256 * p.slab_stride;
+#define RDST_MLPB(NC)                                                                                                \
+  {                                                                                                                  \
+    auto kern = mlp_bwd_kernel<NC>;                                                                                  \
+    constexpr int smem = MlpCfg<NC>::SMEM;                                                                           \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * NC), smem, st, p);                                     \
+  }
+  if (nct == 2) RDST_MLPB(2) else if (nct == 3) RDST_MLPB(3) else RDST_MLPB(4)
+#undef RDST_MLPB
+  if (int rc = rdst_launch_status("mlp_bwd")) return rc;
+  const int tot = (int)p.slab_stride;
+  hipLaunchKernelGGL(mlp_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, p.slab, (int)grid, p.slab_stride, C, hid, G, dW2, db2);
+  if (int rc = rdst_launch_status("mlp_sum")) return rc;
+  return wgrad_ln_finish_launch(G, W1, ln_w, ln_b, hid, C, 1.0f, dW1, db1, dln_w, dln_b, st);
+}

@@ -99,6 +99,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 # current one, joined before the op returns (fork/join is capturable into a HIP graph).
 _side_streams: dict = {}
 TWO_STREAM_BACKWARD = os.environ.get("RDST_TWO_STREAM", "0") != "0"   # env switch: profiling with clean kernel durations
+MLP_FUSED = os.environ.get("RDST_MLP_FUSED", "1") != "0"   # K7 (fused Mlp kernels) on/off
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -436,14 +437,29 @@ class _SwinBlock(torch.autograd.Function):
         # end of this block's backward, so they overlap the whole data-gradient chain below.  Everything they
         # read (saved activations, dy, dh, dx1, dqkv, their workspaces) stays referenced until then.
         keep = []
-        # fc2 (reads h through GELU):  dh = (dy W2) * gelu'(h)
-        dh = torch.empty_like(h)
-        _linear_bwd_call(lib, h, hid, None, None, None, ACT_GELU, fc2w, dy_r, lddy, dh, hid, None, 0, dfc2w, dfc2b, None,
-                         None, M, hid, C, 1.0, code, dev, join=False, keep=keep)
-        # LN2 + fc1, plus the residual fan-out of x1:  dx1 = dy + LN2'(dh W1)
         dx1 = torch.empty_like(x1)
-        _linear_bwd_call(lib, x1, C, n2w, n2b, stats2, ACT_NONE, fc1w, dh, hid, dx1, C, dy_r, lddy, dfc1w, dfc1b, dn2w,
-                         dn2b, M, C, hid, 1.0, code, dev, join=False, keep=keep)
+        fused_mlp = (MLP_FUSED and all(t is not None for t in (dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b))
+                     and lib.rdst_mlp_fused_supported(C, hid, code))
+        if fused_mlp:
+            # K7: the whole Mlp backward in one pass over (x1, dy); the hidden activations are recomputed
+            nb = lib.rdst_mlp_bwd_workspace(M, C, hid)
+            wsp_m = _workspace(nb, dev)
+            rc = lib.rdst_mlp_bwd(x1.data_ptr(), C, n2w.data_ptr(), n2b.data_ptr(), stats2.data_ptr(), fc1w.data_ptr(),
+                                  fc1b.data_ptr(), fc2w.data_ptr(), dy_r.data_ptr(), lddy, dx1.data_ptr(), C,
+                                  dfc1w.data_ptr(), dfc1b.data_ptr(), dfc2w.data_ptr(), dfc2b.data_ptr(), dn2w.data_ptr(),
+                                  dn2b.data_ptr(), wsp_m.data_ptr(), nb, M, C, hid, code, _stream())
+            if rc == _lib.ENOTSUP:
+                fused_mlp = False
+            else:
+                _lib.check(rc, "rdst_mlp_bwd")
+        if not fused_mlp:
+            # fc2 (reads h through GELU):  dh = (dy W2) * gelu'(h)
+            dh = torch.empty_like(h)
+            _linear_bwd_call(lib, h, hid, None, None, None, ACT_GELU, fc2w, dy_r, lddy, dh, hid, None, 0, dfc2w, dfc2b,
+                             None, None, M, hid, C, 1.0, code, dev, join=False, keep=keep)
+            # LN2 + fc1, plus the residual fan-out of x1:  dx1 = dy + LN2'(dh W1)
+            _linear_bwd_call(lib, x1, C, n2w, n2b, stats2, ACT_NONE, fc1w, dh, hid, dx1, C, dy_r, lddy, dfc1w, dfc1b,
+                             dn2w, dn2b, M, C, hid, 1.0, code, dev, join=False, keep=keep)
         # proj:  da = dx1 Wp
         da = torch.empty_like(a)
         _linear_bwd_call(lib, a, C, None, None, None, ACT_NONE, projw, dx1, C, da, C, None, 0, dprojw, dprojb, None, None,
