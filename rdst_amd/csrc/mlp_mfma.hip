@@ -35,6 +35,8 @@ struct MlpArgs {
   const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx;
   float* slab; int64_t slab_stride;   // per-workgroup partials: G1 [hid][C+1], then dW2^T [hid+1][C]
   int64_t M; int C; int hid; int64_t ntiles; int tiles_per_wg;
+  int dbg;   // RDST_MLP_DEBUG ablation bits: 1 no GELU math, 2 no phase-1 MFMAs, 4 no phase 2, 8 no phase-3 MFMAs, 16 no dX stores
+  unsigned long long* stamps;   // RDST_MLP_STAMPS=n (debug): [grid][16] s_memtime stamps of thread 0
 };
 
 template <int NCT> struct MlpCfg {
@@ -51,8 +53,31 @@ __device__ __forceinline__ void unpack8(const u32x4_a4& v, float (&f)[8]) {
   f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
 }
 
-template <int NCT>
-__global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
+// GELU(erf) and its derivative for TWO elements at a time on the packed fp32 pipes (v_pk_fma_f32 / v_pk_mul_f32):
+// the kernel's phase 1 is bound by exactly this arithmetic (measured: ~100 cycles per element unpacked).
+// erf by Abramowitz & Stegun 7.1.26 as in common.h (|error| <= 1.5e-7); the coefficients carry the factor 1/2:
+//   q = (1/2) erfc(|x|/sqrt2),  cdf = x >= 0 ? 1 - q : q,  pdf*sqrt(2 pi) = ex = exp(-x^2/2)
+__device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& cdf, f32x2& ex) {
+  const f32x2 z = x * 0.70710678118654752440f;
+  f32x2 az;
+  az.x = __builtin_fabsf(z.x); az.y = __builtin_fabsf(z.y);
+  const f32x2 den = __builtin_elementwise_fma(az, (f32x2)(0.3275911f), (f32x2)(1.0f));
+  f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  f32x2 pl = __builtin_elementwise_fma(t, (f32x2)(0.5f * 1.061405429f), (f32x2)(0.5f * -1.453152027f));
+  pl = __builtin_elementwise_fma(pl, t, (f32x2)(0.5f * 1.421413741f));
+  pl = __builtin_elementwise_fma(pl, t, (f32x2)(0.5f * -0.284496736f));
+  pl = __builtin_elementwise_fma(pl, t, (f32x2)(0.5f * 0.254829592f));
+  pl = pl * t;
+  const f32x2 a2 = (z * -1.4426950408889634f) * z;
+  ex.x = __builtin_amdgcn_exp2f(a2.x); ex.y = __builtin_amdgcn_exp2f(a2.y);
+  const f32x2 qn = pl * ex, qp = (f32x2)(1.0f) - qn;
+  cdf.x = x.x >= 0.f ? qp.x : qn.x;
+  cdf.y = x.y >= 0.f ? qp.y : qn.y;
+}
+
+template <int NCT, bool SPLIT>
+__global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) {
   using CF = MlpCfg<NCT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = CF::NT, JP = CF::JP, LDW = CF::LDW, LDX = CF::LDX, PK = CF::PK, NJ = CF::NJ;
@@ -62,6 +87,11 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
   float* b1s = reinterpret_cast<float*>(smem + CF::OFF_B1);
   float* sm = reinterpret_cast<float*>(smem + CF::OFF_SM);
   float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
+  int nst = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+  };
+  stamp();   // 0: start
 
   // ---- prologue ------------------------------------------------------------------------------------
   // W2^T tile of the wave, in registers for the whole kernel: pack t, element e = W2[16t + 8hh + e][j]
@@ -72,38 +102,59 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
     for (int t = 0; t < CF::KC; ++t)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int c = 16 * t + 8 * hh + e;
-        f[t][e] = (c < C && j < hid) ? p.W2[(int64_t)c * hid + j] : 0.f;
+        const int c = 16 * t + 8 * hh + e;   // unconditional loads (clamped), zeroed afterwards: all of them in flight at once
+        f[t][e] = p.W2[(int64_t)(c < C ? c : C - 1) * hid + (j < hid ? j : hid - 1)];
       }
 #pragma unroll
-    for (int t = 0; t < CF::KC; ++t) w2b[t] = MM::pack(f[t]);
+    for (int t = 0; t < CF::KC; ++t) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[t][e] = (16 * t + 8 * hh + e < C && j < hid) ? f[t][e] : 0.f;
+      w2b[t] = MM::pack(f[t]);
+    }
   }
+  stamp();   // W2 tile loaded
   lds_zero16(smem + CF::OFF_W1, CF::OFF_DH - CF::OFF_W1, tid, NT);   // W1 image and both tiles: padding rows / columns
   // W1 (hid, C) -> bf16 image of W1*gamma, and the per-pack partial dot products with beta (b1' = b1 + W1 beta)
   const int pk = tid % PK, jr = tid / PK, c0 = 8 * pk;
   {
     float gq[8], bq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gq[e] = c0 + e < C ? p.lnw[c0 + e] : 0.f;
-      bq[e] = c0 + e < C ? p.lnb[c0 + e] : 0.f;
+    for (int e = 0; e < 8; ++e) {   // unconditional loads, masked afterwards
+      const int c = c0 + e < C ? c0 + e : C - 1;
+      gq[e] = p.lnw[c];
+      bq[e] = p.lnb[c];
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gq[e] = c0 + e < C ? gq[e] : 0.f;
+      bq[e] = c0 + e < C ? bq[e] : 0.f;
+    }
+    // every pack is read as the 8 floats at min(c0, C-8) of its row and shifted down by `sh` (zeros shifted in):
+    // no conditional loads, so all NJ passes are in flight together
+    const int cl = c0 < C - 8 ? c0 : C - 8, sh = c0 - cl;
     float w[NJ][8];
 #pragma unroll
     for (int ps = 0; ps < NJ; ++ps) {
       const int jj = jr + 32 * ps;
-      const bool ok = jj < hid;
-      const float* src = p.W1 + (int64_t)(ok ? jj : 0) * C + c0;
-      if (ok && c0 + 8 <= C) {
-        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src), b = *reinterpret_cast<const u32x4_a4*>(src + 4);
-        w[ps][0] = __uint_as_float(a.x); w[ps][1] = __uint_as_float(a.y); w[ps][2] = __uint_as_float(a.z); w[ps][3] = __uint_as_float(a.w);
-        w[ps][4] = __uint_as_float(b.x); w[ps][5] = __uint_as_float(b.y); w[ps][6] = __uint_as_float(b.z); w[ps][7] = __uint_as_float(b.w);
-      } else {
+      const float* src = p.W1 + (int64_t)(jj < hid ? jj : hid - 1) * C + cl;
+      const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src), b = *reinterpret_cast<const u32x4_a4*>(src + 4);
+      w[ps][0] = __uint_as_float(a.x); w[ps][1] = __uint_as_float(a.y); w[ps][2] = __uint_as_float(a.z); w[ps][3] = __uint_as_float(a.w);
+      w[ps][4] = __uint_as_float(b.x); w[ps][5] = __uint_as_float(b.y); w[ps][6] = __uint_as_float(b.z); w[ps][7] = __uint_as_float(b.w);
+    }
+    if (sh != 0) {   // the row's tail pack (sh = 2, 4, 6) or a pack past the row (sh = 8)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[ps][e] = (ok && c0 + e < C) ? src[e] : 0.f;
+      for (int ps = 0; ps < NJ; ++ps) {
+        float t4[8], t2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t4[e] = (sh & 4) ? (e + 4 < 8 ? w[ps][e + 4 < 8 ? e + 4 : 7] : 0.f) : w[ps][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t2[e] = (sh & 2) ? (e + 2 < 8 ? t4[e + 2 < 8 ? e + 2 : 7] : 0.f) : t4[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[ps][e] = sh >= 8 ? 0.f : t2[e];
       }
     }
     __syncthreads();   // zero fill done
+    stamp();   // W1 loads issued + zero fill
     float* part = reinterpret_cast<float*>(smem + CF::OFF_DH);
 #pragma unroll
     for (int ps = 0; ps < NJ; ++ps) {
@@ -122,6 +173,7 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
     if (tid < 32) *reinterpret_cast<uint16_t*>(smem + CF::OFF_XH + tid * LDX + C * 2) = 0x3f80;   // ones column of x-hat
   }
   __syncthreads();
+  stamp();   // W1 image written
   {
     const float* part = reinterpret_cast<const float*>(smem + CF::OFF_DH);
     for (int jj = tid; jj < JP; jj += NT) {
@@ -136,43 +188,85 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
   }
   __syncthreads();
 
-  // ---- the loader's plan: one 16-B chunk of one row of x and of dY per thread ---------------------------
-  const int lrow = tid / PK, lchk = tid - lrow * PK;
+  stamp();   // 1: prologue done
+  // ---- the loaders' plan: 16-B chunks of x and of dY, one per thread, or (SPLIT) two per thread of waves NCT..2NCT-1
+  // only.  Waves 0..NCT-1 store dX, and loads and stores share one in-order counter (vmcnt): a wave that does both
+  // waits for its stores' acknowledgements before it may touch the prefetched chunks.
+  constexpr int NU = SPLIT ? 2 : 1;
+  const bool loader = SPLIT ? wave >= NCT : true;
   const int rowbytes = C * 2;
-  const bool lact = lchk * 16 < rowbytes;
-  int loff = lchk * 16;
-  if (loff + 16 > rowbytes) loff = rowbytes - 16;   // the row's last chunk overlaps its neighbour
-  if (!lact) loff = 0;
-  const bool laligned = (loff & 15) == 0;
-  u32x4_a4 rx, rdy;
-  float2 rst;
-  auto fetch = [&](int64_t tile) {
-    int64_t row = tile * 32 + lrow;
-    row = row < p.M ? row : p.M - 1;
-    rx = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.X + row * p.ldx) + loff);
-    rdy = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.dY + row * p.lddy) + loff);
-    rst = *reinterpret_cast<const float2*>(p.stats + 2 * row);
+  int lrow[NU], loff[NU];
+  bool lact[NU], lal[NU], lfirst[NU];
+  const char* xp[NU];    // the thread's chunk in the current prefetch tile (advanced by 32 rows per tile)
+  const char* yp[NU];
+  const float* sp[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int idx = SPLIT ? (tid - 64 * NCT) + 64 * NCT * u : tid;   // 0 .. 32*PK-1
+    lrow[u] = (idx / PK) & 31;
+    const int chk = idx - (idx / PK) * PK;
+    lact[u] = loader && chk * 16 < rowbytes;
+    int o = chk * 16;
+    if (o + 16 > rowbytes) o = rowbytes - 16;   // the row's last chunk overlaps its neighbour
+    if (!lact[u]) o = 0;
+    loff[u] = o;
+    lal[u] = (o & 15) == 0;
+    lfirst[u] = lact[u] && chk == 0;
+  }
+  u32x4_a4 rx[NU], rdy[NU];
+  float2 rst[NU];
+  auto seek = [&](int64_t tile) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      int64_t row = tile * 32 + lrow[u];
+      row = row < p.M ? row : p.M - 1;
+      xp[u] = reinterpret_cast<const char*>(p.X + row * p.ldx) + loff[u];
+      yp[u] = reinterpret_cast<const char*>(p.dY + row * p.lddy) + loff[u];
+      sp[u] = p.stats + 2 * row;
+    }
   };
-  auto put16 = [&](char* dst, const Pack16& v) {
-    if (laligned) *reinterpret_cast<Pack16*>(dst) = v;
+  auto fetch = [&]() {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      rx[u] = *reinterpret_cast<const u32x4_a4*>(xp[u]);
+      rdy[u] = *reinterpret_cast<const u32x4_a4*>(yp[u]);
+      rst[u] = *reinterpret_cast<const float2*>(sp[u]);
+    }
+  };
+  const int64_t xstep = 32 * p.ldx * 2, ystep = 32 * p.lddy * 2;
+  auto advance = [&]() {   // to the next tile: plain 64-bit adds (the ragged last tile is re-sought)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      xp[u] += xstep;
+      yp[u] += ystep;
+      sp[u] += 64;
+    }
+  };
+  auto put16 = [&](char* dst, const Pack16& v, bool aligned) {
+    if (aligned) *reinterpret_cast<Pack16*>(dst) = v;
     else {
       uint32_t* d = reinterpret_cast<uint32_t*>(dst);
       d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];
     }
   };
   auto stash = [&](int64_t tile) {
-    const bool valid = tile * 32 + lrow < p.M;
-    if (lact) {
-      float f[8];
-      unpack8(rx, f);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = valid ? (f[e] - rst.x) * rst.y : 0.f;
-      put16(smem + CF::OFF_XH + lrow * LDX + loff, MM::pack(f));
-      Pack16 d;
-      d.w[0] = valid ? rdy.x : 0u; d.w[1] = valid ? rdy.y : 0u; d.w[2] = valid ? rdy.z : 0u; d.w[3] = valid ? rdy.w : 0u;
-      put16(smem + CF::OFF_DY + lrow * LDX + loff, d);
+    for (int u = 0; u < NU; ++u) {
+      const bool valid = tile * 32 + lrow[u] < p.M;
+      if (lact[u]) {
+        float f[8];
+        unpack8(rx[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = valid ? (f[e] - rst[u].x) * rst[u].y : 0.f;
+        put16(smem + CF::OFF_XH + lrow[u] * LDX + loff[u], MM::pack(f), lal[u]);
+        Pack16 d;
+        d.w[0] = valid ? rdy[u].x : 0u; d.w[1] = valid ? rdy[u].y : 0u; d.w[2] = valid ? rdy[u].z : 0u; d.w[3] = valid ? rdy[u].w : 0u;
+        put16(smem + CF::OFF_DY + lrow[u] * LDX + loff[u], d, lal[u]);
+      }
     }
-    if (lchk == 0) sm[lrow] = rst.y;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (lfirst[u]) sm[lrow[u]] = rst[u].y;
   };
 
   // ---- per-lane LDS positions (loop invariant) ------------------------------------------------------------
@@ -197,11 +291,22 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
   const int64_t t0 = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
   const float invC = 1.0f / (float)C;
-  if (t0 < t1) fetch(t0);
+  const int64_t full_tiles = p.M / 32;   // tiles below this index have 32 valid rows: their addresses are plain increments
+  if (loader && t0 < t1) {
+    seek(t0);
+    fetch();
+  }
   for (int64_t tile = t0; tile < t1; ++tile) {
-    stash(tile);
-    fetch(tile + 1 < t1 ? tile + 1 : tile);   // every iteration defines the whole prefetch set
+    if (loader) {
+      stash(tile);
+      if (tile + 1 < t1) {   // past the end the last tile is re-read: every iteration defines the whole prefetch set
+        if (tile + 1 < full_tiles) advance();
+        else seek(tile + 1);
+      }
+      fetch();
+    }
     __syncthreads();   // B1: tiles staged
+    stamp();   // 2 (+4i): staged
     // ---- phase 1
     Pack16 hA[2], dA[2];
     {
@@ -210,7 +315,7 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) { ah[v] = bj; ad[v] = 0.f; }
 #pragma unroll
-      for (int t = 0; t < CF::KC; ++t) {
+      for (int t = 0; t < ((p.dbg & 2) ? 0 : CF::KC); ++t) {
         const Pack16 xa = lds_pack(xrow + 32 * t), wb = lds_pack(wrow + 32 * t), ya = lds_pack(yrow + 32 * t);
         MM::mma(ah, xa, wb);        // rows (registers) = tokens, columns (lanes) = hidden units
         MM::mma(ad, ya, w2b[t]);
@@ -218,18 +323,18 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
       const bool ones = j == hid;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        float hv[8], dv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = ah[8 * s + e];
-          float er, ex;
-          erf_as(x * 0.70710678118654752440f, er, ex);
-          const float cdf = 0.5f * (1.0f + er);
-          hv[e] = ones ? 1.0f : x * cdf;
-          dv[e] = ad[8 * s + e] * fmaf(x * 0.39894228040143267794f, ex, cdf);
+        for (int e2 = 0; e2 < 4; ++e2) {
+          f32x2 x, g, cdf, ex;
+          x.x = ah[8 * s + 2 * e2]; x.y = ah[8 * s + 2 * e2 + 1];
+          g.x = ad[8 * s + 2 * e2]; g.y = ad[8 * s + 2 * e2 + 1];
+          if (p.dbg & 1) { cdf = x; ex = g; } else
+          gelu_pair(x, cdf, ex);
+          const f32x2 hv = x * cdf;
+          const f32x2 dv = g * __builtin_elementwise_fma(x * 0.39894228040143267794f, ex, cdf);
+          hA[s].w[e2] = ones ? 0x3f803f80u : pack_bf16x2(hv.x, hv.y);   // the ones row: d(bias) of fc2
+          dA[s].w[e2] = pack_bf16x2(dv.x, dv.y);
         }
-        hA[s] = MM::pack(hv);
-        dA[s] = MM::pack(dv);
         // dHp -> [hidden][token] image: registers 8s..8s+3 are tokens 16s+4hh.., 8s+4..8s+7 tokens 16s+8+4hh..
         u32x2_t lo, hi;
         lo.x = dA[s].w[0]; lo.y = dA[s].w[1]; hi.x = dA[s].w[2]; hi.y = dA[s].w[3];
@@ -238,7 +343,9 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
       }
     }
     __syncthreads();   // B2: dHp image complete
+    stamp();   // 3: phase 1 done
     // ---- phase 2: weight gradients (contraction over the tile's 32 tokens, 2 k-steps)
+    if (!(p.dbg & 4))
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -252,14 +359,20 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
     f32x16 dx;
     float rstd = 0.f;
     if (wave < NCT) {
+      f32x16 dx2;   // two independent accumulation chains: only one wave per SIMD is in this phase
 #pragma unroll
-      for (int v = 0; v < 16; ++v) dx[v] = 0.f;
+      for (int v = 0; v < 16; ++v) { dx[v] = 0.f; dx2[v] = 0.f; }
 #pragma unroll
-      for (int kk = 0; kk < CF::KJ; ++kk) {
+      for (int kk = 0; kk < ((p.dbg & 8) ? 0 : CF::KJ); kk += 2) {
         const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
         const Pack16 db = lds_tr_pack(dtr + 16 * kk * CF::LDH, dtr + (16 * kk + 4) * CF::LDH);
+        const Pack16 wa2 = lds_tr_pack(wtr + 16 * (kk + 1) * LDW, wtr + (16 * (kk + 1) + 4) * LDW);
+        const Pack16 db2 = lds_tr_pack(dtr + 16 * (kk + 1) * CF::LDH, dtr + (16 * (kk + 1) + 4) * CF::LDH);
         MM::mma(dx, wa, db);   // rows = channels, columns = tokens
+        MM::mma(dx2, wa2, db2);
       }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) dx[v] += dx2[v];
       rstd = sm[r];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -277,6 +390,7 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
       if (hh == 0) *reinterpret_cast<float2*>(red + (wave * 32 + r) * 2) = make_float2(s1, s2);
     }
     __syncthreads();   // B3: row sums exchanged
+    stamp();   // 4: phases 2, 3a done
     if (wave < NCT) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -297,7 +411,7 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
         for (int e = 0; e < 4; ++e) o[4 * g4 + e] = fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, dy[e]);
       }
       const int64_t row = tile * 32 + r;
-      if (row < p.M) {
+      if (row < p.M && !(p.dbg & 16)) {
         bf16* drow = p.dX + row * p.lddx;
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
@@ -323,6 +437,7 @@ __global__ void __launch_bounds__(128 * NCT) mlp_bwd_kernel(const MlpArgs p) {
       }
     }
     __syncthreads();   // B4: tiles free for the next stash
+    stamp();   // 5: stores done
   }
   // ---- epilogue: the workgroup's partial weight gradients
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
@@ -397,7 +512,7 @@ extern "C" size_t rdst_mlp_bwd_workspace(int64_t M, int C, int hid) {
   (void)M;
   if (C <= 0 || hid <= 0) return 0;
   const size_t per = (size_t)hid * (C + 1) + (size_t)(hid + 1) * C;
-  return sizeof(float) * (256 * per + (size_t)hid * (C + 1) + 64);
+  return sizeof(float) * (512 * per + (size_t)hid * (C + 1) + 64);
 }
 
 extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
@@ -418,21 +533,51 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   p.dY = (const bf16*)dY; p.lddy = ld_dy; p.dX = (bf16*)dX; p.lddx = ld_dx;
   p.M = M; p.C = C; p.hid = hid;
   p.ntiles = (M + 31) / 32;
-  int64_t grid = p.ntiles < 256 ? p.ntiles : 256;
+  // narrow layers (4 waves, <= 256 registers in total per SIMD lane pair, 37 KB of LDS) run TWO workgroups per CU: one
+  // wave per SIMD hides no latency, and two independent workgroups overlap each other's phases
+  int64_t cap = nct == 2 ? 512 : 256;
+  { const char* e = getenv("RDST_MLP_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
+  int64_t grid = p.ntiles < cap ? p.ntiles : cap;
   p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
   grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   p.slab = (float*)workspace;
   p.slab_stride = (int64_t)hid * (C + 1) + (int64_t)(hid + 1) * C;
-  float* G = p.slab + 256 * p.slab_stride;
+  float* G = p.slab + 512 * p.slab_stride;
 #define RDST_MLPB(NC)                                                                                                \
   {                                                                                                                  \
-    auto kern = mlp_bwd_kernel<NC>;                                                                                  \
+    auto kern = split ? mlp_bwd_kernel<NC, true> : mlp_bwd_kernel<NC, false>;                                                                                \
     constexpr int smem = MlpCfg<NC>::SMEM;                                                                           \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * NC), smem, st, p);                                     \
   }
+  static int split = -1;
+  if (split < 0) { const char* e = getenv("RDST_MLP_SPLIT"); split = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = getenv("RDST_MLP_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  static int want_stamps = -1;
+  if (want_stamps < 0) { const char* e = getenv("RDST_MLP_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps > 0) {
+    (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
+    (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);
+  }
   if (nct == 2) RDST_MLPB(2) else if (nct == 3) RDST_MLPB(3) else RDST_MLPB(4)
 #undef RDST_MLPB
+  if (want_stamps > 0) {
+    (void)hipStreamSynchronize(st);
+    unsigned long long* hst = (unsigned long long*)malloc((size_t)grid * 16 * 8);
+    (void)hipMemcpy(hst, p.stamps, (size_t)grid * 16 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(p.stamps);
+    if (--want_stamps == 0) {
+      double sum[16] = {0}; int cnt[16] = {0};
+      for (int64_t w = 0; w < grid; ++w)
+        for (int k = 1; k < 16; ++k) {
+          if (!hst[w * 16 + k]) continue;
+          sum[k] += (double)(hst[w * 16 + k] - hst[w * 16 + k - 1]); cnt[k]++;
+        }
+      fprintf(stderr, "[mlp_bwd stamps C=%d hid=%d grid=%lld] mean ticks between consecutive stamps\n", C, hid, (long long)grid);
+      for (int k = 1; k < 16; ++k) if (cnt[k]) fprintf(stderr, "  %2d: %9.0f (n=%d)\n", k, sum[k] / cnt[k], cnt[k]);
+    }
+    free(hst);
+  }
   if (int rc = rdst_launch_status("mlp_bwd")) return rc;
   const int tot = (int)p.slab_stride;
   hipLaunchKernelGGL(mlp_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, p.slab, (int)grid, p.slab_stride, C, hid, G, dW2, db2);
