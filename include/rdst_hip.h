@@ -119,6 +119,11 @@ int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const flo
  *   dY (M, C) -> dX (M, C) = dY + LayerNorm'(fc1'(GELU'(fc2'(dY))));  dW1, db1, dW2, db2, dln_w, dln_b overwritten.
  */
 int rdst_mlp_fused_supported(int C, int hid, int dtype);
+/* Forward: Y (M, C) = X + fc2(GELU(fc1(LayerNorm(X)))) in one pass; the hidden activations never reach HBM and
+ * nothing but `stats` (M, 2) {mean, rstd} is kept for the backward.  b1 / b2 may be NULL.  Y may not alias X. */
+int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* W1,
+                 const float* b1, const float* W2, const float* b2, void* Y, int64_t ld_y, float* stats,
+                 int64_t M, int C, int hid, int dtype, void* stream);
 size_t rdst_mlp_bwd_workspace(int64_t M, int C, int hid);
 int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
                  const float* W1, const float* b1, const float* W2, const void* dY, int64_t ld_dy, void* dX,

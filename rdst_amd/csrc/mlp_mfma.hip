@@ -454,6 +454,365 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward: y = x + fc2(GELU(fc1(LayerNorm(x)))) in one pass, the hidden activations never leave the CU.
+// Same workgroup shape as the backward (wave w = hidden units 32w..32w+31, one 32-token tile per step), but in the
+// TRANSPOSED orientation (token on the lane, hidden unit / channel in the registers): a lane then needs the
+// LayerNorm statistics of its own token only, and the outputs leave as 16-B row stores.
+//   stash    raw x chunks -> token-major LDS tile, plus per-chunk (sum, M2) partials of the row statistics
+//   phase 1  H^T = (W1 gamma) x^T on the RAW rows; the lane combines its token's partials into (mean, rstd) while
+//            the MFMAs run, then h = GELU(rstd (H - mean S) + b1'), S[j] = sum_c (W1 gamma)[j][c]   -> bf16 tile [token][hidden]
+//   phase 2  waves 0..C/32: Y^T = W2 h^T + b2 + x (contraction over all hidden units from the LDS tile)
+// The statistics (mean, rstd) are written out for the backward.
+template <int NCT> struct MlpFwdCfg {
+  static constexpr int NJ = 2 * NCT, NT = 64 * NJ, CP = 32 * NCT, JP = 32 * NJ;
+  static constexpr int KC = CP / 16, KJ = JP / 16, PK = CP / 8;
+  static constexpr int LDW = CP * 2 + 16, LDX = CP * 2 + 16, LD2 = JP * 2 + 16;
+  // the W1 image holds `hid` rows and the W2 image `C` rows: the MFMAs of the last tiles read on into the next
+  // region, which always holds finite bf16 data, and what they produce there meets zero weights or is not stored
+  static constexpr int off_w2(int hid) { return hid * LDW; }
+  static constexpr int off_x(int hid, int C) { return off_w2(hid) + C * LD2; }
+  static constexpr int off_h(int hid, int C) { return off_x(hid, C) + 32 * LDX; }
+  static constexpr int off_pst(int hid, int C) { return off_h(hid, C) + 32 * LD2; }
+  static constexpr int off_s(int hid, int C) { return off_pst(hid, C) + 32 * 16 * 8; }
+  static constexpr int smem(int hid, int C) { return off_s(hid, C) + 2 * JP * 4 + CP * 4; }
+};
+
+struct MlpFwdArgs {
+  const bf16* X; int64_t ldx; const float* lnw; const float* lnb;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  bf16* Y; int64_t ldy; float* stats;
+  int64_t M; int C; int hid; int64_t ntiles; int tiles_per_wg;
+  int dbg;
+  unsigned long long* stamps;   // RDST_MLPF_STAMPS=n (debug)
+};
+
+template <int NCT>
+__global__ void __launch_bounds__(128 * NCT, 2) mlp_fwd_kernel(const MlpFwdArgs p) {
+  using CF = MlpFwdCfg<NCT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = CF::NT, JP = CF::JP, CP = CF::CP, LDW = CF::LDW, LDX = CF::LDX, LD2 = CF::LD2, PK = CF::PK, NJ = CF::NJ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
+  const int C = p.C, hid = p.hid;
+  const int OFF_W2 = CF::off_w2(hid), OFF_X = CF::off_x(hid, C), OFF_H = CF::off_h(hid, C), OFF_PST = CF::off_pst(hid, C),
+            OFF_S = CF::off_s(hid, C);
+  float* Ss = reinterpret_cast<float*>(smem + OFF_S);   // [JP] column sums of the bf16 W1*gamma image
+  float* b1s = Ss + JP;                                  // [JP] b1 + W1 beta
+  float* b2s = b1s + JP;                                 // [CP]
+  float2* pst = reinterpret_cast<float2*>(smem + OFF_PST);   // [32 rows][16] (sum, M2) of each 16-B chunk
+  int nst = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+  };
+  stamp();
+
+  // ---- prologue: both weight images ----
+  lds_zero16(smem, OFF_H, tid, NT);   // W1, W2 images and the x tile: padding columns
+  const int pk = tid % PK, jr = tid / PK, c0 = 8 * pk;
+  {
+    float gq[8], bq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e < C ? c0 + e : C - 1;
+      gq[e] = p.lnw[c];
+      bq[e] = p.lnb[c];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gq[e] = c0 + e < C ? gq[e] : 0.f;
+      bq[e] = c0 + e < C ? bq[e] : 0.f;
+    }
+    const int cl = c0 < C - 8 ? c0 : C - 8, sh = c0 - cl;
+    float w[NJ][8];
+#pragma unroll
+    for (int ps = 0; ps < NJ; ++ps) {
+      const int jj = jr + 32 * ps;
+      const float* src = p.W1 + (int64_t)(jj < hid ? jj : hid - 1) * C + cl;
+      const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src), b = *reinterpret_cast<const u32x4_a4*>(src + 4);
+      w[ps][0] = __uint_as_float(a.x); w[ps][1] = __uint_as_float(a.y); w[ps][2] = __uint_as_float(a.z); w[ps][3] = __uint_as_float(a.w);
+      w[ps][4] = __uint_as_float(b.x); w[ps][5] = __uint_as_float(b.y); w[ps][6] = __uint_as_float(b.z); w[ps][7] = __uint_as_float(b.w);
+    }
+    if (sh != 0) {
+#pragma unroll
+      for (int ps = 0; ps < NJ; ++ps) {
+        float t4[8], t2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t4[e] = (sh & 4) ? (e + 4 < 8 ? w[ps][e + 4 < 8 ? e + 4 : 7] : 0.f) : w[ps][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t2[e] = (sh & 2) ? (e + 2 < 8 ? t4[e + 2 < 8 ? e + 2 : 7] : 0.f) : t4[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[ps][e] = sh >= 8 ? 0.f : t2[e];
+      }
+    }
+    __syncthreads();   // zero fill done
+    stamp();   // 1: W1 loads arrived
+    // scratch for the per-pack partial dot products with beta: the h tile is free until the first phase 1
+    float* part = reinterpret_cast<float*>(smem + OFF_H);
+#pragma unroll
+    for (int ps = 0; ps < NJ; ++ps) {
+      const int jj = jr + 32 * ps;
+      if (jj < hid) {
+        float f[8], dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f[e] = w[ps][e] * gq[e];
+          dot = fmaf(w[ps][e], bq[e], dot);
+        }
+        *reinterpret_cast<Pack16*>(smem + jj * LDW + c0 * 2) = MM::pack(f);
+        part[jj * PK + pk] = dot;
+      }
+    }
+    stamp();   // 2: W1 image written
+    // W2 (C, hid) -> bf16 image [c][hid]: thread -> (row, pack of 8) by flat index, 16-B loads where the pack is whole
+    const int P2 = (hid + 7) >> 3;   // packs per row
+    for (int base = tid; base < C * P2; base += NT * 4) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int idx = base + NT * u;
+        idx = idx < C * P2 ? idx : C * P2 - 1;
+        const int c = idx / P2, pq = idx - c * P2;
+        const int k0 = 8 * pq < hid - 8 ? 8 * pq : hid - 8;   // the row's tail pack: its last 8 floats, shifted below
+        const float* src = p.W2 + (int64_t)c * hid + k0;
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src), b = *reinterpret_cast<const u32x4_a4*>(src + 4);
+        v[u][0] = __uint_as_float(a.x); v[u][1] = __uint_as_float(a.y); v[u][2] = __uint_as_float(a.z); v[u][3] = __uint_as_float(a.w);
+        v[u][4] = __uint_as_float(b.x); v[u][5] = __uint_as_float(b.y); v[u][6] = __uint_as_float(b.z); v[u][7] = __uint_as_float(b.w);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + NT * u;
+        if (idx < C * P2) {
+          const int c = idx / P2, pq = idx - c * P2;
+          const int k0 = 8 * pq < hid - 8 ? 8 * pq : hid - 8, s2 = 8 * pq - k0;
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x = (k == e + s2) ? v[u][k] : x;
+            f[e] = x;
+          }
+          *reinterpret_cast<Pack16*>(smem + OFF_W2 + c * LD2 + pq * 16) = MM::pack(f);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  stamp();   // 3: W2 image written
+  {
+    const float* part = reinterpret_cast<const float*>(smem + OFF_H);
+    for (int jj = tid; jj < JP; jj += NT) {
+      float v = 0.f, sv = 0.f;
+      if (jj < hid) {
+        v = p.b1 ? p.b1[jj] : 0.f;
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+          v += part[jj * PK + k];
+          // the row sums are those of the ROUNDED weights the MFMAs will see: read back from the image
+          float fr[8];
+          MM::unpack(*reinterpret_cast<const Pack16*>(smem + jj * LDW + k * 16), fr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sv += fr[e];
+        }
+      }
+      b1s[jj] = v;
+      Ss[jj] = sv;
+    }
+    for (int c = tid; c < CP; c += NT) b2s[c] = (c < C && p.b2) ? p.b2[c] : 0.f;
+  }
+  __syncthreads();
+
+  stamp();   // 4: prologue done
+  // ---- loader plan: one 16-B chunk of one row of x per thread ----
+  const int lrow = tid / PK, lchk = tid - lrow * PK;
+  const int rowbytes = C * 2;
+  const int nchunk = (rowbytes + 15) >> 4;
+  const bool lact = lchk < nchunk;
+  int loff = lchk * 16;
+  if (loff + 16 > rowbytes) loff = rowbytes - 16;
+  if (!lact) loff = 0;
+  const bool lal = (loff & 15) == 0;
+  const int lskip = lact ? 8 * lchk - (loff >> 1) : 0;   // leading elements of the (overlapping) last chunk that belong to its neighbour
+  const float linv = 1.0f / (float)(8 - lskip);
+  u32x4_a4 rx;
+  const char* xp = nullptr;
+  auto seek = [&](int64_t tile) {
+    int64_t row = tile * 32 + lrow;
+    row = row < p.M ? row : p.M - 1;
+    xp = reinterpret_cast<const char*>(p.X + row * p.ldx) + loff;
+  };
+  const int64_t xstep = 32 * p.ldx * 2;
+  auto stash = [&]() {
+    if (lact) {
+      Pack16 v;
+      v.w[0] = rx.x; v.w[1] = rx.y; v.w[2] = rx.z; v.w[3] = rx.w;
+      char* dst = smem + OFF_X + lrow * LDX + loff;
+      if (lal) *reinterpret_cast<Pack16*>(dst) = v;
+      else {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];
+      }
+      float f[8];
+      unpack8(rx, f);
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += e >= lskip ? f[e] : 0.f;
+      const float mi = sum * linv;
+      float m2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = e >= lskip ? f[e] - mi : 0.f;
+        m2 = fmaf(d, d, m2);
+      }
+      pst[lchk * 32 + lrow] = make_float2(sum, m2);   // [chunk][row]: the readers' lanes are consecutive rows
+    }
+  };
+
+  const int j0 = 32 * wave;
+  const lds_cp xrow = (lds_cp)(smem + OFF_X + r * LDX + hh * 16);
+  const lds_cp wrow = (lds_cp)(smem + (j0 + r) * LDW + hh * 16);
+  const lds_cp hwr = (lds_cp)(smem + OFF_H + r * LD2 + (j0 + 4 * hh) * 2);
+  const lds_cp hrd = (lds_cp)(smem + OFF_H + r * LD2 + hh * 16);
+  const lds_cp w2row = (lds_cp)(smem + OFF_W2 + (j0 + r) * LD2 + hh * 16);   // wave < NCT: channel tile = wave
+  // loop invariants of the lane: S, b1' of its 16 hidden units, b2 of its 16 channels (register v <-> unit j0 + acc_row(v, hh))
+  float Sr[16], B1r[16], B2r[16];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const float4 s4 = *reinterpret_cast<const float4*>(Ss + j0 + 8 * g4 + 4 * hh);
+    const float4 b4 = *reinterpret_cast<const float4*>(b1s + j0 + 8 * g4 + 4 * hh);
+    const float4 c4 = *reinterpret_cast<const float4*>(b2s + (wave < NCT ? j0 : 0) + 8 * g4 + 4 * hh);
+    Sr[4 * g4] = s4.x; Sr[4 * g4 + 1] = s4.y; Sr[4 * g4 + 2] = s4.z; Sr[4 * g4 + 3] = s4.w;
+    B1r[4 * g4] = b4.x; B1r[4 * g4 + 1] = b4.y; B1r[4 * g4 + 2] = b4.z; B1r[4 * g4 + 3] = b4.w;
+    B2r[4 * g4] = c4.x; B2r[4 * g4 + 1] = c4.y; B2r[4 * g4 + 2] = c4.z; B2r[4 * g4 + 3] = c4.w;
+  }
+  const int64_t t0 = (int64_t)blockIdx.x * p.tiles_per_wg;
+  const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
+  const int64_t full_tiles = p.M / 32;
+  const float invC = 1.0f / (float)C;
+  const int nlast = C - 8 * (nchunk - 1);   // elements the row's last chunk contributes
+  const float inv_nlast = 1.0f / (float)nlast;
+  if (t0 < t1) {
+    seek(t0);
+    rx = *reinterpret_cast<const u32x4_a4*>(xp);
+  }
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    stash();
+    if (tile + 1 < t1) {
+      if (tile + 1 < full_tiles) xp += xstep;
+      else seek(tile + 1);
+    }
+    rx = *reinterpret_cast<const u32x4_a4*>(xp);
+    __syncthreads();   // B1: raw tile + partials staged
+    stamp();
+    // ---- phase 1
+    {
+      f32x16 ah, ah2;   // two accumulation chains
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { ah[v] = 0.f; ah2[v] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < CF::KC; t += 2) {
+        const Pack16 wa = lds_pack(wrow + 32 * t), xb = lds_pack(xrow + 32 * t);
+        const Pack16 wa2 = lds_pack(wrow + 32 * (t + 1)), xb2 = lds_pack(xrow + 32 * (t + 1));
+        MM::mma(ah, wa, xb);   // rows (registers) = hidden units, columns (lanes) = tokens
+        MM::mma(ah2, wa2, xb2);
+      }
+      // the lane's token: combine the chunk partials (Chan's formula) while the MFMAs run; each lane half takes
+      // every other chunk, the halves are added by a swap
+      float2 q2[PK / 2];
+#pragma unroll
+      for (int k = 0; k < PK / 2; ++k) q2[k] = pst[(2 * k + hh) * 32 + r];
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < PK / 2; ++k) sum += 2 * k + hh < nchunk ? q2[k].x : 0.f;
+      sum = half_swap_sum(sum);
+      const float mean = sum * invC;
+      float m2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < PK / 2; ++k) {
+        const int kc = 2 * k + hh;
+        const bool last = kc == nchunk - 1;
+        const float d = q2[k].x * (last ? inv_nlast : 0.125f) - mean;
+        m2 += kc < nchunk ? fmaf((last ? (float)nlast : 8.0f) * d, d, q2[k].y) : 0.f;
+      }
+      m2 = half_swap_sum(m2);
+#pragma unroll
+      for (int v = 0; v < 16; ++v) ah[v] += ah2[v];
+      const float rstd = 1.0f / sqrtf(m2 * invC + 1e-5f);
+      const int64_t row = tile * 32 + r;
+      if (wave == 0 && hh == 0 && row < p.M) *reinterpret_cast<float2*>(p.stats + 2 * row) = make_float2(mean, rstd);
+      const float nm = -mean * rstd;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float sq[4] = {Sr[4 * g4], Sr[4 * g4 + 1], Sr[4 * g4 + 2], Sr[4 * g4 + 3]};
+        const float bq[4] = {B1r[4 * g4], B1r[4 * g4 + 1], B1r[4 * g4 + 2], B1r[4 * g4 + 3]};
+        float hv[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+          f32x2 x, cdf, ex;
+          x.x = fmaf(ah[4 * g4 + 2 * e2], rstd, fmaf(nm, sq[2 * e2], bq[2 * e2]));
+          x.y = fmaf(ah[4 * g4 + 2 * e2 + 1], rstd, fmaf(nm, sq[2 * e2 + 1], bq[2 * e2 + 1]));
+          gelu_pair(x, cdf, ex);
+          hv[2 * e2] = x.x * cdf.x;
+          hv[2 * e2 + 1] = x.y * cdf.y;
+        }
+        u32x2_t w2;
+        w2.x = pack_bf16x2(hv[0], hv[1]); w2.y = pack_bf16x2(hv[2], hv[3]);
+        *reinterpret_cast<LDS_AS u32x2_t*>(hwr + 16 * g4) = w2;
+      }
+    }
+    __syncthreads();   // B2: h tile complete
+    stamp();
+    // ---- phase 2: waves 0..NCT-1 (channel tile = wave)
+    if (wave < NCT) {
+      f32x16 y0, y1;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { y0[v] = B2r[v]; y1[v] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < CF::KJ; kk += 2) {
+        const Pack16 wa = lds_pack(w2row + 32 * kk), hb = lds_pack(hrd + 32 * kk);
+        const Pack16 wa2 = lds_pack(w2row + 32 * (kk + 1)), hb2 = lds_pack(hrd + 32 * (kk + 1));
+        MM::mma(y0, wa, hb);   // rows = channels, columns = tokens
+        MM::mma(y1, wa2, hb2);
+      }
+      float o[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + OFF_X + r * LDX) + (j0 + 8 * g4 + 4 * hh) * 2);
+        const float xr[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * g4 + e] = y0[4 * g4 + e] + y1[4 * g4 + e] + xr[e];
+      }
+      const int64_t row = tile * 32 + r;
+      if (row < p.M) {
+        bf16* yrow = p.Y + row * p.ldy;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float c8[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * gp + e]), __float_as_uint(o[8 * gp + 4 + e]), false, false);
+            c8[e] = __uint_as_float(sw[0]);
+            c8[4 + e] = __uint_as_float(sw[1]);
+          }
+          const int cb = j0 + 8 * (2 * gp + hh);
+          if (cb + 8 <= C) {
+            u32x4_a4 u;
+            u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+            u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+            *reinterpret_cast<u32x4_a4*>(yrow + cb) = u;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (cb + e < C) yrow[cb + e] = __float2bfloat16(c8[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // B3: tiles free for the next stash
+    stamp();
+  }
+}
+
 // sum of the per-workgroup partials in fixed order: G (hid, C+1) for the LayerNorm finish, dW2 (C, hid), db2 (C)
 __global__ void __launch_bounds__(256) mlp_sum_kernel(const float* __restrict__ slab, int nwg, int64_t stride, int C, int hid,
                                                       float* __restrict__ G, float* __restrict__ dW2, float* __restrict__ db2) {
@@ -491,6 +850,9 @@ int mlp_nct(int C, int hid) {
   if (nct < 2 || nct > 4) return 0;
   if (hid + 1 > 64 * nct || hid < 32) return 0;
   if ((C & 1) || C * 2 < 16) return 0;
+  // the forward keeps both weight images in LDS
+  const int fs = nct == 2 ? MlpFwdCfg<2>::smem(hid, C) : nct == 3 ? MlpFwdCfg<3>::smem(hid, C) : MlpFwdCfg<4>::smem(hid, C);
+  if (fs > 160 * 1024) return 0;
   return nct;
 }
 
@@ -583,4 +945,60 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   hipLaunchKernelGGL(mlp_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, p.slab, (int)grid, p.slab_stride, C, hid, G, dW2, db2);
   if (int rc = rdst_launch_status("mlp_sum")) return rc;
   return wgrad_ln_finish_launch(G, W1, ln_w, ln_b, hid, C, 1.0f, dW1, db1, dln_w, dln_b, st);
+}
+
+extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* W1, const float* b1,
+                            const float* W2, const float* b2, void* Y, int64_t ld_y, float* stats, int64_t M, int C, int hid,
+                            int dtype, void* stream) {
+  if (!X || !ln_w || !ln_b || !W1 || !W2 || !Y || !stats) return rdst_fail(RDST_EINVAL, "rdst_mlp_fwd: null pointer");
+  if (M < 0 || C <= 0 || hid <= 0 || ld_x < C || ld_y < C) return rdst_fail(RDST_EINVAL, "rdst_mlp_fwd: bad dimensions");
+  if (!rdst_mlp_fused_supported(C, hid, dtype)) return RDST_ENOTSUP;
+  if (((uintptr_t)X & 3) || ((uintptr_t)Y & 3) || (ld_x & 1) || (ld_y & 1) || hid < 8) return RDST_ENOTSUP;
+  if (M == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int nct = mlp_nct(C, hid);
+  MlpFwdArgs p{};
+  p.X = (const bf16*)X; p.ldx = ld_x; p.lnw = ln_w; p.lnb = ln_b; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2;
+  p.Y = (bf16*)Y; p.ldy = ld_y; p.stats = stats; p.M = M; p.C = C; p.hid = hid;
+  p.ntiles = (M + 31) / 32;
+  int64_t cap = nct == 2 ? 512 : 256;   // the narrow layers fit two workgroups per CU (see rdst_mlp_bwd)
+  { const char* e = getenv("RDST_MLP_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
+  int64_t grid = p.ntiles < cap ? p.ntiles : cap;
+  p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
+  grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+#define RDST_MLPF(NC)                                                                                                \
+  {                                                                                                                  \
+    auto kern = mlp_fwd_kernel<NC>;                                                                                  \
+    const int smem = MlpFwdCfg<NC>::smem(hid, C);                                                                    \
+    if (smem > 160 * 1024) return RDST_ENOTSUP;                                                                      \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * NC), smem, st, p);                                     \
+  }
+  { const char* e = getenv("RDST_MLP_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  static int want_stamps = -1;
+  if (want_stamps < 0) { const char* e = getenv("RDST_MLPF_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps > 0) {
+    (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
+    (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);
+  }
+  if (nct == 2) RDST_MLPF(2) else if (nct == 3) RDST_MLPF(3) else RDST_MLPF(4)
+#undef RDST_MLPF
+  if (want_stamps > 0) {
+    (void)hipStreamSynchronize(st);
+    unsigned long long* hst = (unsigned long long*)malloc((size_t)grid * 16 * 8);
+    (void)hipMemcpy(hst, p.stamps, (size_t)grid * 16 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(p.stamps);
+    if (--want_stamps == 0) {
+      double sum[16] = {0}; int cnt[16] = {0};
+      for (int64_t w = 0; w < grid; ++w)
+        for (int k = 1; k < 16; ++k) {
+          if (!hst[w * 16 + k]) continue;
+          sum[k] += (double)(hst[w * 16 + k] - hst[w * 16 + k - 1]); cnt[k]++;
+        }
+      fprintf(stderr, "[mlp_fwd stamps C=%d hid=%d grid=%lld] mean ticks between consecutive stamps\n", C, hid, (long long)grid);
+      for (int k = 1; k < 16; ++k) if (cnt[k]) fprintf(stderr, "  %2d: %9.0f (n=%d)\n", k, sum[k] / cnt[k], cnt[k]);
+    }
+    free(hst);
+  }
+  return rdst_launch_status("mlp_fwd");
 }

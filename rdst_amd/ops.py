@@ -408,10 +408,21 @@ class _SwinBlock(torch.autograd.Function):
         x1 = torch.empty(lead + (C,), dtype=dt, device=dev)
         lin(a.data_ptr(), C, None, None, ACT_NONE, projw_, projb_, x_r.data_ptr(), ldx, x1, C, None, C)
         stats2 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n2w_ is not None else None
-        h = torch.empty(lead + (hid,), dtype=dt, device=dev)
-        lin(x1.data_ptr(), C, n2w_, n2b_, ACT_NONE, fc1w_, fc1b_, None, 0, h, hid, stats2, C)
         y = torch.empty(lead + (C,), dtype=dt, device=dev)
-        lin(h.data_ptr(), hid, None, None, ACT_GELU, fc2w_, fc2b_, x1.data_ptr(), C, y, C, None, hid)
+        h = None
+        fused_mlp = MLP_FUSED and n2w_ is not None and bool(lib.rdst_mlp_fused_supported(C, hid, code))
+        if fused_mlp:
+            # K7: the whole Mlp half in one kernel; the hidden activations are not kept (the backward recomputes them)
+            rc = lib.rdst_mlp_fwd(x1.data_ptr(), C, n2w_.data_ptr(), n2b_.data_ptr(), fc1w_.data_ptr(), _ptr(fc1b_),
+                                  fc2w_.data_ptr(), _ptr(fc2b_), y.data_ptr(), C, stats2.data_ptr(), M, C, hid, code, st)
+            if rc == _lib.ENOTSUP:
+                fused_mlp = False
+            else:
+                _lib.check(rc, "rdst_mlp_fwd")
+        if not fused_mlp:
+            h = torch.empty(lead + (hid,), dtype=dt, device=dev)
+            lin(x1.data_ptr(), C, n2w_, n2b_, ACT_NONE, fc1w_, fc1b_, None, 0, h, hid, stats2, C)
+            lin(h.data_ptr(), hid, None, None, ACT_GELU, fc2w_, fc2b_, x1.data_ptr(), C, y, C, None, hid)
         ctx.save_for_backward(x_r, stats1, qkv, a, x1, stats2, h, *P)
         ctx.meta = (M, B, H, W, C, hid, heads, ws, shift, float(scale), ldx, code)
         return y
@@ -438,17 +449,25 @@ class _SwinBlock(torch.autograd.Function):
         # read (saved activations, dy, dh, dx1, dqkv, their workspaces) stays referenced until then.
         keep = []
         dx1 = torch.empty_like(x1)
-        fused_mlp = (MLP_FUSED and all(t is not None for t in (dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b))
-                     and lib.rdst_mlp_fused_supported(C, hid, code))
+        # K7 when the forward was fused (h was never written) or whenever every Mlp gradient is wanted anyway
+        fused_mlp = h is None or (MLP_FUSED and all(t is not None for t in (dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b))
+                                  and bool(lib.rdst_mlp_fused_supported(C, hid, code)))
         if fused_mlp:
-            # K7: the whole Mlp backward in one pass over (x1, dy); the hidden activations are recomputed
+            # the whole Mlp backward in one pass over (x1, dy); the hidden activations are recomputed.  The kernel
+            # writes every parameter gradient: the ones nobody asked for land in scratch.
+            def out(t, like, n=None):
+                if t is not None:
+                    return t
+                return torch.empty_like(like) if like is not None else torch.empty(n, dtype=torch.float32, device=dev)
+            o = [out(dfc1w, fc1w), out(dfc1b, fc1b, hid), out(dfc2w, fc2w), out(dfc2b, fc2b, C), out(dn2w, n2w),
+                 out(dn2b, n2b)]
             nb = lib.rdst_mlp_bwd_workspace(M, C, hid)
             wsp_m = _workspace(nb, dev)
             rc = lib.rdst_mlp_bwd(x1.data_ptr(), C, n2w.data_ptr(), n2b.data_ptr(), stats2.data_ptr(), fc1w.data_ptr(),
-                                  fc1b.data_ptr(), fc2w.data_ptr(), dy_r.data_ptr(), lddy, dx1.data_ptr(), C,
-                                  dfc1w.data_ptr(), dfc1b.data_ptr(), dfc2w.data_ptr(), dfc2b.data_ptr(), dn2w.data_ptr(),
-                                  dn2b.data_ptr(), wsp_m.data_ptr(), nb, M, C, hid, code, _stream())
-            if rc == _lib.ENOTSUP:
+                                  _ptr(fc1b), fc2w.data_ptr(), dy_r.data_ptr(), lddy, dx1.data_ptr(), C,
+                                  o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
+                                  o[5].data_ptr(), wsp_m.data_ptr(), nb, M, C, hid, code, _stream())
+            if rc == _lib.ENOTSUP and h is not None:
                 fused_mlp = False
             else:
                 _lib.check(rc, "rdst_mlp_bwd")

@@ -15,7 +15,7 @@ CASES = [  # M, C, hid
     (4096, 90, 180),
     (2048 + 32, 120, 240),
     (300, 62, 100),             # hid != 2C, odd pack tails
-    (64, 126, 254),             # the largest supported widths
+    (64, 124, 232),             # about the largest widths whose two weight images fit the 160 KB of LDS
 ]
 
 
@@ -73,10 +73,63 @@ def test_mlp_bwd_fused(M, C, hid):
         assert _rel(got, want) <= tol, name
 
 
+@pytest.mark.parametrize("M,C,hid", CASES)
+def test_mlp_fwd_fused(M, C, hid):
+    from rdst_amd import _lib
+    lib = _lib.load()
+    x, gy, lw, lb, w1, b1, w2, b2 = _inputs(M, C, hid)
+    yref, _ = _reference(x, lw, lb, w1, b1, w2, b2, gy)
+    xg = x.to(DEV).bfloat16()
+    P = [t.to(DEV).contiguous() for t in (lw, lb, w1, b1, w2, b2)]
+    y = torch.full_like(xg, float("nan"))
+    stats = torch.full((M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.rdst_mlp_fwd(xg.data_ptr(), C, P[0].data_ptr(), P[1].data_ptr(), P[2].data_ptr(), P[3].data_ptr(),
+                                P[4].data_ptr(), P[5].data_ptr(), y.data_ptr(), C, stats.data_ptr(), M, C, hid, _lib.BF16,
+                                st), "rdst_mlp_fwd")
+    torch.cuda.synchronize()
+    # bf16 operands, fp32 accumulation, bf16 output: the bound test_ops_gpu.py uses for the unfused bf16 kernels
+    assert (y.float().cpu() - yref).abs().max().item() <= 3e-2 * max(1.0, yref.abs().max().item())
+    assert _rel(y, yref) <= 1e-2
+    xf = x.double()
+    mean, var = xf.mean(-1), xf.var(-1, unbiased=False)
+    assert (stats[:, 0].double().cpu() - mean).abs().max().item() <= 1e-5
+    assert ((stats[:, 1].double().cpu() - (var + 1e-5).rsqrt()) / (var + 1e-5).rsqrt()).abs().max().item() <= 1e-5
+
+
+def test_swin_block_fused_vs_composed():
+    """The block with K7 on and off (same process, module switch) agrees to bf16 noise, forward and backward."""
+    from rdst_amd import ops
+    C, hid, H, W, heads, ws = 60, 120, 16, 16, 6, 8
+    torch.manual_seed(0)
+    x = torch.randn(2, H * W, C, device=DEV).bfloat16()
+    prm = [1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C), torch.randn(3 * C, C) * C ** -0.5, 0.1 * torch.randn(3 * C),
+           0.02 * torch.randn((2 * ws - 1) ** 2, heads), torch.randn(C, C) * C ** -0.5, 0.1 * torch.randn(C),
+           1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C), torch.randn(hid, C) * C ** -0.5, 0.1 * torch.randn(hid),
+           torch.randn(C, hid) * hid ** -0.5, 0.1 * torch.randn(C)]
+    gy = torch.randn(2, H * W, C, device=DEV).bfloat16()
+    res = []
+    keep = ops.MLP_FUSED
+    try:
+        for fused in (True, False):
+            ops.MLP_FUSED = fused
+            xs = x.clone().requires_grad_(True)
+            ps = [t.to(DEV).requires_grad_(True) for t in prm]
+            y = ops.swin_block(xs, *ps, H, W, heads, ws, 4, (C // heads) ** -0.5)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append([y.detach().float(), xs.grad.float()] + [t.grad.float() for t in ps])
+    finally:
+        ops.MLP_FUSED = keep
+    for a, b in zip(*res):
+        assert (a - b).norm().item() <= 2e-2 * max(b.norm().item(), 1e-6)
+
+
 def test_mlp_unsupported_shapes_say_so():
     from rdst_amd import _lib
     lib = _lib.load()
     assert lib.rdst_mlp_fused_supported(60, 120, _lib.F32) == 0     # fp32 parity mode composes K3 kernels
     assert lib.rdst_mlp_fused_supported(128, 256, _lib.BF16) == 0   # no room for the ones column
+    assert lib.rdst_mlp_fused_supported(126, 254, _lib.BF16) == 0   # the forward's weight images exceed the LDS
     assert lib.rdst_mlp_fused_supported(60, 200, _lib.BF16) == 0    # hidden width beyond the wave count
     assert lib.rdst_mlp_fused_supported(61, 120, _lib.BF16) == 0    # odd rows are not dword aligned

@@ -18,6 +18,12 @@ def run():
     _lib.check(lib.rdst_mlp_bwd(x.data_ptr(), C, lw.data_ptr(), lb.data_ptr(), stats.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                 w2.data_ptr(), dy.data_ptr(), C, dx.data_ptr(), C, *[g.data_ptr() for g in G], wsp.data_ptr(), nb,
                                 M, C, hid, _lib.BF16, st), "mlp_bwd")
+b2 = torch.zeros(C, device=dev); y = torch.empty_like(x); st2 = torch.empty(M, 2, device=dev)
+def runf():
+    _lib.check(lib.rdst_mlp_fwd(x.data_ptr(), C, lw.data_ptr(), lb.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                b2.data_ptr(), y.data_ptr(), C, st2.data_ptr(), M, C, hid, _lib.BF16, st), "mlp_fwd")
+if len(sys.argv) > 3 and sys.argv[3] == "fwd":
+    run = runf
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
