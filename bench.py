@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3, help="replay passes over the captured K1/K2 launches")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the K1/K2 measurements (clean per-step kernel profiles)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -217,7 +218,7 @@ def main():
         "loss": round(loss_val, 6),
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_roofline:
         # ---- roofline of the window-attention forward kernel (K1), HIP events on the launch stream ----
         # One eager step with a capturing KernelTimer: every K1 / K2 launch of the step (its real operands,
         # 48 launches each, C = 60/90/120, shifted and not) is kept and then replayed back to back inside

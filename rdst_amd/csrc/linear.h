@@ -39,3 +39,9 @@ int linear_dgrad_ln2_mfma(const T* X, int64_t ldx, const float* stats, const flo
 // finish of a LayerNorm-fused weight gradient from G (N, K+1) = [dY^T x-hat | colsum(dY)] (see linear_wgrad_ln_mfma)
 int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
                            float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st);
+int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st);
+// LayerNorm + Linear backward (dX, dW, dbias, d(gamma), d(beta)) in ONE pass over (x, dY): mlp_mfma.hip
+int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
+                             const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,
+                             int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
+                             int64_t M, int K, int N, float s, hipStream_t st);

@@ -291,6 +291,11 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
     if (ln_w && ln_b && dW && dbias && dln_w && dln_b && dX && K <= 128 && !getenv("RDST_LN_BWD_V1")) {
       float* G = dA;   // the fp32 dA buffer of the generic path is unused here: N*(K+1) <= M*K floats of scratch
       if ((int64_t)N * (K + 1) <= M * K) {
+        if constexpr (sizeof(T) == 2) {   // one pass over (x, dY) for everything, where the shape is covered
+          const int rcf = linear_ln_bwd_fused_bf16(X, ldx, ln_w, ln_b, stats, Wt, dY, lddy, dX, lddx, acc, ldacc, dW, dbias, dln_w,
+                                                   dln_b, slabW, G, M, K, N, s, st);
+          if (rcf != RDST_ENOTSUP) return rcf;
+        }
         int rc = linear_wgrad_ln_mfma<T>(X, ldx, ln_w, ln_b, stats, Wt, dY, lddy, dW, dbias, dln_w, dln_b, slabW, G, M, K, N,
                                          s, st);
         if (rc == 0) {

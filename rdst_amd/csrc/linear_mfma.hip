@@ -1326,6 +1326,10 @@ __global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __re
 
 }  // namespace
 
+int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, nwg, tot, G);
+  return rdst_launch_status("wgrad_sum");
+}
 // launcher of the LayerNorm finish for other translation units (mlp_mfma.hip)
 int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
                            float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st) {

@@ -845,6 +845,277 @@ __global__ void __launch_bounds__(256) mlp_sum_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of a LayerNorm-fused Linear (norm1 + qkv) in ONE pass over (x, dY): the same skeleton as the Mlp
+// backward without the recompute.  Unfused, dY (3C wide) and x are read twice (data-gradient kernel, weight-
+// gradient kernel); here every tile is staged once and feeds both products:
+//   phase 2  wave w: G[n-tile w][c] += dY^T x-hat   (both operands read transposed from the token-major tiles)
+//   phase 3  waves 0..K/32: dX-hat^T = (W gamma)^T dY^T (W gamma read transposed from its one LDS image, dY rows as
+//            they lie), LayerNorm backward, + dX_add (the residual fan-out), 16-B row stores
+// G (N, K+1) goes through the same sum / LayerNorm-finish kernels as linear_wgrad_ln_mfma.
+struct LnLinArgs {
+  const bf16* X; int64_t ldx; const float* stats; const float* lnw; const float* W;
+  const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx; const bf16* Acc; int64_t ldacc;
+  float* slab; int64_t slab_stride;
+  int64_t M; int K; int N; int NW; int64_t ntiles; int tiles_per_wg;
+};
+
+template <int NCT>
+__global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CP = 32 * NCT, PK = CP / 8, LDW = CP * 2 + 16, LDX = LDW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
+  const int K = p.K, N = p.N, NW = p.NW, NT = 64 * NW;
+  const int NP = 32 * NW, KN = 2 * NW, LDY = NP * 2 + 16;
+  const int OFF_XH = NP * LDW, OFF_AC = OFF_XH + 32 * LDX, OFF_DY = OFF_AC + 32 * LDX, OFF_SM = OFF_DY + 32 * LDY,
+            OFF_RED = OFF_SM + 128;
+  float* sm = reinterpret_cast<float*>(smem + OFF_SM);
+  float* red = reinterpret_cast<float*>(smem + OFF_RED);
+
+  // ---- prologue: zero padding, ones column, W*gamma image ----
+  lds_zero16(smem, OFF_SM, tid, NT);
+  {
+    const int pk = tid % PK, jr = tid / PK, c0 = 8 * pk, rpp = NT / PK;   // rows per pass
+    float gq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gq[e] = p.lnw[c0 + e < K ? c0 + e : K - 1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gq[e] = c0 + e < K ? gq[e] : 0.f;
+    const int cl = c0 < K - 8 ? c0 : K - 8, sh = c0 - cl;
+    __syncthreads();   // zero fill done
+    for (int n0 = 0; n0 < N; n0 += 4 * rpp) {
+      float w[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u * rpp + jr;
+        const float* src = p.W + (int64_t)(n < N ? n : N - 1) * K + cl;
+        const u32x4_a4 a = *reinterpret_cast<const u32x4_a4*>(src), b = *reinterpret_cast<const u32x4_a4*>(src + 4);
+        w[u][0] = __uint_as_float(a.x); w[u][1] = __uint_as_float(a.y); w[u][2] = __uint_as_float(a.z); w[u][3] = __uint_as_float(a.w);
+        w[u][4] = __uint_as_float(b.x); w[u][5] = __uint_as_float(b.y); w[u][6] = __uint_as_float(b.z); w[u][7] = __uint_as_float(b.w);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u * rpp + jr;
+        if (n < N && sh < 8) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x = (k == e + sh) ? w[u][k] : x;
+            f[e] = x * gq[e];
+          }
+          *reinterpret_cast<Pack16*>(smem + n * LDW + c0 * 2) = MM::pack(f);
+        }
+      }
+    }
+    if (tid < 32) *reinterpret_cast<uint16_t*>(smem + OFF_XH + tid * LDX + K * 2) = 0x3f80;   // ones column of x-hat
+  }
+
+  // ---- loader plan: slots 0, 1 = dY chunks, 2 = x chunk, 3 = dX_add chunk ----
+  const int PKY = (N * 2 + 15) >> 4;
+  const char* gp[4];
+  int lds_off[4];
+  bool act[4], al[4];
+  int64_t gstep[4];
+  int lrow[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool isy = u < 2;
+    const int idx = isy ? tid + NT * u : tid;
+    const int per = isy ? PKY : PK, rowbytes = isy ? N * 2 : K * 2;
+    const int row = idx / per, chk = idx - row * per;
+    act[u] = row < 32 && chk * 16 < rowbytes && (u != 3 || p.Acc != nullptr);
+    int o = chk * 16;
+    if (o + 16 > rowbytes) o = rowbytes - 16;
+    if (!act[u]) o = 0;
+    lrow[u] = row & 31;
+    al[u] = (o & 15) == 0;
+    lds_off[u] = (isy ? OFF_DY + lrow[u] * LDY : (u == 2 ? OFF_XH : OFF_AC) + lrow[u] * LDX) + o;
+    const bf16* base = isy ? p.dY : (u == 2 ? p.X : (p.Acc ? p.Acc : p.X));
+    const int64_t ld = isy ? p.lddy : (u == 2 ? p.ldx : (p.Acc ? p.ldacc : p.ldx));
+    gp[u] = reinterpret_cast<const char*>(base) + o;   // + row * ld * 2 at seek
+    gstep[u] = ld * 2;
+  }
+  const float* sp = p.stats;
+  u32x4_a4 rd[4];
+  float2 rst;
+  const char* cur[4];
+  const float* scur = nullptr;
+  auto seek = [&](int64_t tile) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t row = tile * 32 + lrow[u];
+      row = row < p.M ? row : p.M - 1;
+      cur[u] = gp[u] + row * gstep[u];
+      if (u == 2) scur = sp + 2 * row;
+    }
+  };
+  auto fetch = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rd[u] = *reinterpret_cast<const u32x4_a4*>(cur[u]);
+    rst = *reinterpret_cast<const float2*>(scur);
+  };
+  auto put16 = [&](char* dst, const Pack16& v, bool aligned) {
+    if (aligned) *reinterpret_cast<Pack16*>(dst) = v;
+    else {
+      uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+      d[0] = v.w[0]; d[1] = v.w[1]; d[2] = v.w[2]; d[3] = v.w[3];
+    }
+  };
+  auto stash = [&](int64_t tile) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!act[u]) continue;
+      const bool valid = tile * 32 + lrow[u] < p.M;
+      Pack16 v;
+      if (u == 2) {
+        float f[8];
+        unpack8(rd[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = valid ? (f[e] - rst.x) * rst.y : 0.f;
+        v = MM::pack(f);
+      } else {
+        v.w[0] = valid ? rd[u].x : 0u; v.w[1] = valid ? rd[u].y : 0u; v.w[2] = valid ? rd[u].z : 0u; v.w[3] = valid ? rd[u].w : 0u;
+      }
+      put16(smem + lds_off[u], v, al[u]);
+    }
+    if (act[2] && (lds_off[2] - OFF_XH) % LDX == 0) sm[lrow[2]] = rst.y;
+  };
+
+  const int q = (lane & 15) >> 2, pp = lane & 3, gq1 = (lane >> 4) & 1;
+  const int trc = (16 * gq1 + 4 * pp) * 2;
+  const lds_cp ytr = (lds_cp)(smem + OFF_DY + (8 * hh + q) * LDY + trc + wave * 64);   // dY columns of the wave's n-tile
+  const lds_cp xtr = (lds_cp)(smem + OFF_XH + (8 * hh + q) * LDX + trc);
+  const lds_cp wtr = (lds_cp)(smem + (8 * hh + q) * LDW + trc + wave * 64);            // wave < NCT: channel tile = wave
+  const lds_cp yrow = (lds_cp)(smem + OFF_DY + r * LDY + hh * 16);
+
+  f32x16 G[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) G[ct][v] = 0.f;
+
+  const int64_t t0 = (int64_t)blockIdx.x * p.tiles_per_wg;
+  const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
+  const float invK = 1.0f / (float)K;
+  __syncthreads();   // W image, ones column
+  if (t0 < t1) {
+    seek(t0);
+    fetch();
+  }
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    stash(tile);
+    seek(tile + 1 < t1 ? tile + 1 : tile);
+    fetch();
+    __syncthreads();   // B1
+    // ---- phase 2
+    {
+      Pack16 ya[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ya[s] = lds_tr_pack(ytr + 16 * s * LDY, ytr + (16 * s + 4) * LDY);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const Pack16 xb = lds_tr_pack(xtr + 16 * s * LDX + ct * 64, xtr + (16 * s + 4) * LDX + ct * 64);
+          MM::mma(G[ct], ya[s], xb);   // rows = output features n, columns = channels (column K = d(bias))
+        }
+    }
+    // ---- phase 3
+    f32x16 dx;
+    float rstd = 0.f;
+    if (wave < NCT) {
+      f32x16 dx2;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) { dx[v] = 0.f; dx2[v] = 0.f; }
+#pragma unroll 2
+      for (int kk = 0; kk < KN; kk += 2) {
+        const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
+        const Pack16 yb = lds_pack(yrow + 32 * kk);
+        const Pack16 wa2 = lds_tr_pack(wtr + 16 * (kk + 1) * LDW, wtr + (16 * (kk + 1) + 4) * LDW);
+        const Pack16 yb2 = lds_pack(yrow + 32 * (kk + 1));
+        MM::mma(dx, wa, yb);   // rows = channels, columns = tokens
+        MM::mma(dx2, wa2, yb2);
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) dx[v] += dx2[v];
+      rstd = sm[r];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + OFF_XH + r * LDX) + (32 * wave + 8 * g4 + 4 * hh) * 2);
+        const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1 += dx[4 * g4 + e];
+          s2 = fmaf(dx[4 * g4 + e], xh[e], s2);
+        }
+      }
+      s1 = half_swap_sum(s1);
+      s2 = half_swap_sum(s2);
+      if (hh == 0) *reinterpret_cast<float2*>(red + (wave * 32 + r) * 2) = make_float2(s1, s2);
+    }
+    __syncthreads();   // B3
+    if (wave < NCT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NCT; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(red + (w * 32 + r) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+      s1 *= invK; s2 *= invK;
+      float o[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cb = (32 * wave + 8 * g4 + 4 * hh) * 2;
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + OFF_XH + r * LDX) + cb);
+        const u32x2_t av = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + OFF_AC + r * LDX) + cb);   // zeros without dX_add
+        const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
+        const float ac[4] = {bf16lo(av.x), bf16hi(av.x), bf16lo(av.y), bf16hi(av.y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * g4 + e] = fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, ac[e]);
+      }
+      const int64_t row = tile * 32 + r;
+      if (row < p.M) {
+        bf16* drow = p.dX + row * p.lddx;
+#pragma unroll
+        for (int gp2 = 0; gp2 < 2; ++gp2) {
+          float c8[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * gp2 + e]), __float_as_uint(o[8 * gp2 + 4 + e]), false, false);
+            c8[e] = __uint_as_float(sw[0]);
+            c8[4 + e] = __uint_as_float(sw[1]);
+          }
+          const int cb = 32 * wave + 8 * (2 * gp2 + hh);
+          if (cb + 8 <= K) {
+            u32x4_a4 u;
+            u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+            u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+            *reinterpret_cast<u32x4_a4*>(drow + cb) = u;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (cb + e < K) drow[cb + e] = __float2bfloat16(c8[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // B4
+  }
+  float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int c = 32 * ct + r;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int n = 32 * wave + acc_row(v, hh);
+      if (n < N && c <= K) my[(int64_t)n * (K + 1) + c] = G[ct][v];
+    }
+  }
+}
+
 int mlp_nct(int C, int hid) {
   const int nct = (C + 1 + 31) / 32;
   if (nct < 2 || nct > 4) return 0;
@@ -1001,4 +1272,48 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
     free(hst);
   }
   return rdst_launch_status("mlp_fwd");
+}
+
+int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st);
+
+// LayerNorm + Linear backward in one pass (bf16, K+1 <= 128, 96 <= N <= 384, out_scale 1); RDST_ENOTSUP otherwise
+int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
+                             const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,
+                             int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
+                             int64_t M, int K, int N, float s, hipStream_t st) {
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("RDST_LNLIN_V1"); off = (e && e[0] == '1') ? 1 : 0; }
+  if (off || s != 1.0f || M <= 0) return RDST_ENOTSUP;
+  const int nct = (K + 1 + 31) / 32;
+  if (nct < 2 || nct > 4 || (K & 1) || K < 8 || (N & 1) || N < 8) return RDST_ENOTSUP;
+  const int NW = (N + 31) / 32;
+  if (NW < nct || NW > 12) return RDST_ENOTSUP;
+  const int NT = 64 * NW, PK = 4 * nct, PKY = (N * 2 + 15) / 16;
+  if (2 * NT < 32 * PKY || NT < 32 * PK) return RDST_ENOTSUP;
+  if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3) || (ldx & 1) || (lddy & 1) ||
+      (lddx & 1) || (ldacc & 1))
+    return RDST_ENOTSUP;
+  const int CP = 32 * nct, LDW = CP * 2 + 16, NP = 32 * NW, LDY = NP * 2 + 16;
+  const int smem = NP * LDW + 2 * 32 * LDW + 32 * LDY + 128 + nct * 32 * 8;
+  if (smem > 160 * 1024) return RDST_ENOTSUP;
+  LnLinArgs p{};
+  p.X = X; p.ldx = ldx; p.stats = stats; p.lnw = ln_w; p.W = Wt; p.dY = dY; p.lddy = lddy; p.dX = dX; p.lddx = lddx;
+  p.Acc = acc; p.ldacc = ldacc; p.M = M; p.K = K; p.N = N; p.NW = NW;
+  p.ntiles = (M + 31) / 32;
+  int64_t grid = p.ntiles < 256 ? p.ntiles : 256;
+  p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
+  grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  p.slab = slab;
+  p.slab_stride = (int64_t)N * (K + 1);
+#define RDST_LNLIN(NC)                                                                                               \
+  {                                                                                                                  \
+    auto kern = lnlin_bwd_kernel<NC>;                                                                                \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, st, p);                                           \
+  }
+  if (nct == 2) RDST_LNLIN(2) else if (nct == 3) RDST_LNLIN(3) else RDST_LNLIN(4)
+#undef RDST_LNLIN
+  if (int rc = rdst_launch_status("lnlin_bwd")) return rc;
+  if (int rc = wgrad_sum_launch(slab, (int)grid, N * (K + 1), G, st)) return rc;
+  return wgrad_ln_finish_launch(G, Wt, ln_w, ln_b, N, K, 1.0f, dW, dbias, dln_w, dln_b, st);
 }
