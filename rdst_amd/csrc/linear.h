@@ -18,6 +18,7 @@ int linear_wgrad_mfma(const T* X, int64_t ldx, const float* ln_w, const float* l
                       const T* dY, int64_t lddy, float* dW, float* dbias, float* slab, int64_t M, int K, int N, float s,
                       hipStream_t st);
 size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N);
+int linear_wgrad_max_wgs(int N);   // slab rows the workspace holds for a Linear of N outputs
 // dgrad with the LayerNorm backward fused in (K <= 128): dX written/accumulated, d(gamma)/d(beta) partials in
 // slab[*nslab][2][K] for the caller to reduce
 template <typename T>
@@ -40,6 +41,7 @@ int linear_dgrad_ln2_mfma(const T* X, int64_t ldx, const float* stats, const flo
 int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
                            float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st);
 int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st);
+int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float* dW, float* dbias, hipStream_t st);
 // LayerNorm + Linear backward (dX, dW, dbias, d(gamma), d(beta)) in ONE pass over (x, dY): mlp_mfma.hip
 int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
                              const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,

@@ -309,6 +309,13 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
         }
       }
     }
+    if constexpr (sizeof(T) == 2) {   // plain Linear (proj): dX, dW, dbias in one pass over (x, dY)
+      if (!ln_w && !in_act && dW && dbias && dX) {
+        const int rcf = linear_ln_bwd_fused_bf16(X, ldx, nullptr, nullptr, nullptr, Wt, dY, lddy, dX, lddx, acc, ldacc, dW, dbias,
+                                                 nullptr, nullptr, slabW, nullptr, M, K, N, s, st);
+        if (rcf != RDST_ENOTSUP) return rcf;
+      }
+    }
     bool wgrad_done = false;
     if (dW || dbias) {
       const int rc = linear_wgrad_mfma<T>(X, ldx, ln_w, ln_b, stats, in_act, dY, lddy, dW, dbias, slabW, M, K, N, s, st);

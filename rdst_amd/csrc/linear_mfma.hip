@@ -1326,6 +1326,11 @@ __global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __re
 
 }  // namespace
 
+int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float* dW, float* dbias, hipStream_t st) {
+  const int tot = N * (K + 1);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, nwg, N, K, K + 1, s, dW, dbias);
+  return rdst_launch_status("wgrad_reduce");
+}
 int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st) {
   hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, nwg, tot, G);
   return rdst_launch_status("wgrad_sum");
@@ -1393,10 +1398,13 @@ int linear_dgrad_ln_mfma(const T* X, int64_t ldx, const float* stats, const floa
   return rdst_launch_status("lin_dgrad_ln_mfma");
 }
 
+int linear_wgrad_max_wgs(int N);
 size_t linear_wgrad_mfma_slab_floats(int64_t M, int K, int N) {
   (void)M;
-  return (size_t)256 * N * (K + 1);
+  // 256 workgroups, or up to 1024 small ones for the narrow projections (linear_ln_bwd_fused_bf16)
+  return (size_t)linear_wgrad_max_wgs(N) * N * (K + 1);
 }
+int linear_wgrad_max_wgs(int N) { return N <= 128 ? 1024 : N <= 192 ? 512 : 256; }
 
 namespace {
 template <typename T>

@@ -860,7 +860,8 @@ struct LnLinArgs {
   int64_t M; int K; int N; int NW; int64_t ntiles; int tiles_per_wg;
 };
 
-template <int NCT>
+// LN = false: plain Linear (proj): x-hat is x itself, no LayerNorm backward, W unscaled
+template <int NCT, bool LN>
 __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CP = 32 * NCT, PK = CP / 8, LDW = CP * 2 + 16, LDX = LDW;
@@ -878,7 +879,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     const int pk = tid % PK, jr = tid / PK, c0 = 8 * pk, rpp = NT / PK;   // rows per pass
     float gq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) gq[e] = p.lnw[c0 + e < K ? c0 + e : K - 1];
+    for (int e = 0; e < 8; ++e) gq[e] = LN ? p.lnw[c0 + e < K ? c0 + e : K - 1] : 1.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) gq[e] = c0 + e < K ? gq[e] : 0.f;
     const int cl = c0 < K - 8 ? c0 : K - 8, sh = c0 - cl;
@@ -912,34 +913,37 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     if (tid < 32) *reinterpret_cast<uint16_t*>(smem + OFF_XH + tid * LDX + K * 2) = 0x3f80;   // ones column of x-hat
   }
 
-  // ---- loader plan: slots 0, 1 = dY chunks, 2 = x chunk, 3 = dX_add chunk ----
+  // ---- loader plan: up to 4 chunk slots per thread over [dY chunks | x chunks | dX_add chunks] (the x range is no
+  // longer than the thread count, so a thread owns at most one x chunk and needs one statistics pair) ----
   const int PKY = (N * 2 + 15) >> 4;
+  const int nY = 32 * PKY, nX = 32 * PK, nA = p.Acc ? 32 * PK : 0;
   const char* gp[4];
-  int lds_off[4];
-  bool act[4], al[4];
+  int lds_off[4], lrow[4], kind[4];   // kind: 0 dY, 1 x, 2 dX_add, -1 none
+  bool al[4];
   int64_t gstep[4];
-  int lrow[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const bool isy = u < 2;
-    const int idx = isy ? tid + NT * u : tid;
-    const int per = isy ? PKY : PK, rowbytes = isy ? N * 2 : K * 2;
-    const int row = idx / per, chk = idx - row * per;
-    act[u] = row < 32 && chk * 16 < rowbytes && (u != 3 || p.Acc != nullptr);
+    const int g = tid + NT * u;
+    const int kd = g < nY ? 0 : g < nY + nX ? 1 : g < nY + nX + nA ? 2 : -1;
+    const int idx = kd == 0 ? g : kd == 1 ? g - nY : g - nY - nX;
+    const int per = kd == 0 ? PKY : PK, rowbytes = kd == 0 ? N * 2 : K * 2;
+    const int row = (kd < 0 ? 0 : idx / per), chk = kd < 0 ? 0 : idx - row * per;
     int o = chk * 16;
+    const bool on = kd >= 0 && o < rowbytes;
     if (o + 16 > rowbytes) o = rowbytes - 16;
-    if (!act[u]) o = 0;
+    if (!on) o = 0;
+    kind[u] = on ? kd : -1;
     lrow[u] = row & 31;
     al[u] = (o & 15) == 0;
-    lds_off[u] = (isy ? OFF_DY + lrow[u] * LDY : (u == 2 ? OFF_XH : OFF_AC) + lrow[u] * LDX) + o;
-    const bf16* base = isy ? p.dY : (u == 2 ? p.X : (p.Acc ? p.Acc : p.X));
-    const int64_t ld = isy ? p.lddy : (u == 2 ? p.ldx : (p.Acc ? p.ldacc : p.ldx));
+    lds_off[u] = (kd == 0 ? OFF_DY + lrow[u] * LDY : (kd == 2 ? OFF_AC : OFF_XH) + lrow[u] * LDX) + o;
+    const bf16* base = kd == 0 ? p.dY : kd == 2 ? p.Acc : p.X;
+    const int64_t ld = kd == 0 ? p.lddy : kd == 2 ? p.ldacc : p.ldx;
     gp[u] = reinterpret_cast<const char*>(base) + o;   // + row * ld * 2 at seek
     gstep[u] = ld * 2;
   }
   const float* sp = p.stats;
   u32x4_a4 rd[4];
-  float2 rst;
+  float2 rst = make_float2(0.f, 1.f);
   const char* cur[4];
   const float* scur = nullptr;
   auto seek = [&](int64_t tile) {
@@ -948,13 +952,13 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       int64_t row = tile * 32 + lrow[u];
       row = row < p.M ? row : p.M - 1;
       cur[u] = gp[u] + row * gstep[u];
-      if (u == 2) scur = sp + 2 * row;
+      if (LN && kind[u] == 1) scur = sp + 2 * row;
     }
   };
   auto fetch = [&]() {
 #pragma unroll
     for (int u = 0; u < 4; ++u) rd[u] = *reinterpret_cast<const u32x4_a4*>(cur[u]);
-    rst = *reinterpret_cast<const float2*>(scur);
+    if (LN && scur) rst = *reinterpret_cast<const float2*>(scur);
   };
   auto put16 = [&](char* dst, const Pack16& v, bool aligned) {
     if (aligned) *reinterpret_cast<Pack16*>(dst) = v;
@@ -966,10 +970,10 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   auto stash = [&](int64_t tile) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (!act[u]) continue;
+      if (kind[u] < 0) continue;
       const bool valid = tile * 32 + lrow[u] < p.M;
       Pack16 v;
-      if (u == 2) {
+      if (LN && kind[u] == 1) {
         float f[8];
         unpack8(rd[u], f);
 #pragma unroll
@@ -980,7 +984,11 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       }
       put16(smem + lds_off[u], v, al[u]);
     }
-    if (act[2] && (lds_off[2] - OFF_XH) % LDX == 0) sm[lrow[2]] = rst.y;
+    if (LN) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (kind[u] == 1 && (lds_off[u] - OFF_XH) % LDX == 0) sm[lrow[u]] = rst.y;
+    }
   };
 
   const int q = (lane & 15) >> 2, pp = lane & 3, gq1 = (lane >> 4) & 1;
@@ -1040,6 +1048,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) dx[v] += dx2[v];
+      if (LN) {
       rstd = sm[r];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1055,16 +1064,19 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       s1 = half_swap_sum(s1);
       s2 = half_swap_sum(s2);
       if (hh == 0) *reinterpret_cast<float2*>(red + (wave * 32 + r) * 2) = make_float2(s1, s2);
+      }
     }
-    __syncthreads();   // B3
+    if (LN) __syncthreads();   // B3
     if (wave < NCT) {
       float s1 = 0.f, s2 = 0.f;
+      if (LN) {
 #pragma unroll
       for (int w = 0; w < NCT; ++w) {
         const float2 v = *reinterpret_cast<const float2*>(red + (w * 32 + r) * 2);
         s1 += v.x; s2 += v.y;
       }
       s1 *= invK; s2 *= invK;
+      }
       float o[16];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -1074,7 +1086,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
         const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
         const float ac[4] = {bf16lo(av.x), bf16hi(av.x), bf16lo(av.y), bf16hi(av.y)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[4 * g4 + e] = fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, ac[e]);
+        for (int e = 0; e < 4; ++e) o[4 * g4 + e] = LN ? fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, ac[e]) : dx[4 * g4 + e] + ac[e];
       }
       const int64_t row = tile * 32 + r;
       if (row < p.M) {
@@ -1274,22 +1286,25 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
   return rdst_launch_status("mlp_fwd");
 }
 
-int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st);
+int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float* dW, float* dbias, hipStream_t st);
 
-// LayerNorm + Linear backward in one pass (bf16, K+1 <= 128, 96 <= N <= 384, out_scale 1); RDST_ENOTSUP otherwise
+// Linear backward in one pass over (x, dY), with (ln_w != NULL) or without a LayerNorm in front: bf16, K+1 <= 128,
+// N <= 384, out_scale 1, no input activation; RDST_ENOTSUP otherwise
 int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
                              const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,
                              int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
                              int64_t M, int K, int N, float s, hipStream_t st) {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("RDST_LNLIN_V1"); off = (e && e[0] == '1') ? 1 : 0; }
-  if (off || s != 1.0f || M <= 0) return RDST_ENOTSUP;
+  if (off < 0) { const char* e = getenv("RDST_LNLIN_V1"); off = e ? atoi(e) : 0; }   // 1: all off, 2: the plain-Linear form off
+  const bool ln = ln_w != nullptr;
+  if (off == 1 || (off == 2 && !ln) || s != 1.0f || M <= 0) return RDST_ENOTSUP;
   const int nct = (K + 1 + 31) / 32;
   if (nct < 2 || nct > 4 || (K & 1) || K < 8 || (N & 1) || N < 8) return RDST_ENOTSUP;
   const int NW = (N + 31) / 32;
   if (NW < nct || NW > 12) return RDST_ENOTSUP;
   const int NT = 64 * NW, PK = 4 * nct, PKY = (N * 2 + 15) / 16;
-  if (2 * NT < 32 * PKY || NT < 32 * PK) return RDST_ENOTSUP;
+  if (4 * NT < 32 * (PKY + PK * (acc ? 2 : 1))) return RDST_ENOTSUP;
+  if (ln && NT < 32 * PK) return RDST_ENOTSUP;   // one statistics pair per thread: at most one x chunk each
   if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3) || (ldx & 1) || (lddy & 1) ||
       (lddx & 1) || (ldacc & 1))
     return RDST_ENOTSUP;
@@ -1300,20 +1315,29 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   p.X = X; p.ldx = ldx; p.stats = stats; p.lnw = ln_w; p.W = Wt; p.dY = dY; p.lddy = lddy; p.dX = dX; p.lddx = lddx;
   p.Acc = acc; p.ldacc = ldacc; p.M = M; p.K = K; p.N = N; p.NW = NW;
   p.ntiles = (M + 31) / 32;
-  int64_t grid = p.ntiles < 256 ? p.ntiles : 256;
+  // small workgroups (the C -> C projections: 2-4 waves) share a CU: up to 12 waves and the LDS that fits
+  int per_cu = 12 / NW;
+  if (per_cu > 160 * 1024 / smem) per_cu = 160 * 1024 / smem;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 2) per_cu = 2;   // more workgroups only add slab traffic (measured)
+  { const char* e = getenv("RDST_LNLIN_PERCU"); if (e && atoi(e) > 0) per_cu = atoi(e); }
+  int64_t cap = 256 * per_cu;
+  if (cap > linear_wgrad_max_wgs(N)) cap = linear_wgrad_max_wgs(N);   // what the workspace's slab region holds
+  int64_t grid = p.ntiles < cap ? p.ntiles : cap;
   p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
   grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   p.slab = slab;
   p.slab_stride = (int64_t)N * (K + 1);
 #define RDST_LNLIN(NC)                                                                                               \
   {                                                                                                                  \
-    auto kern = lnlin_bwd_kernel<NC>;                                                                                \
+    auto kern = ln ? lnlin_bwd_kernel<NC, true> : lnlin_bwd_kernel<NC, false>;                                       \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, st, p);                                           \
   }
   if (nct == 2) RDST_LNLIN(2) else if (nct == 3) RDST_LNLIN(3) else RDST_LNLIN(4)
 #undef RDST_LNLIN
   if (int rc = rdst_launch_status("lnlin_bwd")) return rc;
+  if (!ln) return wgrad_reduce_launch(slab, (int)grid, N, K, 1.0f, dW, dbias, st);
   if (int rc = wgrad_sum_launch(slab, (int)grid, N * (K + 1), G, st)) return rc;
   return wgrad_ln_finish_launch(G, Wt, ln_w, ln_b, N, K, 1.0f, dW, dbias, dln_w, dln_b, st);
 }
