@@ -923,9 +923,11 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   int64_t gstep[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
+    // LN form (wide dY): slot u has a fixed kind — 0, 1: dY, 2: x, 3: dX_add; plain form: slots dealt out in order
     const int g = tid + NT * u;
-    const int kd = g < nY ? 0 : g < nY + nX ? 1 : g < nY + nX + nA ? 2 : -1;
-    const int idx = kd == 0 ? g : kd == 1 ? g - nY : g - nY - nX;
+    const int kd = LN ? (u < 2 ? (g < nY ? 0 : -1) : u == 2 ? (tid < nX ? 1 : -1) : (tid < nA ? 2 : -1))
+                      : (g < nY ? 0 : g < nY + nX ? 1 : g < nY + nX + nA ? 2 : -1);
+    const int idx = LN ? (u < 2 ? g : tid) : (kd == 0 ? g : kd == 1 ? g - nY : g - nY - nX);
     const int per = kd == 0 ? PKY : PK, rowbytes = kd == 0 ? N * 2 : K * 2;
     const int row = (kd < 0 ? 0 : idx / per), chk = kd < 0 ? 0 : idx - row * per;
     int o = chk * 16;
@@ -1304,7 +1306,7 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   if (NW < nct || NW > 12) return RDST_ENOTSUP;
   const int NT = 64 * NW, PK = 4 * nct, PKY = (N * 2 + 15) / 16;
   if (4 * NT < 32 * (PKY + PK * (acc ? 2 : 1))) return RDST_ENOTSUP;
-  if (ln && NT < 32 * PK) return RDST_ENOTSUP;   // one statistics pair per thread: at most one x chunk each
+  if (ln && (NT < 32 * PK || 2 * NT < 32 * PKY)) return RDST_ENOTSUP;   // fixed slot kinds: dY in two slots, x and dX_add in one each
   if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3) || (ldx & 1) || (lddy & 1) ||
       (lddx & 1) || (ldacc & 1))
     return RDST_ENOTSUP;
@@ -1316,7 +1318,7 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   p.Acc = acc; p.ldacc = ldacc; p.M = M; p.K = K; p.N = N; p.NW = NW;
   p.ntiles = (M + 31) / 32;
   // small workgroups (the C -> C projections: 2-4 waves) share a CU: up to 12 waves and the LDS that fits
-  int per_cu = 12 / NW;
+  int per_cu = ln ? 1 : 12 / NW;
   if (per_cu > 160 * 1024 / smem) per_cu = 160 * 1024 / smem;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2) per_cu = 2;   // more workgroups only add slab traffic (measured)
