@@ -35,7 +35,6 @@ struct MlpArgs {
   const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx;
   float* slab; int64_t slab_stride;   // per-workgroup partials: G1 [hid][C+1], then dW2^T [hid+1][C]
   int64_t M; int C; int hid; int64_t ntiles; int tiles_per_wg;
-  int dbg;   // RDST_MLP_DEBUG ablation bits: 1 no GELU math, 2 no phase-1 MFMAs, 4 no phase 2, 8 no phase-3 MFMAs, 16 no dX stores
   unsigned long long* stamps;   // RDST_MLP_STAMPS=n (debug): [grid][16] s_memtime stamps of thread 0
 };
 
@@ -315,7 +314,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
 #pragma unroll
       for (int v = 0; v < 16; ++v) { ah[v] = bj; ad[v] = 0.f; }
 #pragma unroll
-      for (int t = 0; t < ((p.dbg & 2) ? 0 : CF::KC); ++t) {
+      for (int t = 0; t < CF::KC; ++t) {
         const Pack16 xa = lds_pack(xrow + 32 * t), wb = lds_pack(wrow + 32 * t), ya = lds_pack(yrow + 32 * t);
         MM::mma(ah, xa, wb);        // rows (registers) = tokens, columns (lanes) = hidden units
         MM::mma(ad, ya, w2b[t]);
@@ -328,7 +327,6 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
           f32x2 x, g, cdf, ex;
           x.x = ah[8 * s + 2 * e2]; x.y = ah[8 * s + 2 * e2 + 1];
           g.x = ad[8 * s + 2 * e2]; g.y = ad[8 * s + 2 * e2 + 1];
-          if (p.dbg & 1) { cdf = x; ex = g; } else
           gelu_pair(x, cdf, ex);
           const f32x2 hv = x * cdf;
           const f32x2 dv = g * __builtin_elementwise_fma(x * 0.39894228040143267794f, ex, cdf);
@@ -345,7 +343,6 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     __syncthreads();   // B2: dHp image complete
     stamp();   // 3: phase 1 done
     // ---- phase 2: weight gradients (contraction over the tile's 32 tokens, 2 k-steps)
-    if (!(p.dbg & 4))
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -363,7 +360,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
 #pragma unroll
       for (int v = 0; v < 16; ++v) { dx[v] = 0.f; dx2[v] = 0.f; }
 #pragma unroll
-      for (int kk = 0; kk < ((p.dbg & 8) ? 0 : CF::KJ); kk += 2) {
+      for (int kk = 0; kk < CF::KJ; kk += 2) {
         const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
         const Pack16 db = lds_tr_pack(dtr + 16 * kk * CF::LDH, dtr + (16 * kk + 4) * CF::LDH);
         const Pack16 wa2 = lds_tr_pack(wtr + 16 * (kk + 1) * LDW, wtr + (16 * (kk + 1) + 4) * LDW);
@@ -411,7 +408,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
         for (int e = 0; e < 4; ++e) o[4 * g4 + e] = fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, dy[e]);
       }
       const int64_t row = tile * 32 + r;
-      if (row < p.M && !(p.dbg & 16)) {
+      if (row < p.M) {
         bf16* drow = p.dX + row * p.lddx;
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
@@ -483,7 +480,6 @@ struct MlpFwdArgs {
   const float* W1; const float* b1; const float* W2; const float* b2;
   bf16* Y; int64_t ldy; float* stats;
   int64_t M; int C; int hid; int64_t ntiles; int tiles_per_wg;
-  int dbg;
   unsigned long long* stamps;   // RDST_MLPF_STAMPS=n (debug)
 };
 
@@ -1199,7 +1195,6 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   }
   static int split = -1;
   if (split < 0) { const char* e = getenv("RDST_MLP_SPLIT"); split = (e && e[0] == '1') ? 1 : 0; }
-  { const char* e = getenv("RDST_MLP_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   static int want_stamps = -1;
   if (want_stamps < 0) { const char* e = getenv("RDST_MLP_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   if (want_stamps > 0) {
@@ -1259,7 +1254,6 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * NC), smem, st, p);                                     \
   }
-  { const char* e = getenv("RDST_MLP_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   static int want_stamps = -1;
   if (want_stamps < 0) { const char* e = getenv("RDST_MLPF_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   if (want_stamps > 0) {
