@@ -853,7 +853,7 @@ struct LnLinArgs {
   const bf16* X; int64_t ldx; const float* stats; const float* lnw; const float* W;
   const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx; const bf16* Acc; int64_t ldacc;
   float* slab; int64_t slab_stride;
-  int64_t M; int K; int N; int NW; int64_t ntiles; int tiles_per_wg;
+  int64_t M; int K; int N; int NW; int NWV; int64_t ntiles; int tiles_per_wg;   // NW n-tiles, NWV >= NW waves launched
 };
 
 // LN = false: plain Linear (proj): x-hat is x itself, no LayerNorm backward, W unscaled
@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int CP = 32 * NCT, PK = CP / 8, LDW = CP * 2 + 16, LDX = LDW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
-  const int K = p.K, N = p.N, NW = p.NW, NT = 64 * NW;
+  const int K = p.K, N = p.N, NW = p.NW, NT = 64 * p.NWV;
   const int NP = 32 * NW, KN = 2 * NW, LDY = NP * 2 + 16;
   const int OFF_XH = NP * LDW, OFF_AC = OFF_XH + 32 * LDX, OFF_DY = OFF_AC + 32 * LDX, OFF_SM = OFF_DY + 32 * LDY,
             OFF_RED = OFF_SM + 128;
@@ -1015,8 +1015,8 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     seek(tile + 1 < t1 ? tile + 1 : tile);
     fetch();
     __syncthreads();   // B1
-    // ---- phase 2
-    {
+    // ---- phase 2 (waves that own an n-tile)
+    if (wave < NW) {
       Pack16 ya[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) ya[s] = lds_tr_pack(ytr + 16 * s * LDY, ytr + (16 * s + 4) * LDY);
@@ -1115,6 +1115,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     __syncthreads();   // B4
   }
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
+  if (wave < NW)
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
     const int c = 32 * ct + r;
@@ -1297,8 +1298,12 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   const int nct = (K + 1 + 31) / 32;
   if (nct < 2 || nct > 4 || (K & 1) || K < 8 || (N & 1) || N < 8) return RDST_ENOTSUP;
   const int NW = (N + 31) / 32;
-  if (NW < nct || NW > 12) return RDST_ENOTSUP;
-  const int NT = 64 * NW, PK = 4 * nct, PKY = (N * 2 + 15) / 16;
+  if (NW > 12) return RDST_ENOTSUP;
+  const int PK = 4 * nct, PKY = (N * 2 + 15) / 16;
+  // waves launched: one per n-tile, at least the K/32 of phase 3, and enough threads for the loader's fixed slots
+  int NWV = NW > nct ? NW : nct;
+  if (ln && NWV < 2 * nct) NWV = 2 * nct;
+  const int NT = 64 * NWV;
   if (4 * NT < 32 * (PKY + PK * (acc ? 2 : 1))) return RDST_ENOTSUP;
   if (ln && (NT < 32 * PK || 2 * NT < 32 * PKY)) return RDST_ENOTSUP;   // fixed slot kinds: dY in two slots, x and dX_add in one each
   if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3) || (ldx & 1) || (lddy & 1) ||
@@ -1309,10 +1314,10 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   if (smem > 160 * 1024) return RDST_ENOTSUP;
   LnLinArgs p{};
   p.X = X; p.ldx = ldx; p.stats = stats; p.lnw = ln_w; p.W = Wt; p.dY = dY; p.lddy = lddy; p.dX = dX; p.lddx = lddx;
-  p.Acc = acc; p.ldacc = ldacc; p.M = M; p.K = K; p.N = N; p.NW = NW;
+  p.Acc = acc; p.ldacc = ldacc; p.M = M; p.K = K; p.N = N; p.NW = NW; p.NWV = NWV;
   p.ntiles = (M + 31) / 32;
   // small workgroups (the C -> C projections: 2-4 waves) share a CU: up to 12 waves and the LDS that fits
-  int per_cu = ln ? 1 : 12 / NW;
+  int per_cu = ln ? 1 : 12 / NWV;
   if (per_cu > 160 * 1024 / smem) per_cu = 160 * 1024 / smem;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2) per_cu = 2;   // more workgroups only add slab traffic (measured)

@@ -27,6 +27,8 @@ LIN = [  # M, K, N, ln, act, residual, scale
     (200, 90, 180, True, 0, False, 1.0),     # norm2 + fc1 (M not a tile multiple)
     (256, 180, 90, False, 1, True, 1.0),     # GELU + fc2 + residual
     (192, 120, 30, True, 0, False, 0.5),     # dense tail, dense_scale
+    (288, 120, 30, True, 0, False, 1.0),     # dense tail as E1 runs it (one-pass backward, 1 n-tile on 8 waves)
+    (160, 90, 270, True, 0, False, 1.0),     # norm1 + qkv at C = 90 (one-pass backward, 9 waves)
     (130, 48, 48, True, 0, True, 0.9),       # LayerNorm only (no weight), scale + residual
     (64, 33, 17, False, 2, False, 1.0),      # odd sizes, LeakyReLU input
 ]
