@@ -130,6 +130,9 @@ int wgrad_splits(const ConvGeom& g) {
 template <typename T>
 int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr, T* Y,
           int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (int rc = conv_c1_fwd_bf16(X, ldx, in_act, Wc, bias, R, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+  }
   if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
   ConvA<T> la{X, ldx, g, in_act};
   ConvB lb{Wc, g};
@@ -145,6 +148,11 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
   float* slab = wsp;
   float* small = slab + (int64_t)kMaxSplits * wtotal;
   char* mscr = reinterpret_cast<char*>(small + (int64_t)kSmallBlocks * g.Cout + 64);
+  if constexpr (sizeof(T) == 2) {   // the one-output-channel tail conv: vector kernels, its own slab at the end of the workspace
+    float* c1slab = reinterpret_cast<float*>(mscr + conv_mfma_scratch_bytes(ConvGeom{g.B, g.H, g.W, g.Cin, g.Cout, g.ks, g.pad, 2}));
+    if (int rc = conv_c1_bwd_bf16(X, ldx, in_act, Wc, dY, lddy, dX, lddx, acc, ldacc, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP)
+      return rc;
+  }
   // MFMA fast paths want dY as plain (B*H*W, Cout) rows
   int prc = 0;
   int64_t ldp = lddy;
@@ -233,7 +241,7 @@ extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
   ConvGeom g{B, H, W, Cin, Cout, ksize, ksize / 2, 2};  // r = 2 reserves room for an un-shuffled dY
   return sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
-         conv_mfma_scratch_bytes(g);
+         conv_mfma_scratch_bytes(g) + sizeof(float) * conv_c1_slab_floats(Cin);
 }
 
 extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY, int64_t ld_dy,

@@ -90,6 +90,8 @@ CONV = [  # B, H, W, Cin, Cout, k, act, residual, scale, shuffle
     (1, 8, 12, 60, 240, 3, 0, False, 1.0, 2),  # upsampler conv + PixelShuffle(2), non-square
     (2, 9, 7, 1, 60, 3, 0, False, 1.0, 1),     # head conv, odd sizes
     (1, 16, 16, 60, 1, 3, 0, False, 1.0, 1),   # last conv
+    (2, 24, 40, 60, 1, 3, 0, False, 0.5, 1),   # last conv: several workgroups, ragged tail, scale
+    (1, 9, 11, 36, 1, 3, 0, False, 1.0, 1),    # one output channel, channel count not a multiple of 8
     (2, 6, 6, 37, 12, 1, 2, False, 1.0, 1),    # 1x1 conv reading through LeakyReLU ('3conv')
     (1, 6, 6, 48, 108, 3, 0, False, 1.0, 3),   # x3 upsampler
     (2, 5, 5, 3, 3, 1, 0, False, 1.0, 1),      # MeanShift
