@@ -46,8 +46,9 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
                     float* slab, const ConvGeom& g, float s, hipStream_t st);
 size_t conv_mfma_scratch_bytes(const ConvGeom& g);
 
-// one-output-channel 3x3 conv (the tail conv), bf16: plain vector kernels (conv_c1.hip); RDST_ENOTSUP for other shapes
-int conv_c1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, bf16* Y,
+// one-output-channel 3x3 conv (the tail conv) and the 1 -> 1 channel 1x1 conv (MeanShift), bf16: plain vector kernels
+// (conv_c1.hip); RDST_ENOTSUP for other shapes
+int conv_c1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr, bf16* Y,
                      int64_t ldy, const ConvGeom& g, float s, hipStream_t st);
 int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const bf16* dY, int64_t lddy, bf16* dX,
                      int64_t lddx, const bf16* acc, int64_t ldacc, float* dW, float* dbias, float* slab, const ConvGeom& g,

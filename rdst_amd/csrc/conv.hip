@@ -131,7 +131,7 @@ template <typename T>
 int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr, T* Y,
           int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    if (int rc = conv_c1_fwd_bf16(X, ldx, in_act, Wc, bias, R, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+    if (int rc = conv_c1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
   }
   if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
   ConvA<T> la{X, ldx, g, in_act};

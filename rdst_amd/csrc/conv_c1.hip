@@ -48,6 +48,14 @@ __device__ __forceinline__ C1Lane c1_lane(int grp, int Cin) {
   if (!l.on) { l.c0 = 0; l.lo = 8; }
   return l;
 }
+__device__ __forceinline__ void c1_advance(const ConvGeom& g, int& b, int& y, int& x, int step) {
+  x += step;
+  while (x >= g.W) {
+    x -= g.W;
+    if (++y == g.H) { y = 0; ++b; }
+  }
+  if (b >= g.B) { b = g.B - 1; }   // past the end (a lane of the last, ragged step): any valid pixel, masked by `valid`
+}
 __device__ __forceinline__ void c1_weights(const float* W, const C1Lane& l, float (&w)[8][9]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e)
@@ -66,20 +74,24 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_fwd_kernel(const C1Args p)
   c1_weights(p.W, l, w);
   const float b0 = p.bias ? p.bias[0] : 0.f;
   const int64_t P = g.pixels();
+  const int64_t rs = (int64_t)g.W * p.ldx, rsy = (int64_t)g.W * p.lddy;
+  (void)rs; (void)rsy;
   const int64_t beg = (int64_t)blockIdx.x * p.pix_per_wg, end = beg + p.pix_per_wg < P ? beg + p.pix_per_wg : P;
-  for (int64_t base = beg + wave * 8; base < end; base += (C1_THREADS / 64) * 8) {
+  // the lane's pixel advances by 32 per step: one decode (integer divisions) up front, carries afterwards
+  int b, y, x;
+  g.decode(beg + wave * 8 + ps < P ? beg + wave * 8 + ps : P - 1, b, y, x);
+  for (int64_t base = beg + wave * 8; base < end; base += (C1_THREADS / 64) * 8, c1_advance(g, b, y, x, (C1_THREADS / 64) * 8)) {
     const int64_t pix = base + ps;
     const bool valid = pix < end;
-    int b, y, x;
-    g.decode(valid ? pix : beg, b, y, x);
     u32x4_a4 v[9];
     bool ok[9];
+    const bf16* ctr = p.X + (((int64_t)b * g.H + y) * g.W + x) * p.ldx + l.c0;   // neighbours are offsets from the centre
+    const bool yo[3] = {y > 0, true, y + 1 < g.H}, xo[3] = {x > 0, true, x + 1 < g.W};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-      ok[t] = valid && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
-      v[t] = *reinterpret_cast<const u32x4_a4*>(p.X + (((int64_t)b * g.H + yc) * g.W + xc) * p.ldx + l.c0);
+      ok[t] = valid && yo[t / 3] && xo[t % 3];
+      const int64_t off = (int64_t)(t / 3 - 1) * rs + (int64_t)(t % 3 - 1) * p.ldx;
+      v[t] = *reinterpret_cast<const u32x4_a4*>(ok[t] ? ctr + off : ctr);
     }
     float acc = 0.f;
 #pragma unroll
@@ -105,20 +117,24 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_dgrad_kernel(const C1Args 
   float w[8][9];
   c1_weights(p.W, l, w);
   const int64_t P = g.pixels();
+  const int64_t rs = (int64_t)g.W * p.ldx, rsy = (int64_t)g.W * p.lddy;
+  (void)rs; (void)rsy;
   const int64_t beg = (int64_t)blockIdx.x * p.pix_per_wg, end = beg + p.pix_per_wg < P ? beg + p.pix_per_wg : P;
-  for (int64_t base = beg + wave * 8; base < end; base += (C1_THREADS / 64) * 8) {
+  // the lane's pixel advances by 32 per step: one decode (integer divisions) up front, carries afterwards
+  int b, y, x;
+  g.decode(beg + wave * 8 + ps < P ? beg + wave * 8 + ps : P - 1, b, y, x);
+  for (int64_t base = beg + wave * 8; base < end; base += (C1_THREADS / 64) * 8, c1_advance(g, b, y, x, (C1_THREADS / 64) * 8)) {
     const int64_t pix = base + ps;
     const bool valid = pix < end;
-    int b, y, x;
-    g.decode(valid ? pix : beg, b, y, x);
     // dX[q] = sum_tap dY[q - (tap offset)] W[tap]
     float dy[9];
+    const bf16* yctr = p.dY + (((int64_t)b * g.H + y) * g.W + x) * p.lddy;
+    const bool yo[3] = {y + 1 < g.H, true, y > 0}, xo[3] = {x + 1 < g.W, true, x > 0};   // tap t reads the pixel at MINUS its offset
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
-      const bool ok = valid && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
-      const float v = __bfloat162float(p.dY[(((int64_t)b * g.H + yc) * g.W + xc) * p.lddy]);
+      const bool ok = valid && yo[t / 3] && xo[t % 3];
+      const int64_t off = -((int64_t)(t / 3 - 1) * rsy + (int64_t)(t % 3 - 1) * p.lddy);
+      const float v = __bfloat162float(*(ok ? yctr + off : yctr));
       dy[t] = ok ? v * p.s : 0.f;
     }
     float o[8];
@@ -160,21 +176,25 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_wgrad_kernel(const C1Args 
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[e][t] = 0.f;
   const int64_t P = g.pixels();
+  const int64_t rs = (int64_t)g.W * p.ldx, rsy = (int64_t)g.W * p.lddy;
+  (void)rs; (void)rsy;
   const int64_t beg = (int64_t)blockIdx.x * p.pix_per_wg, end = beg + p.pix_per_wg < P ? beg + p.pix_per_wg : P;
-  for (int64_t base = beg + wave * 8; base < end; base += (C1_THREADS / 64) * 8) {
+  // the lane's pixel advances by 32 per step: one decode (integer divisions) up front, carries afterwards
+  int b, y, x;
+  g.decode(beg + wave * 8 + ps < P ? beg + wave * 8 + ps : P - 1, b, y, x);
+  for (int64_t base = beg + wave * 8; base < end; base += (C1_THREADS / 64) * 8, c1_advance(g, b, y, x, (C1_THREADS / 64) * 8)) {
     const int64_t pix = base + ps;
     const bool valid = pix < end;
-    int b, y, x;
-    g.decode(valid ? pix : beg, b, y, x);
     // dW[c][tap] += X[q][c] dY[q - (tap offset)]   (q = input pixel)
-    const u32x4_a4 xv = *reinterpret_cast<const u32x4_a4*>(p.X + (valid ? pix : beg) * p.ldx + l.c0);
+    const u32x4_a4 xv = *reinterpret_cast<const u32x4_a4*>(p.X + (((int64_t)b * g.H + y) * g.W + x) * p.ldx + l.c0);
     float dy[9];
+    const bf16* yctr = p.dY + (((int64_t)b * g.H + y) * g.W + x) * p.lddy;
+    const bool yo[3] = {y + 1 < g.H, true, y > 0}, xo[3] = {x + 1 < g.W, true, x > 0};   // tap t reads the pixel at MINUS its offset
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
-      const bool ok = valid && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
-      const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
-      const float v = __bfloat162float(p.dY[(((int64_t)b * g.H + yc) * g.W + xc) * p.lddy]);
+      const bool ok = valid && yo[t / 3] && xo[t % 3];
+      const int64_t off = -((int64_t)(t / 3 - 1) * rsy + (int64_t)(t % 3 - 1) * p.lddy);
+      const float v = __bfloat162float(*(ok ? yctr + off : yctr));
       dy[t] = ok ? v : 0.f;
     }
     float f[8];
@@ -223,6 +243,46 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_wgrad_kernel(const C1Args 
   }
 }
 
+// 1x1 conv with one input and one output channel (MeanShift on a single-channel image, common.py:151-167): an
+// elementwise affine map.  out = (in * w) * s (+ b * s) (+ add); 8 elements per thread when the rows are contiguous.
+__global__ void __launch_bounds__(256) conv_pw11_kernel(const bf16* __restrict__ in, int64_t ldi, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const bf16* add, int64_t lda, bf16* out,
+                                                        int64_t ldo, int64_t P, float s, int vec) {
+  const float w = W[0] * s, b = bias ? bias[0] * s : 0.f;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (vec) {
+    const int64_t e0 = i * 8;
+    if (e0 + 8 <= P) {
+      float f[8];
+      c1_unpack8(*reinterpret_cast<const u32x4_a4*>(in + e0), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], w, b);
+      if (add) {
+        float a[8];
+        c1_unpack8(*reinterpret_cast<const u32x4_a4*>(add + e0), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += a[e];
+      }
+      u32x4_a4 u;
+      u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]); u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+      *reinterpret_cast<u32x4_a4*>(out + e0) = u;
+    } else {
+      for (int64_t e = e0; e < P; ++e) out[e] = __float2bfloat16(fmaf(__bfloat162float(in[e]), w, b) + (add ? __bfloat162float(add[e]) : 0.f));
+    }
+    return;
+  }
+  if (i < P) out[i * ldo] = __float2bfloat16(fmaf(__bfloat162float(in[i * ldi]), w, b) + (add ? __bfloat162float(add[i * lda]) : 0.f));
+}
+
+int pw11_launch(const bf16* in, int64_t ldi, const float* W, const float* bias, const bf16* add, int64_t lda, bf16* out,
+                int64_t ldo, int64_t P, float s, hipStream_t st, const char* what) {
+  const bool vec = ldi == 1 && ldo == 1 && (!add || lda == 1) && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)add) & 3) == 0;
+  const int64_t n = vec ? (P + 7) / 8 : P;
+  hipLaunchKernelGGL(conv_pw11_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, ldi, W, bias, add, lda, out, ldo, P, s,
+                     vec ? 1 : 0);
+  return rdst_launch_status(what);
+}
+
 bool c1_ok(const ConvGeom& g, int in_act) {
   return g.Cout == 1 && g.ks == 3 && g.r == 1 && in_act == 0 && g.Cin >= 8 && g.Cin <= 64 && (g.Cin & 1) == 0;
 }
@@ -236,8 +296,10 @@ int c1_grid(const ConvGeom& g, int64_t& ppw, int cap) {
 
 }  // namespace
 
-int conv_c1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, bf16* Y,
+int conv_c1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr, bf16* Y,
                      int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
+  if (g.Cin == 1 && g.Cout == 1 && g.ks == 1 && g.r == 1 && in_act == 0)
+    return pw11_launch(X, ldx, Wc, bias, R, ldr, Y, ldy, g.pixels(), s, st, "conv_pw11_fwd");
   if (!c1_ok(g, in_act) || R || ((uintptr_t)X & 3) || (ldx & 1)) return RDST_ENOTSUP;
   C1Args p{};
   p.X = X; p.ldx = ldx; p.W = Wc; p.bias = bias; p.Y = Y; p.ldy = ldy; p.g = g; p.s = s;
@@ -252,6 +314,8 @@ size_t conv_c1_slab_floats(int Cin) { return (size_t)(1024 + 1) * (Cin * 9 + 1);
 int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const bf16* dY, int64_t lddy, bf16* dX,
                      int64_t lddx, const bf16* acc, int64_t ldacc, float* dW, float* dbias, float* slab, const ConvGeom& g,
                      float s, hipStream_t st) {
+  if (g.Cin == 1 && g.Cout == 1 && g.ks == 1 && g.r == 1 && in_act == 0 && !dW && !dbias && dX)   // frozen MeanShift: dX = dY w s (+ dX_add)
+    return pw11_launch(dY, lddy, Wc, nullptr, acc, ldacc, dX, lddx, g.pixels(), s, st, "conv_pw11_dgrad");
   if (!c1_ok(g, in_act) || ((uintptr_t)X & 3) || (ldx & 1) || ((uintptr_t)dX & 3) || (lddx & 1) || ((uintptr_t)acc & 3) || (ldacc & 1))
     return RDST_ENOTSUP;
   C1Args p{};

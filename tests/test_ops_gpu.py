@@ -95,6 +95,7 @@ CONV = [  # B, H, W, Cin, Cout, k, act, residual, scale, shuffle
     (2, 6, 6, 37, 12, 1, 2, False, 1.0, 1),    # 1x1 conv reading through LeakyReLU ('3conv')
     (1, 6, 6, 48, 108, 3, 0, False, 1.0, 3),   # x3 upsampler
     (2, 5, 5, 3, 3, 1, 0, False, 1.0, 1),      # MeanShift
+    (2, 16, 25, 1, 1, 1, 0, True, 0.5, 1),     # MeanShift on a single-channel image (elementwise kernel), + residual, ragged tail
 ]
 
 
