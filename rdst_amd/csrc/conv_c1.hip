@@ -85,13 +85,12 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_fwd_kernel(const C1Args p)
     const bool valid = pix < end;
     u32x4_a4 v[9];
     bool ok[9];
-    const bf16* ctr = p.X + (((int64_t)b * g.H + y) * g.W + x) * p.ldx + l.c0;   // neighbours are offsets from the centre
-    const bool yo[3] = {y > 0, true, y + 1 < g.H}, xo[3] = {x > 0, true, x + 1 < g.W};
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      ok[t] = valid && yo[t / 3] && xo[t % 3];
-      const int64_t off = (int64_t)(t / 3 - 1) * rs + (int64_t)(t % 3 - 1) * p.ldx;
-      v[t] = *reinterpret_cast<const u32x4_a4*>(ok[t] ? ctr + off : ctr);
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      ok[t] = valid && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
+      const int yc = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy), xc = xx < 0 ? 0 : (xx >= g.W ? g.W - 1 : xx);
+      v[t] = *reinterpret_cast<const u32x4_a4*>(p.X + (((int64_t)b * g.H + yc) * g.W + xc) * p.ldx + l.c0);
     }
     float acc = 0.f;
 #pragma unroll
