@@ -30,15 +30,26 @@ def _dim_modifier(input_dim, growth_rate, norm_layer, pre_norm):
     return nn.Sequential(nn.Linear(input_dim, growth_rate), norm_layer(growth_rate))
 
 
-def _apply_dim_modifier(seq, x, out_scale=1.0):
+def _apply_dim_modifier(seq, x, out_scale=1.0, out_slot=None):
+    """out_slot = (ops.DenseBuffer, first channel): the last op writes straight into the RDSTB's dense buffer."""
     if isinstance(seq, nn.Identity):
+        if out_slot is not None:
+            raise NotImplementedError("rdst_amd: dense slot behind an Identity tail")
         return x if out_scale == 1.0 else x * out_scale
     a, b = seq[0], seq[1]
     if isinstance(b, nn.Linear):  # (norm, linear): one fused op
         w, bb = _ln_params(a)
-        return ops.ln_linear(x, w, bb, b.weight, b.bias, out_scale=out_scale)
+        return ops.ln_linear(x, w, bb, b.weight, b.bias, out_scale=out_scale, out_slot=out_slot)
     y = ops.ln_linear(x, None, None, a.weight, a.bias)  # (linear, norm)
-    return _norm_only(y, b, out_scale=out_scale)
+    return _norm_only(y, b, out_scale=out_scale, out_slot=out_slot)
+
+
+def _slot_ok(seq):
+    """Can this tail write into a dense slot?  (Needs a fused op at its end: a Linear, or a LayerNorm that is not Identity.)"""
+    if isinstance(seq, nn.Identity):
+        return False
+    b = seq[1]
+    return isinstance(b, nn.Linear) or isinstance(b, nn.LayerNorm)
 
 
 class DenseSTLayer(nn.Module):
@@ -73,17 +84,28 @@ class DenseSTLayer(nn.Module):
         self.input_resolution = input_resolution
         self.dense_scale = dense_scale
         self.growth_rate = hidden_dim
+        self.growth_rate_out = growth_rate   # channels forward() appends (not a reference attribute)
         self.depth = depth
         self.pre_norm = pre_norm
 
-    def new_features(self, x, x_size):
+    def new_features(self, x, x_size, out_slot=None):
         """dense_scale * tail(body(head(x))): the channels this layer appends."""
         y = _apply_dim_modifier(self.head, x)
         y = self.body(y, x_size)
-        return _apply_dim_modifier(self.tail, y, out_scale=self.dense_scale)
+        return _apply_dim_modifier(self.tail, y, out_scale=self.dense_scale, out_slot=out_slot)
 
     def forward(self, x, x_size):
         return torch.cat((x, self.new_features(x, x_size)), 2)
+
+    def forward_dense(self, x, x_size, buf):
+        """The same with x already lying in the first channels of the RDSTB's dense buffer: the new channels are
+        written next to it in place and the wider view is returned (no copy of x)."""
+        if not _slot_ok(self.tail):
+            new = self.new_features(x, x_size)
+            buf.slot(x.shape[-1], new.shape[-1]).copy_(new.detach())   # values only: `new` itself stays in the graph
+            return ops.dense_join(x, new, buf)
+        new = self.new_features(x, x_size, out_slot=(buf, x.shape[-1]))
+        return ops.dense_join(x, new, buf)
 
 
 def _res_connection(resi_connection, cin, cout):
@@ -142,9 +164,17 @@ class RDSTB(nn.Module):
     def forward(self, x, x_size):
         B, L, C = x.shape
         H, W = x_size
-        y = x
-        for m in self.body:
-            y = m(y, x_size)
+        if x.is_cuda and len(self.body) > 0:
+            # dense buffer: every DenseSTLayer appends its channels in place (no torch.cat of the growing prefix)
+            width = C + sum(m.growth_rate_out for m in self.body)
+            buf = ops.DenseBuffer((B, L), width, x.dtype, x.device)
+            y = ops.into_dense(x, buf)
+            for m in self.body:
+                y = m.forward_dense(y, x_size, buf)
+        else:
+            y = x
+            for m in self.body:
+                y = m(y, x_size)
         out = _apply_res_connection(self.conv, y.view(B, H, W, y.shape[-1]), residual=x.view(B, H, W, C),
                                     out_scale=self.residual_scale)
         return out.view(B, L, C)

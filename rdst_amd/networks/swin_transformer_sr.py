@@ -43,12 +43,15 @@ def _ln_params(norm):
     raise NotImplementedError(f"rdst_amd: norm layer {type(norm).__name__} (nn.LayerNorm or nn.Identity)")
 
 
-def _norm_only(x, norm, out_scale=1.0, residual=None):
+def _norm_only(x, norm, out_scale=1.0, residual=None, out_slot=None):
     w, b = _ln_params(norm)
     if w is None:
         y = x if out_scale == 1.0 else x * out_scale
-        return y if residual is None else y + residual
-    return ops.ln_linear(x, w, b, None, None, out_scale=out_scale, residual=residual)
+        y = y if residual is None else y + residual
+        if out_slot is not None:
+            raise NotImplementedError("rdst_amd: dense slot without a LayerNorm")
+        return y
+    return ops.ln_linear(x, w, b, None, None, out_scale=out_scale, residual=residual, out_slot=out_slot)
 
 
 class Mlp(nn.Module):

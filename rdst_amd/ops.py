@@ -305,7 +305,7 @@ def _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy, lddy, dx, lddx, 
 # ------------------------------------------------------------------------------------------------
 class _LnLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, weight, bias, residual, in_act, out_scale):
+    def forward(ctx, x, ln_w, ln_b, weight, bias, residual, in_act, out_scale, out_slot=None):
         _need_gpu(x, ln_w, ln_b, weight, bias, residual)
         lib = _lib.load()
         K = x.shape[-1]
@@ -313,7 +313,14 @@ class _LnLinear(torch.autograd.Function):
         M = x.numel() // K
         x_r, ldx = _rows(x)
         lw, lb, w, b = _param(ln_w), _param(ln_b), _param(weight), _param(bias)
-        y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        if out_slot is None:
+            y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+            ldy = N
+        else:   # (DenseBuffer, first channel): the kernel writes its N channels straight into the dense buffer
+            y = out_slot[0].slot(out_slot[1], N)
+            ldy = out_slot[0].width
+            if y.shape[:-1] != x.shape[:-1] or y.dtype != x.dtype:
+                raise ValueError("rdst_amd.ln_linear: out_slot does not match the input's rows / dtype")
         r_r, ldr = (None, 0)
         if residual is not None:
             if residual.dtype != x.dtype:
@@ -321,7 +328,7 @@ class _LnLinear(torch.autograd.Function):
             r_r, ldr = _rows(residual)
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if lw is not None else None
         _lib.check(lib.rdst_ln_linear_fwd(x_r.data_ptr(), ldx, _ptr(lw), _ptr(lb), int(in_act), _ptr(w), _ptr(b),
-                                          _ptr(r_r), ldr, y.data_ptr(), N, _ptr(stats), M, K, N, float(out_scale),
+                                          _ptr(r_r), ldr, y.data_ptr(), ldy, _ptr(stats), M, K, N, float(out_scale),
                                           _dtype_code(x), _stream()), "rdst_ln_linear_fwd")
         ctx.save_for_backward(x_r, lw, lb, w, stats)
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
@@ -345,16 +352,64 @@ class _LnLinear(torch.autograd.Function):
         _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy_r, lddy, dx, K, None, 0, dw, db, dlw, dlb, M, K, N,
                          out_scale, _dtype_code(x), dev)
         dres = dy if (has_res and need[5]) else None
-        return dx, dlw, dlb, dw, db, dres, None, None
+        return dx, dlw, dlb, dw, db, dres, None, None, None
+
+
+class DenseBuffer:
+    """The dense concat buffer of an RDSTB (rdst_variations.py:339-340, :436-441): ONE (rows, width) tensor whose
+    channel ranges the DenseSTLayers fill in place, so no torch.cat ever copies the growing prefix.  It is not an
+    autograd tensor; the ops write it through raw pointers (no version-counter traffic) and hand out views."""
+
+    def __init__(self, lead, width, dtype, device):
+        self.width = int(width)
+        self.t = torch.empty(tuple(lead) + (self.width,), dtype=dtype, device=device)
+
+    def slot(self, c0, n):
+        return self.t[..., c0:c0 + n]
+
+
+class _IntoDense(torch.autograd.Function):
+    """x -> the first channels of a dense buffer (the only copy an RDSTB makes)."""
+
+    @staticmethod
+    def forward(ctx, x, buf):
+        v = buf.slot(0, x.shape[-1])
+        v.copy_(x)
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _DenseJoin(torch.autograd.Function):
+    """cat(prefix, new) where both already lie side by side in the dense buffer: returns the wider view."""
+
+    @staticmethod
+    def forward(ctx, prefix, new, buf):
+        ctx.c = prefix.shape[-1]
+        return buf.slot(0, prefix.shape[-1] + new.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.c], g[..., ctx.c:], None
+
+
+def into_dense(x: torch.Tensor, buf: DenseBuffer) -> torch.Tensor:
+    return _IntoDense.apply(x, buf)
+
+
+def dense_join(prefix: torch.Tensor, new: torch.Tensor, buf: DenseBuffer) -> torch.Tensor:
+    return _DenseJoin.apply(prefix, new, buf)
 
 
 def ln_linear(x: torch.Tensor, ln_w: Optional[torch.Tensor], ln_b: Optional[torch.Tensor],
               weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], *, in_act: int = ACT_NONE,
-              residual: Optional[torch.Tensor] = None, out_scale: float = 1.0) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, out_scale: float = 1.0, out_slot=None) -> torch.Tensor:
     """y = (f(x) @ weight^T + bias) * out_scale + residual, f = LayerNorm (ln_w given) or the
     activation ``in_act`` or identity; weight None = LayerNorm only.  One fused HIP op replacing the
     reference's LayerNorm/Linear/GELU/add sequences (see include/rdst_hip.h, K3)."""
-    return _LnLinear.apply(x, ln_w, ln_b, weight, bias, residual, in_act, out_scale)
+    return _LnLinear.apply(x, ln_w, ln_b, weight, bias, residual, in_act, out_scale, out_slot)
 
 
 # ------------------------------------------------------------------------------------------------
