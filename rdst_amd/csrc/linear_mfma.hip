@@ -1289,20 +1289,22 @@ __global__ void __launch_bounds__(256) wgrad_sum_kernel(const float* __restrict_
   for (int k = 0; k < 8; ++k) a += part[k][o];
   G[i] = a;
 }
-// Step 2, one block per 32 LayerNorm channels:  dW[n][k] = s (gamma_k G[n][k] + beta_k db[n]),  dbias[n] = s db[n],
+// Step 2, one block per 8 LayerNorm channels (8 x 128 threads: the whole column of N <= 384 rows is in flight in three
+// rounds of loads; one block per 32 channels walked it in 11 dependent rounds and took 7 us for microseconds of work):
+//   dW[n][k] = s (gamma_k G[n][k] + beta_k db[n]),  dbias[n] = s db[n],
 //   d(gamma)[k] = s sum_n W[n][k] G[n][k],   d(beta)[k] = s sum_n W[n][k] db[n]      (fixed summation order)
 __global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                int N, int K, int Kx, float s, float* __restrict__ dW,
                                                                float* __restrict__ dbias, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
-  __shared__ float pg[32][33], pb[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + tx;
+  __shared__ float pg[128][9], pb[128][9], qg[8][9], qb[8][9];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int k = blockIdx.x * 8 + tx;
   const float gk = k < K ? gamma[k] : 0.f, bk = k < K ? beta[k] : 0.f;
   float ag = 0.f, ab = 0.f;
-#pragma unroll 4
-  for (int n = ty; n < N; n += 32) {
+#pragma unroll 3
+  for (int n = ty; n < N; n += 128) {
     const float db = G[(int64_t)n * Kx + K];
     if (k < K) {
       const float g = G[(int64_t)n * Kx + k], w = Wt[(int64_t)n * K + k];
@@ -1315,10 +1317,18 @@ __global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __re
   pg[ty][tx] = ag;
   pb[ty][tx] = ab;
   __syncthreads();
+  if (ty < 8) {   // two fixed-order levels: 8 partial sums of 16 rows, then their sum
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a += pg[ty * 16 + j][tx]; b += pb[ty * 16 + j][tx]; }
+    qg[ty][tx] = a;
+    qb[ty][tx] = b;
+  }
+  __syncthreads();
   if (ty == 0 && k < K) {
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) { a += pg[j][tx]; b += pb[j][tx]; }
+    for (int j = 0; j < 8; ++j) { a += qg[j][tx]; b += qb[j][tx]; }
     if (dgamma) dgamma[k] = s * a;
     if (dbeta) dbeta[k] = s * b;
   }
@@ -1338,7 +1348,7 @@ int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t 
 // launcher of the LayerNorm finish for other translation units (mlp_mfma.hip)
 int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
                            float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st) {
-  hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 31) / 32), dim3(1024), 0, st, G, Wt, ln_w, ln_b, N, K, K + 1, s, dW, dbias,
+  hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 7) / 8), dim3(1024), 0, st, G, Wt, ln_w, ln_b, N, K, K + 1, s, dW, dbias,
                      dln_w, dln_b);
   return rdst_launch_status("wgrad_ln_finish");
 }
@@ -1456,7 +1466,7 @@ int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, co
   if (lnfin) {
     hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, tot, G);
     if (int rc = rdst_launch_status("wgrad_sum")) return rc;
-    hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 31) / 32), dim3(1024), 0, st, G, Wt_fin, ln_w, ln_b, N, K, p.Kx, s, dW,
+    hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 7) / 8), dim3(1024), 0, st, G, Wt_fin, ln_w, ln_b, N, K, p.Kx, s, dW,
                        dbias, dln_w, dln_b);
     return rdst_launch_status("wgrad_ln_finish");
   }
