@@ -41,7 +41,9 @@ struct MlpArgs {
 template <int NCT> struct MlpCfg {
   static constexpr int NJ = 2 * NCT, NT = 64 * NJ, CP = 32 * NCT, JP = 32 * NJ;
   static constexpr int KC = CP / 16, KJ = JP / 16, PK = CP / 8;   // PK: 16-B chunk slots per row = NT / 32
-  static constexpr int LDW = CP * 2 + 16, LDX = CP * 2 + 16, LDH = 64;
+  // row strides: 80 (mod 256) for the 256-B rows of C = 120 — 272 would stack the four rows of a transposed read on
+  // the same banks (see lnlin_bwd_kernel) — and still an odd number of 16-B slots for the b128 row reads
+  static constexpr int LDW = NCT == 4 ? 336 : CP * 2 + 16, LDX = LDW, LDH = 64;
   static constexpr int OFF_W1 = 0, OFF_XH = OFF_W1 + JP * LDW, OFF_DY = OFF_XH + 32 * LDX, OFF_DH = OFF_DY + 32 * LDX,
                        OFF_B1 = OFF_DH + JP * LDH, OFF_SM = OFF_B1 + JP * 4, OFF_RED = OFF_SM + 32 * 4,
                        SMEM = OFF_RED + NCT * 32 * 8;
@@ -849,25 +851,51 @@ __global__ void __launch_bounds__(256) mlp_sum_kernel(const float* __restrict__ 
 //   phase 3  waves 0..K/32: dX-hat^T = (W gamma)^T dY^T (W gamma read transposed from its one LDS image, dY rows as
 //            they lie), LayerNorm backward, + dX_add (the residual fan-out), 16-B row stores
 // G (N, K+1) goes through the same sum / LayerNorm-finish kernels as linear_wgrad_ln_mfma.
+// loads through an explicitly GLOBAL pointer (address space 1): the value is copied out of the qualified lvalue here
+typedef __attribute__((address_space(1))) const char* gcp;
+__device__ __forceinline__ u32x4_a4 gload16(gcp q) {
+  const u32x4_a4 v = *reinterpret_cast<__attribute__((address_space(1))) const u32x4_a4*>(q);
+  return v;
+}
+__device__ __forceinline__ float2 gload8(gcp q) {
+  const float x = *reinterpret_cast<__attribute__((address_space(1))) const float*>(q);
+  const float y = *reinterpret_cast<__attribute__((address_space(1))) const float*>(q + 4);
+  return make_float2(x, y);
+}
+
+__host__ __device__ inline int lnlin_ldy(int NP) {   // dY tile row stride: see the stride note in the kernel
+  const int b = NP * 2 + 16;
+  return (b & 255) < 48 ? b + 64 : b;
+}
+
 struct LnLinArgs {
   const bf16* X; int64_t ldx; const float* stats; const float* lnw; const float* W;
   const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx; const bf16* Acc; int64_t ldacc;
   float* slab; int64_t slab_stride;
   int64_t M; int K; int N; int NW; int NWV; int64_t ntiles; int tiles_per_wg;   // NW n-tiles, NWV >= NW waves launched
+  unsigned long long* stamps;   // RDST_LNLIN_STAMPS=n (debug)
 };
 
 // LN = false: plain Linear (proj): x-hat is x itself, no LayerNorm backward, W unscaled
 template <int NCT, bool LN>
 __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int CP = 32 * NCT, PK = CP / 8, LDW = CP * 2 + 16, LDX = LDW;
+  // LDS row strides.  The tiles are read TRANSPOSED (4 consecutive rows x 64 B per 16 lanes): a stride of 16 (mod 256)
+  // — 272 B for the 256-B rows of C = 120 — stacks the four rows on the same banks (4-way conflicts, measured: the
+  // whole phase was LDS-throughput bound); 80 (mod 256) keeps b128 row reads conflict-free too (odd 16-B slot count)
+  constexpr int CP = 32 * NCT, PK = CP / 8, LDW = NCT == 4 ? 288 : CP * 2 + 16, LDX = NCT == 4 ? 336 : CP * 2 + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
   const int K = p.K, N = p.N, NW = p.NW, NT = 64 * p.NWV;
-  const int NP = 32 * NW, KN = 2 * NW, LDY = NP * 2 + 16;
+  const int NP = 32 * NW, KN = 2 * NW, LDY = lnlin_ldy(NP);
   const int OFF_XH = NP * LDW, OFF_AC = OFF_XH + 32 * LDX, OFF_DY = OFF_AC + 32 * LDX, OFF_SM = OFF_DY + 32 * LDY,
             OFF_RED = OFF_SM + 128;
   float* sm = reinterpret_cast<float*>(smem + OFF_SM);
   float* red = reinterpret_cast<float*>(smem + OFF_RED);
+  int nst = 0;
+  auto stamp = [&]() {
+    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+  };
+  stamp();
 
   // ---- prologue: zero padding, ones column, W*gamma image ----
   lds_zero16(smem, OFF_SM, tid, NT);
@@ -910,13 +938,13 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   }
 
   // ---- loader plan: up to 4 chunk slots per thread over [dY chunks | x chunks | dX_add chunks] (the x range is no
-  // longer than the thread count, so a thread owns at most one x chunk and needs one statistics pair) ----
+  // longer than the thread count, so a thread owns at most one x chunk and needs one statistics pair).  Kept in
+  // TWO registers per slot (meta = byte offset in the row | tile row << 16 | kind << 24 | aligned << 28, LDS offset):
+  // the kernel runs three waves per SIMD and every register not spent here lets the LDS reads of the phases below
+  // be issued in batches instead of one round trip per MFMA ----
   const int PKY = (N * 2 + 15) >> 4;
   const int nY = 32 * PKY, nX = 32 * PK, nA = p.Acc ? 32 * PK : 0;
-  const char* gp[4];
-  int lds_off[4], lrow[4], kind[4];   // kind: 0 dY, 1 x, 2 dX_add, -1 none
-  bool al[4];
-  int64_t gstep[4];
+  int lds_off[4], meta[4];   // kind: 0 dY, 1 x, 2 dX_add, 7 none
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     // LN form (wide dY): slot u has a fixed kind — 0, 1: dY, 2: x, 3: dX_add; plain form: slots dealt out in order
@@ -930,33 +958,58 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     const bool on = kd >= 0 && o < rowbytes;
     if (o + 16 > rowbytes) o = rowbytes - 16;
     if (!on) o = 0;
-    kind[u] = on ? kd : -1;
-    lrow[u] = row & 31;
-    al[u] = (o & 15) == 0;
-    lds_off[u] = (kd == 0 ? OFF_DY + lrow[u] * LDY : (kd == 2 ? OFF_AC : OFF_XH) + lrow[u] * LDX) + o;
-    const bf16* base = kd == 0 ? p.dY : kd == 2 ? p.Acc : p.X;
-    const int64_t ld = kd == 0 ? p.lddy : kd == 2 ? p.ldacc : p.ldx;
-    gp[u] = reinterpret_cast<const char*>(base) + o;   // + row * ld * 2 at seek
-    gstep[u] = ld * 2;
+    const int lr = row & 31;
+    meta[u] = o | (lr << 16) | ((on ? kd : 7) << 24) | (((o & 15) == 0 ? 1 : 0) << 28);
+    lds_off[u] = (kd == 0 ? OFF_DY + lr * LDY : (kd == 2 ? OFF_AC : OFF_XH) + lr * LDX) + o;
   }
-  const float* sp = p.stats;
+  auto m_off = [](int m) { return m & 0xffff; };
+  auto m_row = [](int m) { return (m >> 16) & 31; };
+  auto m_kind = [](int m) { return (m >> 24) & 7; };
+  auto m_al = [](int m) { return ((m >> 28) & 1) != 0; };
+  const uint32_t ldb_y = (uint32_t)(p.lddy * 2), ldb_x = (uint32_t)(p.ldx * 2), ldb_a = (uint32_t)(p.ldacc * 2);   // row strides, bytes
   u32x4_a4 rd[4];
   float2 rst = make_float2(0.f, 1.f);
-  const char* cur[4];
-  const float* scur = nullptr;
-  auto seek = [&](int64_t tile) {
+  // explicitly GLOBAL pointers: a pointer that went through an integer or a select is a flat pointer to the compiler,
+  // flat loads count on the LDS counter as well, and the next barrier then waits for the whole prefetch (measured)
+  const gcp base_s = (gcp)(uintptr_t)p.stats;
+  const uint32_t Mu = (uint32_t)p.M;
+  // plain form (dynamic slot kinds): one global pointer per slot, set up once (a run-time select between base
+  // addresses inside the loop was lowered to a scratch table and flat loads)
+  const char* gp[4];
+  uint32_t gld[4];
+  if constexpr (!LN) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      int64_t row = tile * 32 + lrow[u];
-      row = row < p.M ? row : p.M - 1;
-      cur[u] = gp[u] + row * gstep[u];
-      if (LN && kind[u] == 1) scur = sp + 2 * row;
+      const int kd = m_kind(meta[u]);
+      const bf16* b0 = kd == 0 ? p.dY : kd == 2 ? p.Acc : p.X;
+      gp[u] = reinterpret_cast<const char*>(b0 ? b0 : p.X) + m_off(meta[u]);
+      gld[u] = kd == 0 ? ldb_y : kd == 2 ? ldb_a : ldb_x;
     }
-  };
-  auto fetch = [&]() {
+  }
+  auto fetch = [&](int64_t tile) {   // byte offsets fit 32 bits (checked by the launcher); no conditional loads either:
+                                     // a lane-masked load is a branch with a wait at its end
+    if constexpr (!LN) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) rd[u] = *reinterpret_cast<const u32x4_a4*>(cur[u]);
-    if (LN && scur) rst = *reinterpret_cast<const float2*>(scur);
+      for (int u = 0; u < 4; ++u) {
+        uint32_t row = (uint32_t)(tile * 32) + (uint32_t)m_row(meta[u]);
+        row = row < Mu ? row : Mu - 1;
+        rd[u] = *reinterpret_cast<const u32x4_a4*>(gp[u] + (size_t)(row * gld[u]));
+      }
+      return;
+    }
+    uint32_t srow = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      // LN form: the slot's kind is a compile-time constant (0, 1: dY, 2: x, 3: dX_add) — no pointer selects
+      const int kd = u < 2 ? 0 : u == 2 ? 1 : 2;
+      uint32_t row = (uint32_t)(tile * 32) + (uint32_t)m_row(meta[u]);
+      row = row < Mu ? row : Mu - 1;
+      const gcp base = kd == 0 ? (gcp)(uintptr_t)p.dY : kd == 2 ? (gcp)(uintptr_t)(p.Acc ? p.Acc : p.X) : (gcp)(uintptr_t)p.X;
+      const uint32_t ldb = kd == 0 ? ldb_y : kd == 2 ? ldb_a : ldb_x;
+      rd[u] = gload16(base + (row * ldb + (uint32_t)m_off(meta[u])));
+      srow = kd == 1 ? row : srow;
+    }
+    if (LN) rst = gload8(base_s + 8 * (size_t)srow);
   };
   auto put16 = [&](char* dst, const Pack16& v, bool aligned) {
     if (aligned) *reinterpret_cast<Pack16*>(dst) = v;
@@ -968,24 +1021,21 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   auto stash = [&](int64_t tile) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (kind[u] < 0) continue;
-      const bool valid = tile * 32 + lrow[u] < p.M;
+      if (m_kind(meta[u]) == 7) continue;
+      const int kd = LN ? (u < 2 ? 0 : u == 2 ? 1 : 2) : m_kind(meta[u]);
+      const bool valid = (uint32_t)(tile * 32) + (uint32_t)m_row(meta[u]) < Mu;
       Pack16 v;
-      if (LN && kind[u] == 1) {
+      if (LN && kd == 1) {
         float f[8];
         unpack8(rd[u], f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = valid ? (f[e] - rst.x) * rst.y : 0.f;
         v = MM::pack(f);
+        if (m_off(meta[u]) == 0) sm[m_row(meta[u])] = rst.y;
       } else {
         v.w[0] = valid ? rd[u].x : 0u; v.w[1] = valid ? rd[u].y : 0u; v.w[2] = valid ? rd[u].z : 0u; v.w[3] = valid ? rd[u].w : 0u;
       }
-      put16(smem + lds_off[u], v, al[u]);
-    }
-    if (LN) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (kind[u] == 1 && (lds_off[u] - OFF_XH) % LDX == 0) sm[lrow[u]] = rst.y;
+      put16(smem + lds_off[u], v, m_al(meta[u]));
     }
   };
 
@@ -1006,27 +1056,27 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
   const float invK = 1.0f / (float)K;
   __syncthreads();   // W image, ones column
-  if (t0 < t1) {
-    seek(t0);
-    fetch();
-  }
+  stamp();   // 1: prologue
+  if (t0 < t1) fetch(t0);
   for (int64_t tile = t0; tile < t1; ++tile) {
     stash(tile);
-    seek(tile + 1 < t1 ? tile + 1 : tile);
-    fetch();
+    fetch(tile + 1 < t1 ? tile + 1 : tile);   // every iteration defines the whole prefetch set
     __syncthreads();   // B1
+    stamp();   // staged
     // ---- phase 2 (waves that own an n-tile)
     if (wave < NW) {
-      Pack16 ya[2];
+      // every operand of the tile is read before the first MFMA (one LDS round trip, not one per MFMA)
+      Pack16 ya[2], xb[NCT][2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) ya[s] = lds_tr_pack(ytr + 16 * s * LDY, ytr + (16 * s + 4) * LDY);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const Pack16 xb = lds_tr_pack(xtr + 16 * s * LDX + ct * 64, xtr + (16 * s + 4) * LDX + ct * 64);
-          MM::mma(G[ct], ya[s], xb);   // rows = output features n, columns = channels (column K = d(bias))
-        }
+        for (int s = 0; s < 2; ++s) xb[ct][s] = lds_tr_pack(xtr + 16 * s * LDX + ct * 64, xtr + (16 * s + 4) * LDX + ct * 64);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) MM::mma(G[ct], ya[s], xb[ct][s]);   // rows = output features n, columns = channels (column K = d(bias))
     }
     // ---- phase 3
     f32x16 dx;
@@ -1035,14 +1085,20 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       f32x16 dx2;
 #pragma unroll
       for (int v = 0; v < 16; ++v) { dx[v] = 0.f; dx2[v] = 0.f; }
-#pragma unroll 2
-      for (int kk = 0; kk < KN; kk += 2) {
-        const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
-        const Pack16 yb = lds_pack(yrow + 32 * kk);
-        const Pack16 wa2 = lds_tr_pack(wtr + 16 * (kk + 1) * LDW, wtr + (16 * (kk + 1) + 4) * LDW);
-        const Pack16 yb2 = lds_pack(yrow + 32 * (kk + 1));
-        MM::mma(dx, wa, yb);   // rows = channels, columns = tokens
-        MM::mma(dx2, wa2, yb2);
+      for (int kk = 0; kk < KN; kk += 4) {   // KN = 2 NW: groups of four k-steps (the last group may hold two), read together
+        Pack16 wa[4], yb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k2 = kk + i < KN ? kk + i : KN - 1;
+          wa[i] = lds_tr_pack(wtr + 16 * k2 * LDW, wtr + (16 * k2 + 4) * LDW);
+          yb[i] = lds_pack(yrow + 32 * k2);
+        }
+        MM::mma(dx, wa[0], yb[0]);   // rows = channels, columns = tokens
+        MM::mma(dx2, wa[1], yb[1]);
+        if (kk + 2 < KN) {
+          MM::mma(dx, wa[2], yb[2]);
+          MM::mma(dx2, wa[3], yb[3]);
+        }
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) dx[v] += dx2[v];
@@ -1065,6 +1121,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       }
     }
     if (LN) __syncthreads();   // B3
+    stamp();   // phases 2, 3a
     if (wave < NCT) {
       float s1 = 0.f, s2 = 0.f;
       if (LN) {
@@ -1113,6 +1170,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       }
     }
     __syncthreads();   // B4
+    stamp();   // 3b
   }
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
   if (wave < NW)
@@ -1309,8 +1367,9 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3) || (ldx & 1) || (lddy & 1) ||
       (lddx & 1) || (ldacc & 1))
     return RDST_ENOTSUP;
-  const int CP = 32 * nct, LDW = CP * 2 + 16, NP = 32 * NW, LDY = NP * 2 + 16;
-  const int smem = NP * LDW + 2 * 32 * LDW + 32 * LDY + 128 + nct * 32 * 8;
+  if ((uint64_t)M * (uint64_t)(lddy > ldx ? (lddy > ldacc ? lddy : ldacc) : (ldx > ldacc ? ldx : ldacc)) * 2 >= (1ull << 31)) return RDST_ENOTSUP;   // 32-bit byte offsets in the loader
+  const int CP = 32 * nct, LDW = nct == 4 ? 288 : CP * 2 + 16, LDX = nct == 4 ? 336 : CP * 2 + 16, NP = 32 * NW, LDY = lnlin_ldy(NP);
+  const int smem = NP * LDW + 2 * 32 * LDX + 32 * LDY + 128 + nct * 32 * 8;
   if (smem > 160 * 1024) return RDST_ENOTSUP;
   LnLinArgs p{};
   p.X = X; p.ldx = ldx; p.stats = stats; p.lnw = ln_w; p.W = Wt; p.dY = dY; p.lddy = lddy; p.dX = dX; p.lddx = lddx;
@@ -1335,8 +1394,31 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, st, p);                                           \
   }
+  static int want_stamps = -1;
+  if (want_stamps < 0) { const char* e = getenv("RDST_LNLIN_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps > 0) {
+    (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
+    (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);
+  }
   if (nct == 2) RDST_LNLIN(2) else if (nct == 3) RDST_LNLIN(3) else RDST_LNLIN(4)
 #undef RDST_LNLIN
+  if (want_stamps > 0) {
+    (void)hipStreamSynchronize(st);
+    unsigned long long* hst = (unsigned long long*)malloc((size_t)grid * 16 * 8);
+    (void)hipMemcpy(hst, p.stamps, (size_t)grid * 16 * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(p.stamps);
+    if (--want_stamps == 0) {
+      double sum[16] = {0}; int cnt[16] = {0};
+      for (int64_t w = 0; w < grid; ++w)
+        for (int k = 1; k < 16; ++k) {
+          if (!hst[w * 16 + k]) continue;
+          sum[k] += (double)(hst[w * 16 + k] - hst[w * 16 + k - 1]); cnt[k]++;
+        }
+      fprintf(stderr, "[lnlin_bwd stamps K=%d N=%d ln=%d grid=%lld] mean ticks between consecutive stamps\n", K, N, (int)ln, (long long)grid);
+      for (int k = 1; k < 16; ++k) if (cnt[k]) fprintf(stderr, "  %2d: %9.0f (n=%d)\n", k, sum[k] / cnt[k], cnt[k]);
+    }
+    free(hst);
+  }
   if (int rc = rdst_launch_status("lnlin_bwd")) return rc;
   if (!ln) return wgrad_reduce_launch(slab, (int)grid, N, K, 1.0f, dW, dbias, st);
   if (int rc = wgrad_sum_launch(slab, (int)grid, N * (K + 1), G, st)) return rc;
