@@ -43,7 +43,9 @@ struct HdB {
   static constexpr int C = D * HEADS;
   static constexpr int SEC = C * 2;
   static constexpr int LDT0 = ((SEC + 31) / 32) * 32;
-  static constexpr int LDT = (LDT0 / 16) % 2 == 0 ? LDT0 + 16 : LDT0;   // odd number of 16-B slots
+  // odd number of 16-B slots (b128 row reads); a 256-B row gets 80 more, not 16: at 272 the four rows of a transposed
+  // read (ds_read_b64_tr_b16: 4 rows x 64 B per 16 lanes) would sit 16 B apart on the same banks (4-way conflicts)
+  static constexpr int LDT = LDT0 % 256 == 0 ? LDT0 + 80 : (LDT0 / 16) % 2 == 0 ? LDT0 + 16 : LDT0;
   static constexpr int PROW = 128;                                     // bytes per P / dS row (64 keys, swizzled)
   static constexpr int PMAT = 64 * PROW;
   static constexpr int OFF_Q = 0, OFF_DO = 64 * LDT, OFF_R = 2 * 64 * LDT;
