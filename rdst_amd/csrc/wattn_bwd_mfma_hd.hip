@@ -54,7 +54,9 @@ struct HdB {
   static constexpr int OFF_TAB = OFF_R + RSIZE;
   static constexpr int TABF = HEADS * 15 * TSX, TABB = TABF + 8;
   static constexpr int OFF_ID = OFF_TAB + (TABB + TABF + 8) * 4;       // [64 lanes][2 x 16 B] 0/1 operand packs
-  static constexpr size_t SMEM = (size_t)OFF_ID + 64 * 32;
+  // the d(table) epilogue lays all HEADS x 64 x 64 partial sums out in LDS (row stride 65 floats: conflict-free)
+  static constexpr size_t SMEM_EPI = (size_t)HEADS * 64 * 65 * 4;
+  static constexpr size_t SMEM = (size_t)OFF_ID + 64 * 32 > SMEM_EPI ? (size_t)OFF_ID + 64 * 32 : SMEM_EPI;
   static constexpr int og(int hd) { return (hd * D) & ~3; }             // first channel row of a head's output tile
 };
 
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
 
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (p.stamps && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();  // 0
   BwCtx c;
@@ -437,19 +439,43 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
   }
   // d(table): the per-lane partial sums of all windows of this workgroup -> one slab row [HEADS][225]
   __syncthreads();
-  float* tacc = reinterpret_cast<float*>(smem + CF::OFF_R);
-  for (int i = tid; i < HEADS * 225; i += NT2) tacc[i] = 0.f;
-  __syncthreads();
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
+  // Every lane holds 32 sums over this workgroup's windows: dS summed per (query, key) pair of its (tile, head).
+  // They are laid out as a dense [head][query][key] matrix in LDS (plain stores) and each of the 15 x 15 relative
+  // positions then adds up its diagonal in a fixed order.  (LDS float atomics on the 225 entries — up to 64 lanes of
+  // a wave on one address — took 75 thousand cycles here: a third of the kernel, measured.)
+  float* ds = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
-      atomicAdd(&tacc[hd * 225 + (yi - yj + 7) * 15 + (xi - xj + 7)], Dsum[kt][v]);
+      ds[(hd * 64 + yi * 8 + xi) * 65 + yj * 8 + xj] = Dsum[kt][v];
     }
   __syncthreads();
   float* my = p.slab + (int64_t)blockIdx.x * HEADS * 225;
-  for (int i = tid; i < HEADS * 225; i += NT2) my[i] = tacc[i];
+  for (int e = tid; e < HEADS * 225; e += NT2) {
+    const int hd2 = e / 225, rem = e - hd2 * 225, dy = rem / 15 - 7, dx = rem - (rem / 15) * 15 - 7;
+    const float* base = ds + hd2 * 64 * 65;
+    // all 64 (query row, query column) candidates with fixed trip counts: the reads are independent and go out
+    // together; pairs whose key falls outside the window read entry 0 and add nothing
+    float a = 0.f;
+#pragma unroll
+    for (int qy = 0; qy < 8; ++qy) {
+      float t[8];
+#pragma unroll
+      for (int qx = 0; qx < 8; ++qx) {
+        const int ky = qy - dy, kx = qx - dx;
+        const bool ok = (unsigned)ky < 8u && (unsigned)kx < 8u;
+        t[qx] = base[ok ? (qy * 8 + qx) * 65 + ky * 8 + kx : 0];
+        t[qx] = ok ? t[qx] : 0.f;
+      }
+#pragma unroll
+      for (int qx = 0; qx < 8; ++qx) a += t[qx];
+    }
+    my[e] = a;
+  }
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
 }
 
 template <int D, int HEADS, int GRAN>
