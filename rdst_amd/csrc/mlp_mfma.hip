@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
   float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (p.stamps && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();   // 0: start
 
@@ -438,6 +438,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     __syncthreads();   // B4: tiles free for the next stash
     stamp();   // 5: stores done
   }
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
   // ---- epilogue: the workgroup's partial weight gradients
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
   float* my2 = my + (int64_t)hid * (C + 1);
@@ -451,6 +452,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       if (jj <= hid && c < C) my2[(int64_t)jj * C + c] = W2g[ct][v];
     }
   }
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -893,7 +895,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   float* red = reinterpret_cast<float*>(smem + OFF_RED);
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (p.stamps && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();
 
@@ -1172,6 +1174,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     __syncthreads();   // B4
     stamp();   // 3b
   }
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
   if (wave < NW)
 #pragma unroll
@@ -1183,6 +1186,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       if (n < N && c <= K) my[(int64_t)n * (K + 1) + c] = G[ct][v];
     }
   }
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
 }
 
 int mlp_nct(int C, int hid) {
