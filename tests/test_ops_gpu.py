@@ -150,3 +150,54 @@ def test_layout_roundtrip():
     assert torch.equal(rows, x.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(ops.rows_to_nchw(rows), x)
     assert torch.equal(ops.rows_to_nchw(ops.nchw_to_rows(x, torch.bfloat16)), x.bfloat16().float())
+
+
+@pytest.mark.parametrize("M,K,N,ln", [(160, 120, 360, True), (96, 60, 60, False), (200, 90, 90, False), (64, 48, 20, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ln_linear_bwd_dx_add(M, K, N, ln, dtype):
+    """rdst_ln_linear_bwd with dX_add (the residual fan-out sum folded into the kernel): dX = dX_add + f'(...),
+    called through the C ABI; covers the one-pass backward kernels (bf16) and the composed path (fp32, small N)."""
+    from rdst_amd import _lib
+    lib = _lib.load()
+    x = rand((M, K), 11)
+    gy = rand((M, N), 12)
+    add = rand((M, K), 13)
+    lw, lb = (1 + 0.1 * rand((K,), 14), 0.1 * rand((K,), 15)) if ln else (None, None)
+    w, b = rand((N, K), 16, K ** -0.5), 0.1 * rand((N,), 17)
+    if dtype == torch.bfloat16:
+        x, gy, add = x.bfloat16().float(), gy.bfloat16().float(), add.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) if t is not None else None for t in (lw, lb, w, b)]
+    h = F.layer_norm(xr, (K,), pr[0], pr[1], 1e-5) if ln else xr
+    F.linear(h, pr[2], pr[3]).backward(gy)
+    want_dx = xr.grad + add
+
+    code = _lib.F32 if dtype == torch.float32 else _lib.BF16
+    xg, gyg, addg = x.to(DEV).to(dtype), gy.to(DEV).to(dtype), add.to(DEV).to(dtype)
+    P = [t.to(DEV).contiguous() if t is not None else None for t in (lw, lb, w, b)]
+    stats = None
+    if ln:
+        xf = xg.float()
+        stats = torch.stack([xf.mean(-1), (xf.var(-1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    dx = torch.empty_like(xg)
+    dW, db = torch.empty_like(P[2]), torch.empty_like(P[3])
+    dlw = torch.empty_like(P[0]) if ln else None
+    dlb = torch.empty_like(P[1]) if ln else None
+    nb = lib.rdst_ln_linear_bwd_workspace(M, K, N)
+    wsp = torch.empty(nb, dtype=torch.uint8, device=DEV)
+
+    def ptr(t):
+        return None if t is None else t.data_ptr()
+    _lib.check(lib.rdst_ln_linear_bwd(xg.data_ptr(), K, ptr(P[0]), ptr(P[1]), ptr(stats), 0, P[2].data_ptr(), gyg.data_ptr(), N,
+                                      dx.data_ptr(), K, addg.data_ptr(), K, dW.data_ptr(), db.data_ptr(), ptr(dlw), ptr(dlb),
+                                      wsp.data_ptr(), nb, M, K, N, 1.0, code, torch.cuda.current_stream().cuda_stream),
+               "rdst_ln_linear_bwd")
+    torch.cuda.synchronize()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+
+    def rel(a, b_):
+        return (a.float().cpu() - b_).norm().item() / max(b_.norm().item(), 1e-12)
+    assert rel(dx, want_dx) <= tol
+    assert rel(dW, pr[2].grad) <= tol and rel(db, pr[3].grad) <= tol
+    if ln:
+        assert rel(dlw, pr[0].grad) <= tol and rel(dlb, pr[1].grad) <= tol
