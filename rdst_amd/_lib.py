@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdst_hip.so")
+# RDST_HIP_LIB: load another build of the same C ABI (tools/ use it for the -DRDST_DEBUG library); the default
+# is the in-tree release library, and a missing file raises either way
+LIB_PATH = os.environ.get("RDST_HIP_LIB") or os.path.join(_HERE, "librdst_hip.so")
 
 F32, BF16 = 0, 1
 EINVAL, ENOTSUP = -10001, -10002

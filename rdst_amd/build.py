@@ -1,6 +1,8 @@
 """Build librdst_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
     python -m rdst_amd.build          # incremental; --force rebuilds everything
+    python -m rdst_amd.build --debug  # librdst_hip_dbg.so with -DRDST_DEBUG (ablation switches, in-kernel stamps,
+                                      # environment overrides: tools/ only; load it with RDST_HIP_LIB=<path>)
 
 One object per .hip file (so edits rebuild in seconds), linked into rdst_amd/librdst_hip.so, which
 stays in-tree: it is git-ignored but travels to the GPU box with the snapshot.
@@ -27,7 +29,10 @@ def _newer(src_list, target):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, debug: bool = False) -> str:
+    OBJ = os.path.join(HERE, "csrc", "_obj_dbg" if debug else "_obj")
+    LIB = os.path.join(HERE, "librdst_hip_dbg.so" if debug else "librdst_hip.so")
+    FLAGS = globals()["FLAGS"] + (["-DRDST_DEBUG"] if debug else [])
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -57,4 +62,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, debug="--debug" in sys.argv))

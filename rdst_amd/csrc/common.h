@@ -9,6 +9,20 @@
 
 typedef __hip_bfloat16 bf16;
 
+// Ablation switches, in-kernel cycle stamps and environment overrides exist only in a -DRDST_DEBUG build
+// (RDST_BUILD_DEBUG=1 python -m rdst_amd.build; tools/ use it).  In the shipped library RDST_DBGV(x) is the
+// constant 0 and rdst_dbg_getenv() a constant null pointer, so every `if (RDST_DBGV(p.dbg) & 2)` /
+// `if (RDST_DBGV(p.stamps) && ...)` branch and every `e ? atoi(e) : dflt` folds away at compile time: no
+// getenv, hipMalloc or host sync in a launcher, no ablation test inside a kernel loop.
+#ifdef RDST_DEBUG
+#include <stdlib.h>
+#define RDST_DBGV(x) (x)
+static inline const char* rdst_dbg_getenv(const char* name) { return getenv(name); }
+#else
+#define RDST_DBGV(x) 0
+static inline constexpr const char* rdst_dbg_getenv(const char*) { return nullptr; }
+#endif
+
 // thread-local last-error text behind rdst_last_error()
 extern thread_local char g_rdst_err[256];
 static inline int rdst_fail(int code, const char* fmt, ...) {

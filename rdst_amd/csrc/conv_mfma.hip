@@ -25,7 +25,7 @@ namespace {
 bool mfma_disabled() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("RDST_DISABLE_MFMA");
+    const char* e = rdst_dbg_getenv("RDST_DISABLE_MFMA");
     v = (e && e[0] == '1') ? 1 : 0;
   }
   return v == 1;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
 
   // raw chunk (ky, kc) of the slab at (b, y, x0): 5 instructions x 8 tile rows
   auto issue = [&](Pack16 (&rw)[5], int b, int y, int x0, int ky, int kc) {
-    if (p.dbg & 1) return;
+    if (RDST_DBGV(p.dbg) & 1) return;
     int yy = y + ky - 1;
     yy = yy < 0 ? 0 : (yy >= g.H ? g.H - 1 : yy);        // rows outside the image are skipped by the consumer
     int off = kc * 128 + cchk * 16;
@@ -236,9 +236,9 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
     // weights of this column chunk: LDS image [tap][column n][contraction k], k contiguous; the tap stride is
     // padded by one 16-B slot so the nine taps of the scattered stores fall on different banks
     const int tapst = ncp * p.ldw + 16;
-    if (!(p.dbg & 32)) lds_zero16(smem, 9 * tapst, tid, 512);
+    if (!(RDST_DBGV(p.dbg) & 32)) lds_zero16(smem, 9 * tapst, tid, 512);
     __syncthreads();
-    if (p.dbg & 16) {
+    if (RDST_DBGV(p.dbg) & 16) {
     } else if (MODE == CMODE_FWD) {
       // Wc[co][ci][tap]: rows co = n0 .. n0+nc-1 are one contiguous block of nc * Cin * 9 floats
       stage_scatter<T>(p.Wc + (int64_t)n0 * g.Cin * 9, nc, g.Cin * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int n, int j) {
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
     __syncthreads();
     const int nct = ncp / 32;
 
-    for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < ((p.dbg & 8) ? 0 : nslabs); slab += (int64_t)gridDim.x * 8) {
+    for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < ((RDST_DBGV(p.dbg) & 8) ? 0 : nslabs); slab += (int64_t)gridDim.x * 8) {
       int b, y, x0;
       g.decode(slab * 32, b, y, x0);
       f32x16 acc[CV_MAXCT];
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
                 for (int c = 0; c < CV_MAXCT; ++c)
                   if (c < nct) {
                     const Pack16 wa = *reinterpret_cast<const Pack16*>(wrow + (size_t)c * 32 * p.ldw);
-                    if (!(p.dbg & 2)) MM::mma(acc[c], wa, a);   // rows = output channels, cols = pixels
+                    if (!(RDST_DBGV(p.dbg) & 2)) MM::mma(acc[c], wa, a);   // rows = output channels, cols = pixels
                   }
               }
             }
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
         }
       }
       // epilogue
-      if (p.dbg & 4) continue;
+      if (RDST_DBGV(p.dbg) & 4) continue;
       const int64_t pix = slab * 32 + r;
       const int x = x0 + r;
 #pragma unroll
@@ -458,7 +458,7 @@ template <typename T, int MODE>
 int launch_conv_rows(ConvArgs<T>& p, hipStream_t st, const char* what) {
   using MM = Mma<T>;
   const ConvGeom& g = p.g;
-  if (g.ks != 3 || g.pad != 1 || g.W % 32 != 0 || getenv("RDST_CONV_V1")) return RDST_ENOTSUP;
+  if (g.ks != 3 || g.pad != 1 || g.W % 32 != 0 || rdst_dbg_getenv("RDST_CONV_V1")) return RDST_ENOTSUP;
   if (MODE == CMODE_FWD && !(g.r == 1 || (g.r == 2 && !p.R && g.Cout % 4 == 0))) return RDST_ENOTSUP;
   const int64_t rowbytes = (int64_t)p.CA * (int64_t)sizeof(T);
   if (((uintptr_t)p.A & 3) || (p.lda * sizeof(T)) % 4 || rowbytes % 4 || rowbytes < 16 || !(rowbytes % 128 == 0 || rowbytes % 128 >= 16))
@@ -474,13 +474,13 @@ int launch_conv_rows(ConvArgs<T>& p, hipStream_t st, const char* what) {
   if (nch > npad) nch = npad;
   p.nch = nch;
   p.eps_off = 9 * (nch * p.ldw + 16);   // here: offset of the wave tiles
-  { const char* e = getenv("RDST_CONV_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  { const char* e = rdst_dbg_getenv("RDST_CONV_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const size_t smem = (size_t)p.eps_off + extra;
   const int64_t nslabs = g.pixels() / 32;
   int64_t grid = (nslabs + 7) / 8;
   if (grid > 256) grid = 256;
   static int pf = -1;
-  if (pf < 0) { const char* e = getenv("RDST_CONV_PF"); pf = e ? atoi(e) : 3; }
+  if (pf < 0) { const char* e = rdst_dbg_getenv("RDST_CONV_PF"); pf = e ? atoi(e) : 3; }
   auto kern = pf == 1 ? conv_rows_kernel<T, MODE, 1> : pf == 2 ? conv_rows_kernel<T, MODE, 2> : conv_rows_kernel<T, MODE, 3>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);

@@ -288,7 +288,7 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
   if (Wt) {
     // LayerNorm-fused Linear with everything requested in one call: the weight-gradient pass runs on x-hat and
     // its reduction also yields d(gamma)/d(beta); the data-gradient kernel then only produces dX.
-    if (ln_w && ln_b && dW && dbias && dln_w && dln_b && dX && K <= 128 && !getenv("RDST_LN_BWD_V1")) {
+    if (ln_w && ln_b && dW && dbias && dln_w && dln_b && dX && K <= 128 && !rdst_dbg_getenv("RDST_LN_BWD_V1")) {
       float* G = dA;   // the fp32 dA buffer of the generic path is unused here: N*(K+1) <= M*K floats of scratch
       if ((int64_t)N * (K + 1) <= M * K) {
         if constexpr (sizeof(T) == 2) {   // one pass over (x, dY) for everything, where the shape is covered

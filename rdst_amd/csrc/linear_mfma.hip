@@ -24,7 +24,7 @@ namespace {
 bool mfma_disabled() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("RDST_DISABLE_MFMA");
+    const char* e = rdst_dbg_getenv("RDST_DISABLE_MFMA");
     v = (e && e[0] == '1') ? 1 : 0;
   }
   return v == 1;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
   const bool has_ln = (MODE == MODE_FWD) && p.lnw != nullptr;
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (RDST_DBGV(p.stamps) && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();  // 0: start
   const int npad = ((p.Nout + 31) / 32) * 32;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
     __syncthreads();
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
-    if (p.dbg & 16) {
+    if (RDST_DBGV(p.dbg) & 16) {
     } else if (MODE == MODE_FWD) {
       // rows n of W (N,K), k contiguous -> packs of the LDS image.  Lean on purpose: thread -> (row, pack) by
       // shift / mask, 4 items of a thread in flight, 16-B loads (a 12-deep batch with integer
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
     if constexpr (PFETCH) {
       if (n0 != 0 && slab0 < nslabs) issue_raw(raw, slab0);
     }
-    for (int64_t slab = slab0; slab < ((p.dbg & 8) ? 0 : nslabs); slab += sstep) {
+    for (int64_t slab = slab0; slab < ((RDST_DBGV(p.dbg) & 8) ? 0 : nslabs); slab += sstep) {
       if constexpr (PFETCH) {
         raw_to_frags(raw, a);
         // every iteration defines the whole prefetch set (past the end it re-reads this slab)
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
             }
         }
       }
-      for (int ct = 0; ct < ((p.dbg & 4) ? 0 : nct); ++ct) {
+      for (int ct = 0; ct < ((RDST_DBGV(p.dbg) & 4) ? 0 : nct); ++ct) {
         f32x16 acc;
         if (MODE == MODE_FWD) {   // bias = initial accumulator: register group g holds columns 8g + 4h .. +3
 #pragma unroll
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
             }
           };
           if (MODE == MODE_FWD) {
-            if (p.R && !(p.dbg & 2)) {
+            if (p.R && !(RDST_DBGV(p.dbg) & 2)) {
               float g8[8];
               chunk8(p.R + row * p.ldr, r_vec, g8);
 #pragma unroll
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
             }
             continue;
           }
-          if (p.dbg & 1) continue;
+          if (RDST_DBGV(p.dbg) & 1) continue;
           T* yrow = p.Y + row * p.ldy;
           if (BF) {
             if (y_vec && cb + 8 <= p.Nout) {
@@ -692,7 +692,7 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   using MM = Mma<T>;
   p.Tn = (p.Kc + MM::KP - 1) / MM::KP;
   if (p.Tn > 32) return RDST_ENOTSUP;
-  { const char* e = getenv("RDST_LIN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  { const char* e = rdst_dbg_getenv("RDST_LIN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   {  // the slab loads move whole 16-B chunks of dword-aligned rows (a chunk's tail is never shorter than 16 B)
     const int64_t rowbytes = (int64_t)p.Kc * (int64_t)sizeof(T);
     const bool coal = ((uintptr_t)p.A & 3) == 0 && (p.lda * sizeof(T)) % 4 == 0 && rowbytes % 4 == 0 && rowbytes >= 16 &&
@@ -713,10 +713,10 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   const int64_t nslabs = (p.M + 31) / 32;
   int64_t grid = (nslabs + 7) / 8;
   int64_t cap = 256;  // persistent: one 8-wave workgroup per CU (the kernel's register count admits no second one)
-  { const char* e = getenv("RDST_LIN_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
+  { const char* e = rdst_dbg_getenv("RDST_LIN_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
   if (grid > cap) grid = cap;
   static int want_stamps = -1;
-  if (want_stamps < 0) { const char* e = getenv("RDST_LIN_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps < 0) { const char* e = rdst_dbg_getenv("RDST_LIN_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   unsigned long long* hst = nullptr;
   if (want_stamps > 0) {
     (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);

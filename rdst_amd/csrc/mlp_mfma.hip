@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
   float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (RDST_DBGV(p.stamps) && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();   // 0: start
 
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     __syncthreads();   // B4: tiles free for the next stash
     stamp();   // 5: stores done
   }
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
+  if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
   // ---- epilogue: the workgroup's partial weight gradients
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
   float* my2 = my + (int64_t)hid * (C + 1);
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       if (jj <= hid && c < C) my2[(int64_t)jj * C + c] = W2g[ct][v];
     }
   }
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
+  if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_fwd_kernel(const MlpFwdArgs 
   float2* pst = reinterpret_cast<float2*>(smem + OFF_PST);   // [32 rows][16] (sum, M2) of each 16-B chunk
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (RDST_DBGV(p.stamps) && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();
 
@@ -895,7 +895,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
   float* red = reinterpret_cast<float*>(smem + OFF_RED);
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (RDST_DBGV(p.stamps) && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();
 
@@ -1174,7 +1174,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     __syncthreads();   // B4
     stamp();   // 3b
   }
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
+  if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
   float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
   if (wave < NW)
 #pragma unroll
@@ -1186,7 +1186,7 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
       if (n < N && c <= K) my[(int64_t)n * (K + 1) + c] = G[ct][v];
     }
   }
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
+  if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
 }
 
 int mlp_nct(int C, int hid) {
@@ -1208,7 +1208,7 @@ int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, c
 extern "C" int rdst_mlp_fused_supported(int C, int hid, int dtype) {
   static int off = -1;
   if (off < 0) {
-    const char* e = getenv("RDST_MLP_V1");
+    const char* e = rdst_dbg_getenv("RDST_MLP_V1");
     off = (e && e[0] == '1') ? 1 : 0;
   }
   return (!off && dtype == RDST_BF16 && mlp_nct(C, hid) != 0) ? 1 : 0;
@@ -1242,7 +1242,7 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   // narrow layers (4 waves, <= 256 registers in total per SIMD lane pair, 37 KB of LDS) run TWO workgroups per CU: one
   // wave per SIMD hides no latency, and two independent workgroups overlap each other's phases
   int64_t cap = nct == 2 ? 512 : 256;
-  { const char* e = getenv("RDST_MLP_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
+  { const char* e = rdst_dbg_getenv("RDST_MLP_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
   int64_t grid = p.ntiles < cap ? p.ntiles : cap;
   p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
   grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
@@ -1257,9 +1257,9 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * NC), smem, st, p);                                     \
   }
   static int split = -1;
-  if (split < 0) { const char* e = getenv("RDST_MLP_SPLIT"); split = (e && e[0] == '1') ? 1 : 0; }
+  if (split < 0) { const char* e = rdst_dbg_getenv("RDST_MLP_SPLIT"); split = (e && e[0] == '1') ? 1 : 0; }
   static int want_stamps = -1;
-  if (want_stamps < 0) { const char* e = getenv("RDST_MLP_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps < 0) { const char* e = rdst_dbg_getenv("RDST_MLP_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   if (want_stamps > 0) {
     (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
     (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);
@@ -1305,7 +1305,7 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
   p.Y = (bf16*)Y; p.ldy = ld_y; p.stats = stats; p.M = M; p.C = C; p.hid = hid;
   p.ntiles = (M + 31) / 32;
   int64_t cap = nct == 2 ? 512 : 256;   // the narrow layers fit two workgroups per CU (see rdst_mlp_bwd)
-  { const char* e = getenv("RDST_MLP_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
+  { const char* e = rdst_dbg_getenv("RDST_MLP_GRID"); if (e && atoi(e) > 0) cap = atoi(e); }
   int64_t grid = p.ntiles < cap ? p.ntiles : cap;
   p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
   grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
@@ -1318,7 +1318,7 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(128 * NC), smem, st, p);                                     \
   }
   static int want_stamps = -1;
-  if (want_stamps < 0) { const char* e = getenv("RDST_MLPF_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps < 0) { const char* e = rdst_dbg_getenv("RDST_MLPF_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   if (want_stamps > 0) {
     (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
     (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);
@@ -1354,7 +1354,7 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
                              int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
                              int64_t M, int K, int N, float s, hipStream_t st) {
   static int off = -1;
-  if (off < 0) { const char* e = getenv("RDST_LNLIN_V1"); off = e ? atoi(e) : 0; }   // 1: all off, 2: the plain-Linear form off
+  if (off < 0) { const char* e = rdst_dbg_getenv("RDST_LNLIN_V1"); off = e ? atoi(e) : 0; }   // 1: all off, 2: the plain-Linear form off
   const bool ln = ln_w != nullptr;
   if (off == 1 || (off == 2 && !ln) || s != 1.0f || M <= 0) return RDST_ENOTSUP;
   const int nct = (K + 1 + 31) / 32;
@@ -1384,7 +1384,7 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   if (per_cu > 160 * 1024 / smem) per_cu = 160 * 1024 / smem;
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 2) per_cu = 2;   // more workgroups only add slab traffic (measured)
-  { const char* e = getenv("RDST_LNLIN_PERCU"); if (e && atoi(e) > 0) per_cu = atoi(e); }
+  { const char* e = rdst_dbg_getenv("RDST_LNLIN_PERCU"); if (e && atoi(e) > 0) per_cu = atoi(e); }
   int64_t cap = 256 * per_cu;
   if (cap > linear_wgrad_max_wgs(N)) cap = linear_wgrad_max_wgs(N);   // what the workspace's slab region holds
   int64_t grid = p.ntiles < cap ? p.ntiles : cap;
@@ -1399,7 +1399,7 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, st, p);                                           \
   }
   static int want_stamps = -1;
-  if (want_stamps < 0) { const char* e = getenv("RDST_LNLIN_STAMPS"); want_stamps = e ? atoi(e) : 0; }
+  if (want_stamps < 0) { const char* e = rdst_dbg_getenv("RDST_LNLIN_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   if (want_stamps > 0) {
     (void)hipMalloc((void**)&p.stamps, (size_t)grid * 16 * 8);
     (void)hipMemsetAsync(p.stamps, 0, (size_t)grid * 16 * 8, st);

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
 
     // ================= pass T: keys on registers, query (tile t) on the lane ======================
-    if (!(p.dbg & 2)) {
+    if (!(RDST_DBGV(p.dbg) & 2)) {
       f32x16 X[2], D[2];
       const float* tb = tabL + hd * 15 * TS + (yl + 7) * TS + (xl + 7) - 4 * h;
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
     __syncthreads();  // statistics of both query tiles are in LDS
 
     // ================= pass N: queries on registers, key (tile t) on the lane ======================
-    if (!(p.dbg & 4)) {
+    if (!(RDST_DBGV(p.dbg) & 4)) {
       f32x16 Y[2], E[2];
       const float* tb = tabL + hd * 15 * TS + (7 - yl) * TS + (7 - xl) + 4 * h;
 #pragma unroll
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
 bool mfma_disabled() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("RDST_DISABLE_MFMA");
+    const char* e = rdst_dbg_getenv("RDST_DISABLE_MFMA");
     v = (e && e[0] == '1') ? 1 : 0;
   }
   return v == 1;
@@ -424,7 +424,7 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
   WbArgs<T> p{};
   p.qkv = qkv; p.ld = ld; p.table = table; p.dout = dout; p.ldd = ldd; p.dqkv = dqkv; p.ldq = ldq; p.slab = slab;
   p.g = g; p.scale = scale; p.d = d;
-  { const char* e = getenv("RDST_K2_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  { const char* e = rdst_dbg_getenv("RDST_K2_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const int sec = g.C * (int)sizeof(T);
   int gran = 0;
   for (int gs = 16; gs >= 4; gs >>= 1) {

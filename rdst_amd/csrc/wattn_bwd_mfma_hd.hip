@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
 
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (RDST_DBGV(p.stamps) && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();  // 0
   BwCtx c;
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
   }
   // d(table): the per-lane partial sums of all windows of this workgroup -> one slab row [HEADS][225]
   __syncthreads();
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
+  if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
   // Every lane holds 32 sums over this workgroup's windows: dS summed per (query, key) pair of its (tile, head).
   // They are laid out as a dense [head][query][key] matrix in LDS (plain stores) and each of the 15 x 15 relative
   // positions then adds up its diagonal in a fixed order.  (LDS float atomics on the 225 entries — up to 64 lanes of
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     }
     my[e] = a;
   }
-  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
+  if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
 }
 
 template <int D, int HEADS, int GRAN>
@@ -491,7 +491,7 @@ int launch_bw(const BwArgs& p, int slab_rows, int* nslab, hipStream_t st) {
   *nslab = (int)grid;
   static int want_stamps = -1;
   if (want_stamps < 0) {
-    const char* e = getenv("RDST_K2_STAMPS");
+    const char* e = rdst_dbg_getenv("RDST_K2_STAMPS");
     want_stamps = e ? atoi(e) : 0;
   }
   if (want_stamps > 0) {  // debug: in-kernel phase stamps of every workgroup, summarised on stderr
@@ -538,7 +538,7 @@ int wattn_bwd_mfma_hd(const void* qkv, int64_t ld, const float* table, const voi
   if (g.ws != 8 || g.heads != 6 || g.mask || !(scale > 0.f) || g.C % 6 || slab_rows < 1) return RDST_ENOTSUP;
   static int v1 = -1;
   if (v1 < 0) {
-    const char* e = getenv("RDST_K2_V1");
+    const char* e = rdst_dbg_getenv("RDST_K2_V1");
     v1 = (e && e[0] == '1') ? 1 : 0;
   }
   if (v1) return RDST_ENOTSUP;

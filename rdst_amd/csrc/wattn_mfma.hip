@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
         const int ri = part * RPP + i;          // 0..15 within the wave
         int col = c0 + (ri & 7);
         if (col >= g.W) col -= g.W;
-        const int64_t tok = (p.dbg & 2) ? 0 : rbase[ri >> 3] + col;
+        const int64_t tok = (RDST_DBGV(p.dbg) & 2) ? 0 : rbase[ri >> 3] + col;
         const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
 
     const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
-    for (int hd = hg; hd < ((p.dbg & 1) ? 0 : heads); hd += 2) {
+    for (int hd = hg; hd < ((RDST_DBGV(p.dbg) & 1) ? 0 : heads); hd += 2) {
       const int c_lo = hd * d, c_hi = c_lo + d;
       const int t_lo = c_lo / KP, t_hi = (c_hi - 1) / KP;
       f32x16 X[2];
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
     }
     __syncthreads();
     // LDS (Q section now holds O) -> global rows: wave w copies rows w, w+4, ...; no divisions
-    if (!(p.dbg & 4)) {
+    if (!(RDST_DBGV(p.dbg) & 4)) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         int col = c0 + (i & 7);
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
 bool mfma_disabled() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("RDST_DISABLE_MFMA");
+    const char* e = rdst_dbg_getenv("RDST_DISABLE_MFMA");
     v = (e && e[0] == '1') ? 1 : 0;
   }
   return v == 1;
@@ -322,7 +322,7 @@ int launch_fwd(const T* qkv, int64_t ld, const float* table, T* out, int64_t ldo
   if (g.ws != 8 || d > 32 || g.C > 128 || g.mask) return RDST_ENOTSUP;
   WaArgs<T> p{};
   p.qkv = qkv; p.ld = ld; p.table = table; p.out = out; p.ldo = ldo; p.g = g; p.scale = scale; p.d = d;
-  { const char* e = getenv("RDST_K1_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  { const char* e = rdst_dbg_getenv("RDST_K1_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const int sec = g.C * (int)sizeof(T);
   p.gran = pick_gran((uintptr_t)qkv, (uintptr_t)out, ld * (int64_t)sizeof(T), ldo * (int64_t)sizeof(T), sec);
   if (!p.gran) return RDST_ENOTSUP;

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
 
   int nst = 0;
   auto stamp = [&]() {
-    if (p.stamps && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
+    if (RDST_DBGV(p.stamps) && tid == 0 && nst < 16) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
   };
   stamp();  // 0: kernel start
   constexpr float LOG2E = 1.4426950408889634f;
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
     for (int i = 0; i < 16; ++i) {
       int col = w.c0 + (i & 7);
       if (col >= g.W) col -= g.W;
-      const int64_t tok = (p.dbg & 2) ? 0 : w.rbase[i >> 3] + col;
+      const int64_t tok = (RDST_DBGV(p.dbg) & 2) ? 0 : w.rbase[i >> 3] + col;
       const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld);
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -376,13 +376,13 @@ __global__ void __launch_bounds__(256, MINB) wattn_fwd_hd_kernel(const HdArgs p)
       for (int kt = 0; kt < 2; ++kt) onehot(2 * ((c.mrow && kt * 4 + (r >> 3) >= thr) ? 1 : 0) + rx, 0x3f80u, c.mK[kt]);
       onehot(2 * ((c.mrow && yi >= thr) ? 1 : 0) + rx, cbits, c.mQ);
     }
-    if (!(p.dbg & 1)) {
+    if (!(RDST_DBGV(p.dbg) & 1)) {
       if (hg == 0) hd_group<D, HEADS, 0>(c);
       else hd_group<D, HEADS, 1>(c);
     }
     __syncthreads();
     stamp();  // 3 + 3k: computed
-    if (!(p.dbg & 4)) {  // LDS (Q section now holds O) -> global rows
+    if (!(RDST_DBGV(p.dbg) & 4)) {  // LDS (Q section now holds O) -> global rows
       if constexpr (cps <= 16) {  // 4 token rows per store instruction: lane -> (row = lane >> 4, chunk = lane & 15)
         const int rsub = lane >> 4, chk = lane & 15;
 #pragma unroll
@@ -423,7 +423,7 @@ int launch_hd(const HdArgs& p, hipStream_t st) {
   {
     static int env_wgs = -1;
     if (env_wgs < 0) {
-      const char* e = getenv("RDST_K1_WGS");
+      const char* e = rdst_dbg_getenv("RDST_K1_WGS");
       env_wgs = e ? atoi(e) : 0;
     }
     if (env_wgs > 0 && env_wgs < wg_per_cu) wg_per_cu = env_wgs;
@@ -432,7 +432,7 @@ int launch_hd(const HdArgs& p, hipStream_t st) {
   if (grid > nwin) grid = nwin;
   static int want_stamps = -1;
   if (want_stamps < 0) {
-    const char* e = getenv("RDST_K1_STAMPS");
+    const char* e = rdst_dbg_getenv("RDST_K1_STAMPS");
     want_stamps = e ? atoi(e) : 0;
   }
   if (want_stamps > 0) {  // debug: in-kernel phase stamps of every workgroup, summarised on stderr
@@ -483,18 +483,18 @@ int wattn_fwd_mfma_hd(const void* qkv, int64_t ld, const float* table, void* out
   if (g.ws != 8 || g.heads != 6 || g.mask || !(scale > 0.f) || g.C % 6) return RDST_ENOTSUP;
   static int v1 = -1;
   if (v1 < 0) {
-    const char* e = getenv("RDST_K1_V1");
+    const char* e = rdst_dbg_getenv("RDST_K1_V1");
     v1 = (e && e[0] == '1') ? 1 : 0;
   }
   if (v1) return RDST_ENOTSUP;
   HdArgs p{};
   p.qkv = (const bf16*)qkv; p.ld = ld; p.table = table; p.out = (bf16*)out; p.ldo = ldo; p.g = g; p.scale = scale;
-  { const char* e = getenv("RDST_K1_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+  { const char* e = rdst_dbg_getenv("RDST_K1_DEBUG"); p.dbg = e ? atoi(e) : 0; }
   const int d = g.C / 6;
   const int64_t lb = ld * 2, lob = ldo * 2;
   static int minb = -1;
   if (minb < 0) {
-    const char* e = getenv("RDST_K1_MINB");
+    const char* e = rdst_dbg_getenv("RDST_K1_MINB");
     minb = e ? atoi(e) : 0;
   }
   if (d == 10 && aligned_to(qkv, out, lb, lob, 8)) return minb == 4 ? launch_hd<10, 6, 8, 1, 4>(p, st) : launch_hd<10, 6, 8, 1, 3>(p, st);

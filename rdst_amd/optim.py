@@ -45,10 +45,13 @@ class FlatAdam(torch.optim.Optimizer):
         self._point_state()
 
     def _point_state(self) -> None:
+        # ONE host-side step counter shared by all 750 per-parameter states (torch.optim.Adam's layout wants a
+        # "step" entry per parameter; they are always equal here): a step() updates it once, not 750 times
+        self._step_t = torch.tensor(float(self._steps))
         off = 0
         for p in self.param_groups[0]["params"]:
             k = p.numel()
-            self.state[p] = {"step": torch.tensor(float(self._steps)),
+            self.state[p] = {"step": self._step_t,
                              "exp_avg": self.exp_avg[off:off + k].view_as(p),
                              "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p)}
             off += k
@@ -72,8 +75,7 @@ class FlatAdam(torch.optim.Optimizer):
                                       float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                       float(g["weight_decay"]), self._steps,
                                       torch.cuda.current_stream().cuda_stream), "rdst_adam_step")
-        for st in self.state.values():
-            st["step"].fill_(float(self._steps))
+        self._step_t.fill_(float(self._steps))
         return loss
 
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: D401 - keeps p.grad aliased to the bucket

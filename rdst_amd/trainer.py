@@ -20,6 +20,7 @@ import time
 from typing import Callable, Dict, Optional, Sequence
 
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import dp
@@ -51,20 +52,30 @@ class DPTrainStep:
         self.current_epoch = 0
         self.training_epoch_costs: list = []
 
+    def _keep_step(self, loss: torch.Tensor) -> bool:
+        """The loss-threshold decision of trans_sr_trainer.py:162, made COLLECTIVELY: every rank must take the same
+        branch, or the ranks that skip would leave the others waiting in the gradient all-reduce.  The group skips
+        when ANY rank's local loss is not below the threshold (MAX over ranks of the "skip" flag; a NaN loss skips)."""
+        skip = torch.logical_not(loss.detach() < self.loss_threshold).to(torch.float32).reshape(1)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(skip, op=dist.ReduceOp.MAX, group=self.group)
+        return float(skip.item()) == 0.0
+
     def step(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
-        """One iteration of trans_sr_trainer.py:141-173; returns the (device) loss."""
+        """One iteration of trans_sr_trainer.py:131-178; returns the (device) loss."""
+        t0 = time.time()                               # :132
+        self.current_epoch += 1                        # :134 — advanced whether or not the update is skipped
         self.net.train()
         out = self.net(inputs)
         loss = self.loss_fn(out, targets)
-        if self.loss_threshold < GUARD_OFF and not (float(loss.item()) < self.loss_threshold):
-            return loss.detach()                       # :162 — the update is skipped
-        self.optimizer.zero_grad()                     # one memset of the flat bucket
-        loss.backward()
-        self.bucket.all_reduce_mean(self.group)        # no-op on one rank
-        self.optimizer.step()
-        if self.scheduler is not None:
-            self.scheduler.step()
-        self.current_epoch += 1
+        if self.loss_threshold >= GUARD_OFF or self._keep_step(loss):   # :162
+            self.optimizer.zero_grad()                 # one memset of the flat bucket
+            loss.backward()
+            self.bucket.all_reduce_mean(self.group)    # no-op on one rank
+            self.optimizer.step()
+            if self.scheduler is not None:
+                self.scheduler.step()
+        self.training_epoch_costs.append(time.time() - t0)   # :176-178 (host-side enqueue time unless the guard synced)
         return loss.detach()
 
     # ---- models/basic_trainer.py:164-208 -----------------------------------------------------------

@@ -97,3 +97,45 @@ def test_bucket_single_process_is_noop_and_zeroes():
     b.zero()
     assert b.flat.abs().sum() == 0 and all(p.grad.abs().sum() == 0 for p in net.parameters())
     assert b.nbytes == 4 * sum(p.numel() for p in net.parameters())
+
+
+def _guard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rdst_amd.trainer import DPTrainStep
+    torch.set_num_threads(1)
+    net = _tiny()
+    tr = DPTrainStep(net, loss_threshold=0.5)
+    before = [p.detach().clone() for p in net.parameters()]
+    # rank 0's local loss is below the threshold, rank 1's is not: the decision must be the same on both ranks
+    local = torch.tensor(0.1 if rank == 0 else 0.9)
+    keep_mixed = tr._keep_step(local)
+    keep_all = tr._keep_step(torch.tensor(0.1))
+    keep_nan = tr._keep_step(torch.tensor(float("nan") if rank == 0 else 0.1))
+    # a whole step on the skip path (targets far away on rank 1 only): neither rank enters the gradient all-reduce,
+    # nothing hangs, the iteration counter and the cost record advance as trans_sr_trainer.py:134,176-178 do
+    x = torch.rand(2, 1, 8, 8)
+    t = torch.rand(2, 1, 8, 8) + (100.0 if rank == 1 else 0.0)
+    tr.loss_threshold = 50.0
+    tr.step(x, t)
+    same = all(torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+    q.put((rank, keep_mixed, keep_all, keep_nan, tr.current_epoch, len(tr.training_epoch_costs), same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_loss_threshold_guard_is_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, keep_mixed, keep_all, keep_nan, epoch, ncost, same in res:
+        assert keep_mixed is False and keep_all is True and keep_nan is False, rank
+        assert epoch == 1 and ncost == 1 and same, rank
