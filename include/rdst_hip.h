@@ -141,9 +141,14 @@ int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln
  * (common.py:125-136) and the last conv (rdst_variations.py:1303); MeanShift (common.py:151-167).
  *   Wc : fp32 (Cout, Cin, k, k) as nn.Conv2d stores it.   R/Y rows are in the OUTPUT geometry.
  */
+/*   workspace : rdst_conv_fwd_workspace(Cin, Cout, ksize) bytes of device scratch (16-byte aligned) for the bf16
+ *               fragment-major image of the weights that the register-stationary 3x3 kernels read (conv3_mfma.hip);
+ *               NULL / 0 selects the kernels that stage the fp32 weights themselves. */
+size_t rdst_conv_fwd_workspace(int Cin, int Cout, int ksize);
 int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const float* bias,
-                  const void* R, int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin,
-                  int Cout, int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
+                  const void* R, int64_t ld_r, void* Y, int64_t ld_y, void* workspace, size_t workspace_bytes,
+                  int B, int H, int W, int Cin, int Cout, int ksize, float out_scale, int shuffle_r, int dtype,
+                  void* stream);
 
 /* Backward: dY (output geometry) -> dX (B*H*W, Cin) = dX_add + ... (dX_add optional, may alias dX),
  * dW (Cout,Cin,k,k), dbias (Cout) [overwritten; may be NULL]. */

@@ -18,9 +18,37 @@ typedef __hip_bfloat16 bf16;
 #include <stdlib.h>
 #define RDST_DBGV(x) (x)
 static inline const char* rdst_dbg_getenv(const char* name) { return getenv(name); }
+// per-workgroup cycle counters of a kernel (debug build only): `env`=N arms the next N launches; the launcher passes
+// the returned device buffer ([grid][n] u64, zeroed) to the kernel and calls rdst_stamps_end() after the launch, which
+// synchronises, averages every slot over the workgroups and prints it.
+static inline unsigned long long* rdst_stamps_begin(const char* env, int grid, int n, hipStream_t st) {
+  const char* e = getenv(env);
+  if (!e || atoi(e) <= 0) return nullptr;
+  unsigned long long* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)grid * n * 8) != hipSuccess) return nullptr;
+  (void)hipMemsetAsync(d, 0, (size_t)grid * n * 8, st);
+  return d;
+}
+static inline void rdst_stamps_end(const char* tag, unsigned long long* d, int grid, int n, hipStream_t st) {
+  if (!d) return;
+  (void)hipStreamSynchronize(st);
+  unsigned long long* h = (unsigned long long*)malloc((size_t)grid * n * 8);
+  (void)hipMemcpy(h, d, (size_t)grid * n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  fprintf(stderr, "[stamps %s grid=%d] mean cycles per workgroup:", tag, grid);
+  for (int k = 0; k < n; ++k) {
+    double sum = 0;
+    for (int w = 0; w < grid; ++w) sum += (double)h[(size_t)w * n + k];
+    fprintf(stderr, " %d:%.0f", k, sum / grid);
+  }
+  fprintf(stderr, "\n");
+  free(h);
+}
 #else
 #define RDST_DBGV(x) 0
 static inline constexpr const char* rdst_dbg_getenv(const char*) { return nullptr; }
+static inline unsigned long long* rdst_stamps_begin(const char*, int, int, hipStream_t) { return nullptr; }
+static inline void rdst_stamps_end(const char*, unsigned long long*, int, int, hipStream_t) {}
 #endif
 
 // thread-local last-error text behind rdst_last_error()

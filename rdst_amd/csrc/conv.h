@@ -54,3 +54,11 @@ int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, co
                      int64_t lddx, const bf16* acc, int64_t ldacc, float* dW, float* dbias, float* slab, const ConvGeom& g,
                      float s, hipStream_t st);
 size_t conv_c1_slab_floats(int Cin);
+
+// register-stationary 3x3 kernels for the E1 shapes, bf16 (conv3_mfma.hip); RDST_ENOTSUP for everything else.
+// wpack: conv3_pack_bytes(Cin, Cout) bytes of 16-byte aligned device scratch (NULL -> RDST_ENOTSUP).
+size_t conv3_pack_bytes(int Cin, int Cout);
+int conv3_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr,
+                   bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st);
+int conv3_dgrad_bf16(const float* Wc, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc,
+                     int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st);

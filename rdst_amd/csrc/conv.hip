@@ -129,9 +129,10 @@ int wgrad_splits(const ConvGeom& g) {
 
 template <typename T>
 int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr, T* Y,
-          int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
+          int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (int rc = conv_c1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+    if (int rc = conv3_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, st); rc != RDST_ENOTSUP) return rc;
   }
   if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
   ConvA<T> la{X, ldx, g, in_act};
@@ -144,7 +145,9 @@ template <typename T>
 int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int64_t lddy, T* dX, int64_t lddx,
           const T* acc, int64_t ldacc, float* dW, float* dbias, float* wsp, const ConvGeom& g, float s, hipStream_t st) {
   const int64_t wtotal = (int64_t)g.Cout * g.Cin * g.ks * g.ks;
-  // workspace carve: [generic split-K slab][small][MFMA scratch: un-shuffled dY, wgrad slab]
+  // workspace carve: [packed dgrad weights][generic split-K slab][small][MFMA scratch: un-shuffled dY, wgrad slab]
+  void* wpack = wsp;
+  wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + conv3_pack_bytes(g.Cin, g.Cout));
   float* slab = wsp;
   float* small = slab + (int64_t)kMaxSplits * wtotal;
   char* mscr = reinterpret_cast<char*>(small + (int64_t)kSmallBlocks * g.Cout + 64);
@@ -152,6 +155,15 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
     float* c1slab = reinterpret_cast<float*>(mscr + conv_mfma_scratch_bytes(ConvGeom{g.B, g.H, g.W, g.Cin, g.Cout, g.ks, g.pad, 2}));
     if (int rc = conv_c1_bwd_bf16(X, ldx, in_act, Wc, dY, lddy, dX, lddx, acc, ldacc, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP)
       return rc;
+  }
+  bool dxdone = false;
+  if constexpr (sizeof(T) == 2) {   // register-stationary dgrad reads the (possibly pixel-shuffled) dY as it lies
+    if (dX) {
+      const int rc = conv3_dgrad_bf16(Wc, dY, lddy, dX, lddx, acc, ldacc, in_act, g, s, wpack, st);
+      if (rc == 0) dxdone = true;
+      else if (rc != RDST_ENOTSUP) return rc;
+    }
+    if (dxdone && !dW && !dbias) return 0;
   }
   // MFMA fast paths want dY as plain (B*H*W, Cout) rows
   int prc = 0;
@@ -179,7 +191,7 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
     if (!rc) rc = slab_reduce(slab, dW, z, wtotal, st);
     if (rc) return rc;
   }
-  if (dX) {
+  if (dX && !dxdone) {
     int rc = conv_dgrad_mfma<T>(X, ldx, in_act, Wc, dYp, ldp, dX, lddx, acc, ldacc, g, s, st);
     if (rc == RDST_ENOTSUP) {
       ConvDyA<T> la{dY, lddy, g, s};
@@ -222,9 +234,14 @@ __global__ void __launch_bounds__(256) rows_to_nchw_kernel(const T* __restrict__
 
 }  // namespace
 
+extern "C" size_t rdst_conv_fwd_workspace(int Cin, int Cout, int ksize) {
+  if (Cin <= 0 || Cout <= 0 || ksize != 3) return 16;
+  return conv3_pack_bytes(Cin, Cout);
+}
+
 extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const float* bias, const void* R,
-                             int64_t ld_r, void* Y, int64_t ld_y, int B, int H, int W, int Cin, int Cout, int ksize,
-                             float out_scale, int shuffle_r, int dtype, void* stream) {
+                             int64_t ld_r, void* Y, int64_t ld_y, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                             int Cin, int Cout, int ksize, float out_scale, int shuffle_r, int dtype, void* stream) {
   ConvGeom g;
   if (int rc = make_geom(g, B, H, W, Cin, Cout, ksize, shuffle_r, "rdst_conv_fwd")) return rc;
   if (!X || !Wc || !Y) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: null pointer");
@@ -232,15 +249,16 @@ extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const floa
   if (ld_x < Cin || ld_y < cy || (R && ld_r < cy)) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: leading dimension too small");
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
+  void* wpack = (workspace && workspace_bytes >= rdst_conv_fwd_workspace(Cin, Cout, ksize)) ? workspace : nullptr;
   if (dtype == RDST_F32)
-    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, st);
-  return fwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, g, out_scale, st);
+    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, wpack, st);
+  return fwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, g, out_scale, wpack, st);
 }
 
 extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
   ConvGeom g{B, H, W, Cin, Cout, ksize, ksize / 2, 2};  // r = 2 reserves room for an un-shuffled dY
-  return sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
+  return conv3_pack_bytes(Cin, Cout) + sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
          conv_mfma_scratch_bytes(g) + sizeof(float) * conv_c1_slab_floats(Cin);
 }
 

@@ -1,0 +1,550 @@
+// K4/K5 for the E1 shapes (bf16): 3x3 / pad 1 convolution, forward and dgrad, with the WEIGHTS STATIONARY IN
+// REGISTERS and the input rows rolling through LDS.
+//
+// Why: the 150 -> 60 fusion conv of an RDSTB (rdst_variations.py:420-421) has 9 x 60 x 150 bf16 = 162 KB of weights —
+// more than the 160 KB of LDS next to any pixel tile — so the stripe kernel of conv_mfma.hip ran two weight-chunk
+// passes, re-staged (and converted) the fp32 weights in every workgroup and spent most of a launch there (110-140 us
+// for 21 GFLOP).  A CU's register file is 512 KB.  Here a workgroup is 4 waves (one per SIMD, up to 512 VGPRs each):
+// every wave keeps the A-operand fragments (32 output channels x 16 contraction channels per 32x32x16 MFMA) of ITS
+// share of the weight tensor in registers for the whole kernel — loaded once, as plain 16-B loads, from a bf16 image
+// that a tiny pack kernel lays out fragment-major — and LDS holds only input pixels:
+//   * a workgroup owns a vertical strip, 32 pixels wide and SH rows high; the input rows (34 pixels with the halo,
+//     K channels, pixel stride padded to an odd number of 16-B slots) roll through a ring of NR = 2 RPS + 2 row slots:
+//     a step computes RPS output rows from RPS + 2 resident rows while the next RPS rows are in flight in registers
+//     (coalesced 16-B loads, clamped addresses + select instead of branches, zero fill outside the image), written
+//     to their slots after the step's MFMAs, one barrier per step.  No input row is read twice inside a strip;
+//   * the B operand of a tap (ky, kx) is the SAME LDS image at a row / pixel offset: one ds_read_b128 per
+//     (tap, k-step) with an immediate offset, shared by the wave's NT output-channel tiles;
+//   * accumulators are transposed (output channel in the registers, pixel on the lane): bias is the initial value,
+//     scale + residual (forward) / + dX_add (dgrad) are applied to 16-B row chunks obtained with one
+//     v_permlane32_swap per register pair, PixelShuffle(2) outputs leave as 8-B runs (common.py:125-136).
+// Wave roles per shape (waves = CW x KSPLIT x PSLOTS = 4):
+//   150 -> 60 fwd        : CW 2 (one 32-channel tile each, 90 fragments = 360 VGPRs), 2 pixel slots
+//   60 -> 60 fwd / dgrad : CW 1, NT 2 (72 fragments), 4 pixel slots
+//   60 -> 240 fwd + PS   : CW 4, NT 2 (72 fragments), every wave sees every pixel tile (B read once per 2 MFMAs)
+//   60 -> 150 dgrad      : two launches: channels [0,128) as CW 4 x NT 1, channels [128,150) as 4 pixel slots
+//   240 -> 60 dgrad      : the gradient of conv + PixelShuffle(2): contraction over k' = 60 q + c' (q = sub-pixel), read
+//                          straight from the shuffled dY (no un-shuffle pass); CW 2 x KSPLIT 2 (72 / 63 fragments), the
+//                          two K halves exchange one accumulator tile each through LDS and finish one row each.
+// Everything else (fp32, other channel counts, W % 32 != 0, input activation) stays on conv_mfma.hip.
+#include "conv.h"
+#include "mfma.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int PK_FWD = 0, PK_DGRAD = 1, PK_DGRAD_UNSHUF = 2;
+
+// packed weights: fragment (ct, tap, ks) = 64 lanes x 8 bf16; lane (r, h): output channel n = 32 ct + r,
+// contraction k = 16 ks + 8 h + e.
+//   PK_FWD          : Wc[n][k][tap]
+//   PK_DGRAD        : Wc[k][n][8 - tap]                       (contraction over co, mirrored tap)
+//   PK_DGRAD_UNSHUF : Wc[4 c' + q][n][8 - tap], k = 60 q + c' (conv channel 4c'+q is sub-pixel q of channel c')
+__global__ void __launch_bounds__(256) conv3_pack_kernel(const float* __restrict__ Wc, bf16* __restrict__ out, int Cin,
+                                                         int Cout, int K, int N, int ksteps, int ctiles, int mode, float s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // one thread per 8 packed elements (16 B)
+  const int total = ctiles * 9 * ksteps * 64;
+  if (i >= total) return;
+  const int lane = i & 63, f = i >> 6;
+  const int ks = f % ksteps, tap = (f / ksteps) % 9, ct = f / (ksteps * 9);
+  const int n = ct * 32 + (lane & 31);
+  uint32_t w[4];
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2) {
+    float v[2];
+#pragma unroll
+    for (int e1 = 0; e1 < 2; ++e1) {
+      const int k = ks * 16 + (lane >> 5) * 8 + 2 * e2 + e1;
+      float x = 0.f;
+      if (n < N && k < K) {
+        if (mode == PK_FWD) x = Wc[((int64_t)n * Cin + k) * 9 + tap];
+        else if (mode == PK_DGRAD) x = Wc[((int64_t)k * Cin + n) * 9 + (8 - tap)];
+        else {
+          const int cq = Cout / 4, q = k / cq, c = k - q * cq;
+          x = Wc[((int64_t)(4 * c + q) * Cin + n) * 9 + (8 - tap)];
+        }
+      }
+      v[e1] = x * s;   // out_scale rides on the weights: (conv(W) + bias) s = conv(s W) + s bias
+    }
+    w[e2] = pack_bf16x2(v[0], v[1]);
+  }
+  u32x4_a4 o;
+  o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+  *reinterpret_cast<u32x4_a4*>(out + (int64_t)i * 8) = o;
+}
+
+struct C3Args {
+  const bf16* A; int64_t lda;     // input rows; UNSHUF: the shuffled dY (B, 2H, 2W, K/4)
+  int a_bytes;                    // extent of A in bytes (< 2^31): the buffer descriptor's range
+  const bf16* Wp;                 // packed weights of this launch's channel tiles (tile 0 = channel n0)
+  const float* bias;              // (N) or null
+  const bf16* R; int64_t ldr;     // forward residual / dgrad dX_add, output geometry; or null
+  bf16* Y; int64_t ldy;
+  int B, H, W;                    // the conv's resolution
+  int n0, N;                      // first output channel of this launch, total output channels (store mask)
+  float s;
+  int SH, nys, nstrips;           // strip height, strips per image column, total strips
+  unsigned long long* stamps;     // debug build: [grid][8] cycle counters (RDST_C3_STAMPS), else null
+
+};
+
+constexpr int pix_stride(int K) {  // bytes: >= 2K, multiple of 16, odd number of 16-B slots
+  int s = (2 * K + 15) / 16 * 16;
+  if (((s / 16) & 1) == 0) s += 16;
+  return s;
+}
+
+template <int K, int CW, int NT, int KSPLIT, int PSLOTS, int RPS, bool UNSHUF, bool PSTORE>
+struct C3Cfg {
+  static constexpr int KSTEPS = (K + 15) / 16;
+  static constexpr int KSH = (KSTEPS + KSPLIT - 1) / KSPLIT;
+  static constexpr int PSTRIDE = pix_stride(K);
+  static constexpr int SPP = PSTRIDE / 16;                 // 16-B slots per pixel
+  static constexpr int RPIECES = (34 * SPP + 63) / 64;     // 1-KB LDS-DMA pieces per ring row
+  static constexpr int ROWB = RPIECES * 1024;
+  static constexpr int NR = 2 * RPS + 2;
+  static constexpr int RPW = RPS / PSLOTS;                 // output rows per wave and step
+  static constexpr int XBUF = KSPLIT > 1 ? 4 * NT * 4096 : 0;   // accumulator exchange, per wave NT tiles of 4 KB
+  static constexpr int BIAS_OFF = NR * ROWB + 64;          // 64 B of zeroed slack behind the ring (k-step over-read)
+  static constexpr int XBUF_OFF = BIAS_OFF + CW * NT * 32 * 4;
+  static constexpr int SMEM = XBUF_OFF + XBUF;
+  static constexpr int DSLOTS = (2 * K + 15) / 16;         // slots of a pixel that carry data
+  static constexpr int NA_MAX = 60;                        // weight fragments kept in AGPRs (240 of the 256)
+  static_assert(CW * KSPLIT * PSLOTS == 4, "4 waves");
+  static_assert(RPS % PSLOTS == 0, "rows per step");
+  static_assert(!UNSHUF || (K % 16 == 0), "un-shuffled rows: two sub-pixel pairs of K/2 channels, whole 16-B slots");
+  static_assert(KSPLIT == 1 || RPW == 2, "the K halves exchange one row each");
+};
+
+template <int K, int CW, int NT, int KSPLIT, int PSLOTS, int RPS, bool UNSHUF, bool PSTORE>
+__global__ void __launch_bounds__(256, 1) conv3_kernel(const C3Args p) {
+  using CF = C3Cfg<K, CW, NT, KSPLIT, PSLOTS, RPS, UNSHUF, PSTORE>;
+  constexpr int KSTEPS = CF::KSTEPS, KSH = CF::KSH, PSTRIDE = CF::PSTRIDE, ROWB = CF::ROWB, NR = CF::NR, RPW = CF::RPW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave % CW, kh = (wave / CW) % KSPLIT, ps = wave / (CW * KSPLIT);
+  const int H = p.H, W = p.W;
+  unsigned long long tprev = RDST_DBGV(p.stamps) ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_ADD(k)                                                   \
+  if (RDST_DBGV(p.stamps)) {                                           \
+    const unsigned long long tn_ = __builtin_readcyclecounter();       \
+    tacc[k] += tn_ - tprev;                                            \
+    tprev = tn_;                                                       \
+  }
+  // buffer descriptor of the input tensor (raw buffer, byte offsets, range = a_bytes: reads behind it return zeros), in SGPRs
+  typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
+  u32x4s_t rsrc;
+  rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.A);
+  rsrc.y = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.A >> 32) & 0xffffu);
+  rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)p.a_bytes);
+  rsrc.w = 0x00020000u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  lds_zero16(smem, CF::BIAS_OFF, tid, 256);
+  float* biasL = reinterpret_cast<float*>(smem + CF::BIAS_OFF);
+  for (int i = tid; i < CW * NT * 32; i += 256) biasL[i] = (p.bias && p.n0 + i < p.N) ? p.bias[p.n0 + i] * p.s : 0.f;
+  __syncthreads();
+
+  // ---- strips and their input rows -------------------------------------------------------------------------
+  // rel row q of a strip = input row y0 - 1 + q, ring slot q % NR.  A ring row is RPIECES LDS-DMA pieces of 1 KB
+  // (buffer_load_dwordx4 ... lds: lane l of a piece fills 16-B slot l; the SOURCE address is per lane): slot -> (pixel,
+  // 16-B chunk of its channel row); pad slots, pixels outside the image and the bytes behind the tensor's end are
+  // out-of-range offsets of the buffer descriptor, which the hardware turns into zeros.  No staging registers, no
+  // ds_write; the pieces of a row set are dealt round-robin to the 4 waves.
+  const int nxs = W / 32;
+  struct Strip { int b, y0, x0, nrows; };
+  auto decode = [&](int strip) {
+    const int xs = strip % nxs, tq = strip / nxs;
+    const int ysg = tq % p.nys;
+    Strip s;
+    s.b = tq / p.nys; s.y0 = ysg * p.SH; s.x0 = xs * 32;
+    s.nrows = (H - s.y0 < p.SH) ? H - s.y0 : p.SH;
+    return s;
+  };
+  auto lane_off = [&](const Strip& sp, int pi) {   // byte offset of this lane's 16-B chunk inside an input row, < 0: zeros
+    const int sidx = pi * 64 + lane;
+    const int px = sidx / CF::SPP, sl = sidx - px * CF::SPP;
+    const int x = sp.x0 - 1 + px;
+    const bool ok = x >= 0 && x < W && px < 34 && sl < CF::DSLOTS;
+    int off;
+    if constexpr (UNSHUF) {
+      constexpr int HS = CF::DSLOTS / 2;                 // slots per sub-pixel pair (i = 0 / 1)
+      const int i2 = sl >= HS ? 1 : 0;
+      off = (i2 * 2 * W + 2 * x) * ((int)p.lda * 2) + (sl - i2 * HS) * 16;
+    } else {
+      off = x * ((int)p.lda * 2) + sl * 16;
+    }
+    return ok ? off : -1;
+  };
+  auto dma = [&](const Strip& sp, int rel, int pi, int loff) {
+    const int y = sp.y0 - 1 + rel;
+    const bool rowok = y >= 0 && y < H;
+    const int rowbase = UNSHUF ? (int)((((int64_t)sp.b * (2 * H) + 2 * y) * (int64_t)(2 * W)) * (p.lda * 2))
+                               : (int)((((int64_t)sp.b * H + y) * W) * (p.lda * 2));
+    const int off = (rowok && loff >= 0) ? rowbase + loff : p.a_bytes;   // out of range -> the DMA writes zeros
+    // Inline asm, not the builtin: the compiler orders every later ds_read behind a builtin LDS-DMA with s_waitcnt
+    // vmcnt(0) (it cannot tell that the slots differ), which exposes the whole HBM latency in every step.  The waits are
+    // placed by hand: vmcnt(0) after a step's MFMAs, in front of the barrier that publishes the rows.
+    const uint32_t ldst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((rel % NR) * ROWB + pi * 1024));
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rsrc) : "memory");
+  };
+  auto first_rows = [&](const Strip& sp) {           // rel rows 0 .. RPS + 1
+    for (int q = wave; q < (RPS + 2) * CF::RPIECES; q += 4) {
+      const int rr = q / CF::RPIECES, pi = q - rr * CF::RPIECES;
+      dma(sp, rr, pi, lane_off(sp, pi));
+    }
+  };
+  if ((int)blockIdx.x < p.nstrips) first_rows(decode(blockIdx.x));   // in flight together with the weight loads below
+
+  // ---- this wave's weight fragments: registers for the whole kernel -------------------------------------------
+  // The register file is 256 VGPRs + 256 AGPRs per lane; an MFMA takes its A operand from either.  Left alone, the
+  // compiler keeps "spilling" fragments to AGPRs and copies each back (4 v_accvgpr_read per MFMA) under maximal
+  // register pressure, which also serialises every ds_read with its MFMA.  So the first NA fragments are LOADED INTO
+  // AGPRs by hand (inline asm, "=a": the value's register class is then the accumulator file and the MFMA reads it
+  // there) and only the rest live in VGPRs.
+  constexpr int NFR = NT * 9 * KSH;
+  constexpr int NA = NFR < CF::NA_MAX ? NFR : CF::NA_MAX, NV = NFR - NA;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t wfa[NA > 0 ? NA : 1];
+  Pack16 wfv[NV > 0 ? NV : 1];
+  auto wsrc = [&](int f, bool& real) {
+    const int t = f / (9 * KSH), rem = f - t * (9 * KSH), tap = rem / KSH, kk = rem - tap * KSH;
+    const int ks = kh * KSH + kk;
+    real = ks < KSTEPS;                      // the short K half pads with a zero fragment (its partner has KSH real ones)
+    return reinterpret_cast<const char*>(p.Wp) + ((((int64_t)(cg * NT + t) * 9 + tap) * KSTEPS + (real ? ks : KSTEPS - 1)) * 64 + lane) * 16;
+  };
+#pragma unroll
+  for (int f = 0; f < NA; ++f) {
+    bool real;
+    const char* src = wsrc(f, real);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wfa[f]) : "v"(src) : "memory");
+  }
+#pragma unroll
+  for (int f = 0; f < NV; ++f) {
+    bool real;
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(wsrc(NA + f, real));
+    wfv[f].w[0] = real ? v.x : 0u; wfv[f].w[1] = real ? v.y : 0u; wfv[f].w[2] = real ? v.z : 0u; wfv[f].w[3] = real ? v.w : 0u;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int f = 0; f < NA; ++f) {
+    bool real;
+    (void)wsrc(f, real);
+    if (KSPLIT > 1 && !real) wfa[f] = u32x4_t{0u, 0u, 0u, 0u};
+    asm volatile("" : "+a"(wfa[f]));         // ordered behind the wait: every use of the fragment depends on this
+  }
+  auto wfrag = [&](int t, int tap, int kk) {
+    const int f = (t * 9 + tap) * KSH + kk;
+    return f < NA ? __builtin_bit_cast(bf16x8_t, wfa[f < NA ? f : 0]) : __builtin_bit_cast(bf16x8_t, wfv[f < NA ? 0 : f - NA]);
+  };
+  __syncthreads();
+  STAMP_ADD(0);
+  for (int strip = blockIdx.x; strip < p.nstrips; strip += gridDim.x) {
+    const Strip sp = decode(strip);
+    const int b = sp.b, y0 = sp.y0, x0 = sp.x0, nrows = sp.nrows;
+    const int nsteps = (nrows + RPS - 1) / RPS;
+    if (strip != (int)blockIdx.x) {
+      first_rows(sp);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // the pieces this wave loads in every step: fixed (row-in-step, piece) pairs -> their lane offsets are loop invariants
+    constexpr int NPW = (RPS * CF::RPIECES + 3) / 4;
+    int loff[NPW];
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) loff[k] = lane_off(sp, (wave + 4 * k) % CF::RPIECES);
+    STAMP_ADD(1);
+
+    for (int j = 0; j < nsteps; ++j) {
+      const bool more = j + 1 < nsteps;
+      // residual / dX_add chunks of this step's outputs: in flight during the MFMAs
+      constexpr int RFIN = KSPLIT == 2 ? 1 : RPW;           // rows this wave finishes per step
+      uint32_t rpre[RFIN][NT][2][4];
+      if constexpr (!PSTORE) {
+        if (p.R) {
+#pragma unroll
+          for (int i = 0; i < RFIN; ++i) {
+            const int yo = j * RPS + (KSPLIT == 2 ? kh : i) * PSLOTS + ps;
+            const int yc = y0 + (yo < nrows ? yo : 0);
+            const int pix = (b * H + yc) * W + x0 + r;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int gp = 0; gp < 2; ++gp) {
+                const int cb = p.n0 + (cg * NT + t) * 32 + 8 * (2 * gp + h);
+                const int nv = p.N - cb;
+                const bf16* rp = p.R + (pix * (int)p.ldr + (nv > 0 ? cb : 0));
+                if (nv >= 8) {
+                  const u32x4_a4 q4 = *reinterpret_cast<const u32x4_a4*>(rp);
+                  rpre[i][t][gp][0] = q4.x; rpre[i][t][gp][1] = q4.y; rpre[i][t][gp][2] = q4.z; rpre[i][t][gp][3] = q4.w;
+                } else {
+#pragma unroll
+                  for (int d = 0; d < 4; ++d) rpre[i][t][gp][d] = (2 * d + 2 <= nv) ? *reinterpret_cast<const uint32_t*>(rp + 2 * d) : 0u;
+                }
+              }
+          }
+        }
+      }
+      STAMP_ADD(2);
+
+      f32x16 acc[RPW][NT];
+      bool live[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int yo = j * RPS + i * PSLOTS + ps;        // output row inside the strip
+        live[i] = yo < nrows;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (kh == 0) {   // bias = initial accumulator: register group g4 holds channels 8 g4 + 4 h .. + 3
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 bq = *reinterpret_cast<const float4*>(biasL + (cg * NT + t) * 32 + 8 * g4 + 4 * h);
+              acc[i][t][4 * g4] = bq.x; acc[i][t][4 * g4 + 1] = bq.y; acc[i][t][4 * g4 + 2] = bq.z; acc[i][t][4 * g4 + 3] = bq.w;
+            }
+          } else {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][t][v] = 0.f;
+          }
+        }
+        if (live[i]) {
+          // one B fragment per (tap, k-step), read PD fragments ahead of the MFMA that consumes it (the wave is alone
+          // on its SIMD: nothing else hides the LDS latency)
+          constexpr int NSEQ = 9 * KSH, PD = 6, DSTEP = 3;
+          const char* base[3];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) base[ky] = smem + ((yo + ky) % NR) * ROWB + r * PSTRIDE + h * 16 + kh * (KSH * 32);
+          auto rd = [&](int idx) {
+            const int ky = idx / (3 * KSH), rem = idx - ky * (3 * KSH), kx = rem / KSH, kk = rem - kx * KSH;
+            return *reinterpret_cast<const Pack16*>(base[ky] + kx * PSTRIDE + kk * 32);
+          };
+          Pack16 bq[PD];
+#pragma unroll
+          for (int u = 0; u < PD; ++u) bq[u] = rd(u);
+#pragma unroll
+          for (int idx = 0; idx < NSEQ; ++idx) {
+            const int tap = idx / KSH, kk = idx - tap * KSH;
+            const Pack16 cur = bq[idx % PD];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag(t, tap, kk), __builtin_bit_cast(bf16x8_t, cur), acc[i][t], 0, 0, 0);
+            if (idx + PD < NSEQ) bq[idx % PD] = rd(idx + PD);
+            // the next step's rows (they land in slots no wave reads in this step): one DMA piece every DSTEP MFMAs of
+            // the wave's first row, so that its issue (60-180 cycles each) runs in the shadow of the matrix pipe
+            if (i == 0 && idx % DSTEP == DSTEP - 1 && idx / DSTEP < NPW) {
+              constexpr int kq = 0;
+              (void)kq;
+              const int k = idx / DSTEP;
+              const int q = wave + 4 * k;
+              if (more && q < RPS * CF::RPIECES) {
+                const int rr = q / CF::RPIECES, pi = q - rr * CF::RPIECES;
+                dma(sp, (j + 1) * RPS + 2 + rr, pi, loff[k]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the read PD fragments ahead of its MFMA (the scheduler pairs them up otherwise)
+          }
+        }
+      }
+
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's rows have landed (issued >= half a step ago)
+      STAMP_ADD(3);
+      int fin = 0;                                        // the row (index into acc) this wave finishes
+      if constexpr (KSPLIT == 2) {
+        // the two K halves of a channel group hold partial sums of the same two rows: half kh gives away row 1 - kh
+        // and finishes row kh
+        float* xb = reinterpret_cast<float*>(smem + CF::XBUF_OFF);
+        float* mine = xb + (size_t)wave * NT * 1024;
+        const int partner = (ps * KSPLIT + (1 - kh)) * CW + cg;
+        const float* theirs = xb + (size_t)partner * NT * 1024;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) mine[(t * 16 + v) * 64 + lane] = kh == 0 ? acc[1][t][v] : acc[0][t][v];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const float o = theirs[(t * 16 + v) * 64 + lane];
+            acc[0][t][v] = (kh == 0 ? acc[0][t][v] : acc[1][t][v]) + o;
+          }
+        live[0] = kh == 0 ? live[0] : live[1];
+        fin = kh;
+      }
+
+      STAMP_ADD(4);
+      // ---- epilogue -------------------------------------------------------------------------------------------
+#pragma unroll
+      for (int i = 0; i < (KSPLIT == 2 ? 1 : RPW); ++i) {
+        if (!live[i]) continue;
+        const int yo = j * RPS + (KSPLIT == 2 ? fin : i) * PSLOTS + ps;
+        const int y = y0 + yo, x = x0 + r;
+
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int cb0 = p.n0 + (cg * NT + t) * 32;      // first channel of the tile
+          if constexpr (PSTORE) {
+            // PixelShuffle(2): conv channel n = 4 c' + 2 i + j -> channel c' of output pixel (2y+i, 2x+j).  Register v
+            // holds n = 8 (v>>2) + 4h + (v&3): for q = v & 3 the lane owns c' = 2 (v>>2) + h; one swap per register pair
+            // gives each lane half 4 consecutive c' of that sub-pixel
+            const int cq = cb0 / 4 + 4 * h;
+            const int Co = p.N / 4;
+            bf16* ybase = p.Y + (((b * (2 * H) + 2 * y) * (2 * W) + 2 * x) * (int)p.ldy + cq);   // (extent < 2^31 bytes)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][t][q]), __float_as_uint(acc[i][t][8 + q]), false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][t][4 + q]), __float_as_uint(acc[i][t][12 + q]), false, false);
+              bf16* dst = ybase + ((q >> 1) * 2 * W + (q & 1)) * (int)p.ldy;
+              if (cq + 4 <= Co) {
+                u32x2_a4 u;
+                u.x = pack_bf16x2(__uint_as_float(s0[0]), __uint_as_float(s0[1]));
+                u.y = pack_bf16x2(__uint_as_float(s1[0]), __uint_as_float(s1[1]));
+                *reinterpret_cast<u32x2_a4*>(dst) = u;
+              } else if (cq + 2 <= Co) {
+                *reinterpret_cast<uint32_t*>(dst) = pack_bf16x2(__uint_as_float(s0[0]), __uint_as_float(s0[1]));
+              }
+            }
+          } else {
+            const int pix = (b * H + y) * W + x;   // (extents < 2^31 bytes: 32-bit element offsets)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              float c8[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][t][8 * gp + e]),
+                                                                 __float_as_uint(acc[i][t][8 * gp + 4 + e]), false, false);
+                c8[e] = __uint_as_float(sw[0]);
+                c8[4 + e] = __uint_as_float(sw[1]);
+              }
+              const int cb = cb0 + 8 * (2 * gp + h);      // the lane's 8 consecutive channels
+              const int nv = p.N - cb;                    // valid channels from cb on (N is even)
+              if (nv <= 0) continue;
+              if (p.R) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { c8[2 * d] += bf16lo(rpre[i][t][gp][d]); c8[2 * d + 1] += bf16hi(rpre[i][t][gp][d]); }
+              }
+              bf16* yp = p.Y + (pix * (int)p.ldy + cb);
+              if (nv >= 8) {
+                u32x4_a4 u;
+                u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+                u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+                *reinterpret_cast<u32x4_a4*>(yp) = u;
+              } else {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                  if (2 * d + 2 <= nv) *reinterpret_cast<uint32_t*>(yp + 2 * d) = pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
+              }
+            }
+          }
+        }
+      }
+      STAMP_ADD(5);
+      __syncthreads();
+      STAMP_ADD(6);
+    }
+  }
+  if (RDST_DBGV(p.stamps) && tid == 0)
+    for (int k = 0; k < 8; ++k) p.stamps[(size_t)blockIdx.x * 8 + k] = tacc[k];
+#undef STAMP_ADD
+}
+
+template <int K, int CW, int NT, int KSPLIT, int PSLOTS, int RPS, bool UNSHUF, bool PSTORE>
+int launch_c3(C3Args& p, int ctile0, hipStream_t st, const char* what) {
+  using CF = C3Cfg<K, CW, NT, KSPLIT, PSLOTS, RPS, UNSHUF, PSTORE>;
+  p.Wp += (int64_t)ctile0 * 9 * CF::KSTEPS * 512;
+  p.n0 = ctile0 * 32;
+  int SH = 16;
+  auto count = [&](int sh) { return (int64_t)p.B * ((p.H + sh - 1) / sh) * (p.W / 32); };
+  while (count(SH) < 256 && SH > 2 * RPS) SH /= 2;
+  if (SH < RPS) SH = RPS;
+  p.SH = SH;
+  p.nys = (p.H + SH - 1) / SH;
+  const int64_t ns = count(SH);
+  if (ns >= (1ll << 31)) return RDST_ENOTSUP;
+  p.nstrips = (int)ns;
+  const int grid = ns < 256 ? (int)ns : 256;
+  auto kern = conv3_kernel<K, CW, NT, KSPLIT, PSLOTS, RPS, UNSHUF, PSTORE>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    attr = true;
+  }
+  p.stamps = rdst_stamps_begin("RDST_C3_STAMPS", grid, 8, st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), CF::SMEM, st, p);
+  rdst_stamps_end(what, p.stamps, grid, 8, st);   // 0 weights, 1 first rows, 2 dma issue, 3 mfma, 4 exchange, 5 epilogue, 6 barrier
+  return rdst_launch_status(what);
+}
+
+int pack(const float* Wc, bf16* out, int Cin, int Cout, int K, int N, int mode, float s, hipStream_t st) {
+  const int ksteps = (K + 15) / 16, ctiles = (N + 31) / 32;
+  const int total = ctiles * 9 * ksteps * 64;
+  hipLaunchKernelGGL(conv3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, Wc, out, Cin, Cout, K, N, ksteps,
+                     ctiles, mode, s);
+  return rdst_launch_status("conv3_pack");
+}
+
+bool rows_aligned(const void* ptr, int64_t ld) { return ((uintptr_t)ptr & 3) == 0 && (ld & 1) == 0; }
+
+}  // namespace
+
+size_t conv3_pack_bytes(int Cin, int Cout) {
+  // the larger of the forward image (K = Cin, N = Cout) and the dgrad image (K = Cout, N = Cin)
+  const size_t f = (size_t)((Cout + 31) / 32) * 9 * ((Cin + 15) / 16) * 1024;
+  const size_t d = (size_t)((Cin + 31) / 32) * 9 * ((Cout + 15) / 16) * 1024;
+  return (f > d ? f : d) + 256;
+}
+
+// Forward.  RDST_ENOTSUP = not one of the covered shapes (the caller falls back to conv_mfma.hip).
+int conv3_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr,
+                   bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st) {
+  if (!wpack || g.ks != 3 || g.pad != 1 || in_act || g.W % 32 || ((uintptr_t)wpack & 15)) return RDST_ENOTSUP;
+  const bool ps = g.r == 2;
+  if (!(g.r == 1 || (ps && !R))) return RDST_ENOTSUP;
+  const int cy = g.Cout / (g.r * g.r);
+  if (!rows_aligned(X, ldx) || !rows_aligned(Y, ldy) || (R && !rows_aligned(R, ldr)) || (cy & 1)) return RDST_ENOTSUP;
+  int shape = 0;
+  if (g.Cin == 150 && g.Cout == 60 && !ps) shape = 1;
+  else if (g.Cin == 60 && g.Cout == 60 && !ps) shape = 2;
+  else if (g.Cin == 60 && g.Cout == 240 && ps) shape = 3;
+  if (!shape) return RDST_ENOTSUP;
+  bf16* wp = reinterpret_cast<bf16*>(wpack);
+  if (int rc = pack(Wc, wp, g.Cin, g.Cout, g.Cin, g.Cout, PK_FWD, s, st)) return rc;
+  const int64_t abytes = ((g.pixels() - 1) * ldx + g.Cin) * 2;
+  const int64_t opix = g.pixels() * g.r * g.r;
+  if (abytes >= (1ll << 31) || opix * ldy * 2 >= (1ll << 31) || (R && opix * ldr * 2 >= (1ll << 31))) return RDST_ENOTSUP;
+  C3Args p{};
+  p.A = X; p.lda = ldx; p.a_bytes = (int)abytes; p.Wp = wp; p.bias = bias; p.R = R; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
+  p.B = g.B; p.H = g.H; p.W = g.W; p.N = g.Cout; p.s = s;
+  if (shape == 1) return launch_c3<150, 2, 1, 1, 2, 2, false, false>(p, 0, st, "conv3_fwd_150_60");
+  if (shape == 2) return launch_c3<60, 1, 2, 1, 4, 4, false, false>(p, 0, st, "conv3_fwd_60_60");
+  return launch_c3<60, 4, 2, 1, 1, 2, false, true>(p, 0, st, "conv3_fwd_60_240_ps");
+}
+
+// dgrad: dX = dX_add + s * conv^T(dY).  dY is in the OUTPUT geometry (pixel-shuffled when g.r == 2).
+int conv3_dgrad_bf16(const float* Wc, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc,
+                     int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st) {
+  if (!wpack || g.ks != 3 || g.pad != 1 || in_act || g.W % 32 || ((uintptr_t)wpack & 15)) return RDST_ENOTSUP;
+  if (!rows_aligned(dY, lddy) || !rows_aligned(dX, lddx) || (acc && !rows_aligned(acc, ldacc))) return RDST_ENOTSUP;
+  int shape = 0;
+  if (g.Cin == 150 && g.Cout == 60 && g.r == 1) shape = 1;
+  else if (g.Cin == 60 && g.Cout == 60 && g.r == 1) shape = 2;
+  else if (g.Cin == 60 && g.Cout == 240 && g.r == 2 && lddy == 60) shape = 3;   // sub-pixel pairs contiguous in dY
+  if (!shape) return RDST_ENOTSUP;
+  const int64_t abytes = ((g.pixels() * g.r * g.r - 1) * lddy + g.Cout / (g.r * g.r)) * 2;
+  if (abytes >= (1ll << 31) || g.pixels() * lddx * 2 >= (1ll << 31) || (acc && g.pixels() * ldacc * 2 >= (1ll << 31))) return RDST_ENOTSUP;
+  bf16* wp = reinterpret_cast<bf16*>(wpack);
+  if (int rc = pack(Wc, wp, g.Cin, g.Cout, g.Cout, g.Cin, shape == 3 ? PK_DGRAD_UNSHUF : PK_DGRAD, s, st)) return rc;
+  C3Args p{};
+  p.A = dY; p.lda = lddy; p.a_bytes = (int)abytes; p.Wp = wp; p.bias = nullptr; p.R = acc; p.ldr = ldacc; p.Y = dX; p.ldy = lddx;
+  p.B = g.B; p.H = g.H; p.W = g.W; p.N = g.Cin; p.s = s;
+  if (shape == 1) {
+    C3Args pa = p;
+    if (int rc = launch_c3<60, 4, 1, 1, 1, 2, false, false>(pa, 0, st, "conv3_dgrad_60_150a")) return rc;
+    return launch_c3<60, 1, 1, 1, 4, 4, false, false>(p, 4, st, "conv3_dgrad_60_150b");
+  }
+  if (shape == 2) return launch_c3<60, 1, 2, 1, 4, 4, false, false>(p, 0, st, "conv3_dgrad_60_60");
+  return launch_c3<240, 2, 1, 2, 1, 2, true, false>(p, 0, st, "conv3_dgrad_240_60_unshuf");
+}

@@ -4,7 +4,7 @@
 
 thread_local char g_rdst_err[256] = {0};
 
-extern "C" int rdst_abi_version(void) { return 1; }
+extern "C" int rdst_abi_version(void) { return 2; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {

@@ -598,9 +598,11 @@ class _ConvRows(torch.autograd.Function):
             if residual.dtype != x.dtype or tuple(residual.shape) != tuple(y.shape):
                 raise ValueError("rdst_amd.conv_rows: residual must match the output shape/dtype")
             r_r, ldr = _rows(residual)
+        nws = lib.rdst_conv_fwd_workspace(Cin, Cout, k)
+        wsp = _workspace(nws, x.device)
         _lib.check(lib.rdst_conv_fwd(x_r.data_ptr(), ldx, int(in_act), w.data_ptr(), _ptr(b), _ptr(r_r), ldr,
-                                     y.data_ptr(), cy, B, H, W, Cin, Cout, k, float(out_scale), r, _dtype_code(x),
-                                     _stream()), "rdst_conv_fwd")
+                                     y.data_ptr(), cy, wsp.data_ptr(), nws, B, H, W, Cin, Cout, k, float(out_scale), r,
+                                     _dtype_code(x), _stream()), "rdst_conv_fwd")
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.save_for_backward(x_r, w)
         ctx.meta = (B, H, W, Cin, Cout, k, ldx, int(in_act), float(out_scale), r, bias is not None,
