@@ -62,3 +62,6 @@ int conv3_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, cons
                    bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st);
 int conv3_dgrad_bf16(const float* Wc, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc,
                      int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st);
+size_t conv3_wgrad_slab_bytes(int Cin, int Cout);
+int conv3_wgrad_bf16(const bf16* X, int64_t ldx, int in_act, const bf16* dY, int64_t lddy, float* dW, float* dbias, float* slab,
+                     const ConvGeom& g, float s, hipStream_t st);

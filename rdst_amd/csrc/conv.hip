@@ -148,6 +148,8 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
   // workspace carve: [packed dgrad weights][generic split-K slab][small][MFMA scratch: un-shuffled dY, wgrad slab]
   void* wpack = wsp;
   wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + conv3_pack_bytes(g.Cin, g.Cout));
+  float* w3slab = wsp;
+  wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + (g.ks == 3 ? conv3_wgrad_slab_bytes(g.Cin, g.Cout) : 0));
   float* slab = wsp;
   float* small = slab + (int64_t)kMaxSplits * wtotal;
   char* mscr = reinterpret_cast<char*>(small + (int64_t)kSmallBlocks * g.Cout + 64);
@@ -163,7 +165,12 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
       if (rc == 0) dxdone = true;
       else if (rc != RDST_ENOTSUP) return rc;
     }
-    if (dxdone && !dW && !dbias) return 0;
+    if (dW || dbias) {
+      const int rc = conv3_wgrad_bf16(X, ldx, in_act, dY, lddy, dW, dbias, w3slab, g, s, st);
+      if (rc == 0) { dW = nullptr; dbias = nullptr; }
+      else if (rc != RDST_ENOTSUP) return rc;
+    }
+    if ((dxdone || !dX) && !dW && !dbias) return 0;
   }
   // MFMA fast paths want dY as plain (B*H*W, Cout) rows
   int prc = 0;
@@ -258,7 +265,7 @@ extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const floa
 extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
   ConvGeom g{B, H, W, Cin, Cout, ksize, ksize / 2, 2};  // r = 2 reserves room for an un-shuffled dY
-  return conv3_pack_bytes(Cin, Cout) + sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
+  return conv3_pack_bytes(Cin, Cout) + (ksize == 3 ? conv3_wgrad_slab_bytes(Cin, Cout) : 0) + sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
          conv_mfma_scratch_bytes(g) + sizeof(float) * conv_c1_slab_floats(Cin);
 }
 
