@@ -114,100 +114,6 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # ------------------------------------------------------------------------------------------------
 # K1 / K2: fused window attention
 # ------------------------------------------------------------------------------------------------
-class KernelTimer:
-    """Collects (start, end, algorithmic_bytes) HIP-event pairs around every K1 / K2 launch, recorded
-    on the stream the kernel is launched on (torch's current stream).  bench.py uses it for the
-    `roofline` object; it is None (no events, no overhead) everywhere else."""
-
-    def __init__(self, capture=False):
-        self.fwd, self.bwd = [], []
-        # capture=True also keeps a re-launch closure (and its operands) per K1 / K2 call, so the very
-        # same launches can be replayed back to back inside ONE event bracket: a bracket around a single
-        # 20-50 us kernel reads 5-10 us high (measured against rocprofv3 kernel durations)
-        self.capture = capture
-        self.fwd_calls, self.bwd_calls = [], []
-
-    def replay(self, which="fwd", reps=3):
-        """Average launch duration (ms) of the captured launches replayed back to back on the
-        current stream, one event pair around `reps` passes over all of them."""
-        calls = getattr(self, which + "_calls")
-        if not calls:
-            return None
-        for f, _keep in calls:  # one untimed pass: first-touch effects out of the bracket
-            f()
-        torch.cuda.synchronize()
-        # one pass captured into a HIP graph: the launches then follow each other without host gaps
-        graph = None
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    for f, _keep in calls:
-                        f()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = g
-        except Exception:  # noqa: BLE001 - capture is an optimisation of the measurement only
-            graph = None
-            torch.cuda.synchronize()
-        e0 = _event()
-        for _ in range(reps):
-            if graph is not None:
-                graph.replay()
-            else:
-                for f, _keep in calls:
-                    f()
-        e1 = _event()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / (reps * len(calls))
-
-    def bracket_overhead(self, which="fwd", replay_ms=None):
-        """What an event pair around ONE launch adds to its duration (ms): the same captured launches, replayed
-        eagerly with a pair around each, against their back-to-back replay average."""
-        calls = getattr(self, which + "_calls")
-        if not calls:
-            return None
-        if replay_ms is None:
-            replay_ms = self.replay(which, 1)
-        torch.cuda.synchronize()
-        pairs = []
-        for f, _keep in calls:
-            a = _event()
-            f()
-            pairs.append((a, _event()))
-        torch.cuda.synchronize()
-        single = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
-        return max(0.0, single - replay_ms)
-
-    @staticmethod
-    def _ms(pairs):
-        return [a.elapsed_time(b) for a, b, _ in pairs]
-
-    def summary(self, which="fwd"):
-        pairs = getattr(self, which)
-        ms = self._ms(pairs)
-        nbytes = sum(n for _, _, n in pairs)
-        return {"launches": len(pairs), "total_ms": sum(ms), "bytes": nbytes}
-
-
-_kernel_timer: Optional[KernelTimer] = None
-# measurement only (bench.py): the block forward leaves K1 out, so (step with K1) - (step without) = K1's time in the step
-SKIP_K1_FOR_TIMING = False
-
-
-def set_kernel_timer(t: Optional[KernelTimer]) -> None:
-    global _kernel_timer
-    _kernel_timer = t
-
-
-def _event():
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
-
-
 class _WindowAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, table, mask, H, W, heads, ws, shift, scale):
@@ -220,18 +126,9 @@ class _WindowAttention(torch.autograd.Function):
         msk = _param(mask)
         nw = 0 if msk is None else msk.shape[0]
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
-        kt = _kernel_timer
-        e0 = _event() if kt is not None else None
-
-        def launch():
-            _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
-                                          W, C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()),
-                       "rdst_wattn_fwd")
-        launch()
-        if kt is not None:  # algorithmic bytes of K1: read qkv (3C) + write out (C) per token
-            kt.fwd.append((e0, _event(), B * H * W * 4 * C * qkv.element_size()))
-            if kt.capture:
-                kt.fwd_calls.append((launch, (qkv_r, tab, msk, out)))
+        _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
+                                      W, C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()),
+                   "rdst_wattn_fwd")
         ctx.save_for_backward(qkv_r, tab, msk)
         ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw)
         return out
@@ -246,18 +143,9 @@ class _WindowAttention(torch.autograd.Function):
         dtable = _grad_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, qkv.device)
-        kt = _kernel_timer
-        e0 = _event() if kt is not None else None
-
-        def launch():
-            _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
-                                          dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
-                                          C, heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
-        launch()
-        if kt is not None:  # K2: read qkv (3C) + dout (C), write dqkv (3C) per token
-            kt.bwd.append((e0, _event(), B * H * W * 7 * C * qkv.element_size()))
-            if kt.capture:
-                kt.bwd_calls.append((launch, (qkv, tab, msk, dout_r, dqkv, dtable, wsp)))
+        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
+                                      dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
+                                      C, heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
         return dqkv, dtable, None, None, None, None, None, None, None
 
 
@@ -446,20 +334,8 @@ class _SwinBlock(torch.autograd.Function):
         qkv = torch.empty(lead + (3 * C,), dtype=dt, device=dev)
         lin(x_r.data_ptr(), ldx, n1w_, n1b_, ACT_NONE, qkvw_, qkvb_, None, 0, qkv, 3 * C, stats1, C)
         a = torch.empty(lead + (C,), dtype=dt, device=dev)
-        kt = _kernel_timer
-        e0 = _event() if kt is not None else None
-
-        def k1():
-            _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
-                                          heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
-        if SKIP_K1_FOR_TIMING:
-            a.zero_()      # keep the data finite for the kernels behind it; a memset, not an attention
-        else:
-            k1()
-        if kt is not None:
-            kt.fwd.append((e0, _event(), M * 4 * C * x.element_size()))
-            if kt.capture:
-                kt.fwd_calls.append((k1, (qkv, tab_, a)))
+        _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
+                                      heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
         x1 = torch.empty(lead + (C,), dtype=dt, device=dev)
         lin(a.data_ptr(), C, None, None, ACT_NONE, projw_, projb_, x_r.data_ptr(), ldx, x1, C, None, C)
         stats2 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n2w_ is not None else None
@@ -543,18 +419,9 @@ class _SwinBlock(torch.autograd.Function):
         dtab = _grad_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, dev)
-        kt = _kernel_timer
-        e0 = _event() if kt is not None else None
-
-        def k2():
-            _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), 3 * C, tab.data_ptr(), None, 0, da.data_ptr(), C,
-                                          dqkv.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
-                                          heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
-        k2()
-        if kt is not None:
-            kt.bwd.append((e0, _event(), M * 7 * C * x.element_size()))
-            if kt.capture:
-                kt.bwd_calls.append((k2, (qkv, tab, da, dqkv, dtab, wsp)))
+        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), 3 * C, tab.data_ptr(), None, 0, da.data_ptr(), C,
+                                      dqkv.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
+                                      heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
         # LN1 + qkv, plus the residual fan-out of x:  dx = dx1 + LN1'(dqkv Wqkv)
         dx = torch.empty(x.shape, dtype=dt, device=dev) if need[0] else None
         _linear_bwd_call(lib, x, ldx, n1w, n1b, stats1, ACT_NONE, qkvw, dqkv, 3 * C, dx, C, dx1 if need[0] else None, C,
