@@ -158,6 +158,16 @@ int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, cons
                   float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
                   int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
+/* ---- batched fixed-order reductions -------------------------------------------------------------------
+ * Every backward entry point above that splits its contraction over workgroups ends with a deterministic sum of
+ * per-workgroup partial slabs (and, behind a LayerNorm, a finish kernel).  Between _begin() and _end() those
+ * reductions are recorded instead of launched, and _end() runs all of them as two launches on `stream` — the
+ * backward of a Swin block (rdst_mlp_bwd + 2 x rdst_ln_linear_bwd + rdst_wattn_bwd) then needs 2 reduction
+ * launches instead of 6.  Thread-local; the ops' workspaces and outputs must stay alive until _end() returns and all
+ * ops of a batch must be enqueued on `stream`.  Gradients are complete only after _end(). */
+int rdst_reduce_batch_begin(void);
+int rdst_reduce_batch_end(void* stream);
+
 /* ---- layout helpers at the NCHW boundary of the module ------------------------------------------
  * nchw (B,C,H,W) fp32 <-> token rows (B*H*W, C) of `dtype`.  The caller-facing tensors of
  * RDSTSR.forward are fp32 NCHW (rdst_variations.py:1342-1360). */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
     "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,
                            _f, _i, _i, _p]),
+    "rdst_reduce_batch_begin": (_i, []),
+    "rdst_reduce_batch_end": (_i, [_p]),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "rdst_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _p]),

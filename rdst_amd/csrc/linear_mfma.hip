@@ -17,6 +17,7 @@
 //    Per-workgroup partials go to a slab and are summed in fixed order (deterministic).
 #include "linear.h"
 #include "mfma.h"
+#include "reduce_batch.h"
 #include <stdlib.h>
 
 namespace {
@@ -1236,121 +1237,27 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
   }
 }
 
-// dW[n][k] = s * sum_wg slab[wg][n][k] (k < K);  dbias[n] = s * sum_wg slab[wg][n][K]
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int N, int K, int Kx,
-                                                           float s, float* __restrict__ dW, float* __restrict__ dbias) {
-  __shared__ float part[8][33];
-  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + o;
-  const int tot = N * Kx;
-  float a = 0.f;
-  if (i < tot)
-    for (int w0 = sg; w0 < nwg; w0 += 8 * 8) {   // 8 loads in flight, summed in the same fixed order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < nwg) ? slab[(int64_t)(w0 + 8 * u) * tot + i] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
-    }
-  part[sg][o] = a;
-  __syncthreads();
-  if (sg != 0 || i >= tot) return;
-  a = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a += part[k][o];
-  const int n = i / Kx, k = i - n * Kx;
-  if (k < K) {
-    if (dW) dW[(int64_t)n * K + k] = a * s;
-  } else if (dbias) {
-    dbias[n] = a * s;
-  }
-}
-
-// LayerNorm-fused Linear, weight-gradient side.  The wgrad kernel ran on x-hat, so its slabs hold
-// G[n][k] = sum_m dY[m][n] xhat[m][k] (k < K) and db[n] = sum_m dY[m][n] (column K).  Step 1 sums the slabs.
-__global__ void __launch_bounds__(256) wgrad_sum_kernel(const float* __restrict__ slab, int nwg, int tot, float* __restrict__ G) {
-  __shared__ float part[8][33];
-  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + o;
-  float a = 0.f;
-  if (i < tot)
-    for (int w0 = sg; w0 < nwg; w0 += 8 * 8) {   // 8 loads in flight, summed in the same fixed order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < nwg) ? slab[(int64_t)(w0 + 8 * u) * tot + i] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
-    }
-  part[sg][o] = a;
-  __syncthreads();
-  if (sg != 0 || i >= tot) return;
-  a = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a += part[k][o];
-  G[i] = a;
-}
-// Step 2, one block per 8 LayerNorm channels (8 x 128 threads: the whole column of N <= 384 rows is in flight in three
-// rounds of loads; one block per 32 channels walked it in 11 dependent rounds and took 7 us for microseconds of work):
-//   dW[n][k] = s (gamma_k G[n][k] + beta_k db[n]),  dbias[n] = s db[n],
-//   d(gamma)[k] = s sum_n W[n][k] G[n][k],   d(beta)[k] = s sum_n W[n][k] db[n]      (fixed summation order)
-__global__ void __launch_bounds__(1024) wgrad_ln_finish_kernel(const float* __restrict__ G, const float* __restrict__ Wt,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int N, int K, int Kx, float s, float* __restrict__ dW,
-                                                               float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
-  __shared__ float pg[128][9], pb[128][9], qg[8][9], qb[8][9];
-  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-  const int k = blockIdx.x * 8 + tx;
-  const float gk = k < K ? gamma[k] : 0.f, bk = k < K ? beta[k] : 0.f;
-  float ag = 0.f, ab = 0.f;
-#pragma unroll 3
-  for (int n = ty; n < N; n += 128) {
-    const float db = G[(int64_t)n * Kx + K];
-    if (k < K) {
-      const float g = G[(int64_t)n * Kx + k], w = Wt[(int64_t)n * K + k];
-      if (dW) dW[(int64_t)n * K + k] = s * fmaf(gk, g, bk * db);
-      ag = fmaf(w, g, ag);
-      ab = fmaf(w, db, ab);
-    }
-    if (blockIdx.x == 0 && tx == 0 && dbias) dbias[n] = s * db;
-  }
-  pg[ty][tx] = ag;
-  pb[ty][tx] = ab;
-  __syncthreads();
-  if (ty < 8) {   // two fixed-order levels: 8 partial sums of 16 rows, then their sum
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { a += pg[ty * 16 + j][tx]; b += pb[ty * 16 + j][tx]; }
-    qg[ty][tx] = a;
-    qb[ty][tx] = b;
-  }
-  __syncthreads();
-  if (ty == 0 && k < K) {
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { a += qg[j][tx]; b += qb[j][tx]; }
-    if (dgamma) dgamma[k] = s * a;
-    if (dbeta) dbeta[k] = s * b;
-  }
-}
-
+// (the slab sums and the LayerNorm finish live in reduce_batch.hip)
 }  // namespace
 
 int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float* dW, float* dbias, hipStream_t st) {
-  const int tot = N * (K + 1);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, nwg, N, K, K + 1, s, dW, dbias);
-  return rdst_launch_status("wgrad_reduce");
+  rbatch::SumJob j{};
+  j.slab = slab; j.nwg = nwg; j.stride = (int64_t)N * (K + 1); j.tot = N * (K + 1); j.map = rbatch::MAP_LINEAR;
+  j.out = dW; j.out2 = dbias; j.a = K; j.b = K + 1; j.s = s;
+  return rbatch::sum(j, st);
 }
 int wgrad_sum_launch(const float* slab, int nwg, int tot, float* G, hipStream_t st) {
-  hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, nwg, tot, G);
-  return rdst_launch_status("wgrad_sum");
+  rbatch::SumJob j{};
+  j.slab = slab; j.nwg = nwg; j.stride = tot; j.tot = tot; j.map = rbatch::MAP_COPY; j.out = G;
+  return rbatch::sum(j, st);
 }
 // launcher of the LayerNorm finish for other translation units (mlp_mfma.hip)
 int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, const float* ln_b, int N, int K, float s,
                            float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st) {
-  hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 7) / 8), dim3(1024), 0, st, G, Wt, ln_w, ln_b, N, K, K + 1, s, dW, dbias,
-                     dln_w, dln_b);
-  return rdst_launch_status("wgrad_ln_finish");
+  rbatch::FinJob j{};
+  j.G = G; j.Wt = Wt; j.gamma = ln_w; j.beta = ln_b; j.N = N; j.K = K; j.Kx = K + 1; j.s = s;
+  j.dW = dW; j.dbias = dbias; j.dgamma = dln_w; j.dbeta = dln_b;
+  return rbatch::finish(j, st);
 }
 
 template <typename T>
@@ -1464,14 +1371,18 @@ int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, co
   if (int rc = rdst_launch_status("lin_wgrad_mfma")) return rc;
   const int tot = N * p.Kx;
   if (lnfin) {
-    hipLaunchKernelGGL(wgrad_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, tot, G);
-    if (int rc = rdst_launch_status("wgrad_sum")) return rc;
-    hipLaunchKernelGGL(wgrad_ln_finish_kernel, dim3((K + 7) / 8), dim3(1024), 0, st, G, Wt_fin, ln_w, ln_b, N, K, p.Kx, s, dW,
-                       dbias, dln_w, dln_b);
-    return rdst_launch_status("wgrad_ln_finish");
+    rbatch::SumJob sj{};
+    sj.slab = slab; sj.nwg = (int)nwg; sj.stride = tot; sj.tot = tot; sj.map = rbatch::MAP_COPY; sj.out = G;
+    if (int rc = rbatch::sum(sj, st)) return rc;
+    rbatch::FinJob fj{};
+    fj.G = G; fj.Wt = Wt_fin; fj.gamma = ln_w; fj.beta = ln_b; fj.N = N; fj.K = K; fj.Kx = p.Kx; fj.s = s;
+    fj.dW = dW; fj.dbias = dbias; fj.dgamma = dln_w; fj.dbeta = dln_b;
+    return rbatch::finish(fj, st);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, slab, (int)nwg, N, K, p.Kx, s, dW, dbias);
-  return rdst_launch_status("wgrad_reduce");
+  rbatch::SumJob sj{};
+  sj.slab = slab; sj.nwg = (int)nwg; sj.stride = tot; sj.tot = tot; sj.map = rbatch::MAP_LINEAR;
+  sj.out = dW; sj.out2 = dbias; sj.a = K; sj.b = p.Kx; sj.s = s;
+  return rbatch::sum(sj, st);
 }
 }  // namespace
 

@@ -22,6 +22,7 @@
 // and beta into the bias; the reduction forms dW1 = gamma G + beta db^T, d(gamma), d(beta) from G.
 #include "linear.h"
 #include "mfma.h"
+#include "reduce_batch.h"
 #include "wattn_hd.h"
 #include <stdlib.h>
 
@@ -813,38 +814,6 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_fwd_kernel(const MlpFwdArgs 
   }
 }
 
-// sum of the per-workgroup partials in fixed order: G (hid, C+1) for the LayerNorm finish, dW2 (C, hid), db2 (C)
-__global__ void __launch_bounds__(256) mlp_sum_kernel(const float* __restrict__ slab, int nwg, int64_t stride, int C, int hid,
-                                                      float* __restrict__ G, float* __restrict__ dW2, float* __restrict__ db2) {
-  __shared__ float part[8][33];
-  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + o;
-  const int tot = (int)stride;
-  float a = 0.f;
-  if (i < tot)
-    for (int w0 = sg; w0 < nwg; w0 += 8 * 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < nwg) ? slab[(int64_t)(w0 + 8 * u) * stride + i] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
-    }
-  part[sg][o] = a;
-  __syncthreads();
-  if (sg != 0 || i >= tot) return;
-  a = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a += part[k][o];
-  const int n1 = hid * (C + 1);
-  if (i < n1) {
-    G[i] = a;
-  } else {
-    const int i2 = i - n1, jj = i2 / C, c = i2 - jj * C;
-    if (jj < hid) dW2[(int64_t)c * hid + jj] = a;
-    else db2[c] = a;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Backward of a LayerNorm-fused Linear (norm1 + qkv) in ONE pass over (x, dY): the same skeleton as the Mlp
 // backward without the recompute.  Unfused, dY (3C wide) and x are read twice (data-gradient kernel, weight-
@@ -1285,8 +1254,12 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   }
   if (int rc = rdst_launch_status("mlp_bwd")) return rc;
   const int tot = (int)p.slab_stride;
-  hipLaunchKernelGGL(mlp_sum_kernel, dim3((tot + 31) / 32), dim3(256), 0, st, p.slab, (int)grid, p.slab_stride, C, hid, G, dW2, db2);
-  if (int rc = rdst_launch_status("mlp_sum")) return rc;
+  {
+    rbatch::SumJob sj{};
+    sj.slab = p.slab; sj.nwg = (int)grid; sj.stride = p.slab_stride; sj.tot = tot; sj.map = rbatch::MAP_MLP;
+    sj.out = G; sj.out2 = dW2; sj.out3 = db2; sj.a = C; sj.b = hid;
+    if (int rc = rbatch::sum(sj, st)) return rc;
+  }
   return wgrad_ln_finish_launch(G, W1, ln_w, ln_b, hid, C, 1.0f, dW1, db1, dln_w, dln_b, st);
 }
 

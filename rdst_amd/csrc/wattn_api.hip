@@ -1,6 +1,7 @@
 // C-ABI entry points of the window-attention path (K1/K2) + the deterministic d(table) reduction.
 #include "common.h"
 #include "wattn.h"
+#include "reduce_batch.h"
 
 thread_local char g_rdst_err[256] = {0};
 
@@ -22,32 +23,6 @@ int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shi
   if (mask && mask_nw <= 0) return rdst_fail(RDST_EINVAL, "%s: mask given with mask_nw=%d", who, mask_nw);
   g.mask = mask; g.mask_nw = mask ? mask_nw : 1;
   return 0;
-}
-
-// dtable[t*heads + h] = sum over windows of slab[(win*heads + h)*T + t]; fixed summation order.
-__global__ void __launch_bounds__(1024)
-dtable_reduce(const float* __restrict__ slab, float* __restrict__ dtable, int nwin, int heads, int T) {
-  __shared__ float part[16][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int chunks = (T + 63) / 64;
-  const int h = blockIdx.x / chunks, t = (blockIdx.x % chunks) * 64 + lane;
-  float s = 0.f;
-  if (t < T)
-    for (int w0 = grp; w0 < nwin; w0 += 16 * 8) {   // 8 loads in flight, summed in the same fixed order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (w0 + 16 * u < nwin) ? slab[((int64_t)(w0 + 16 * u) * heads + h) * T + t] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-  part[grp][lane] = s;
-  __syncthreads();
-  if (grp == 0 && t < T) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a += part[k][lane];
-    dtable[t * heads + h] = a;
-  }
 }
 
 }  // namespace
@@ -97,7 +72,8 @@ extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* tabl
     if (rc != RDST_ENOTSUP) return rc;
     if (int rc2 = wattn_bwd_generic(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, g, scale, dtype, st)) return rc2;
   }
-  const int chunks = (g.T + 63) / 64;
-  hipLaunchKernelGGL(dtable_reduce, dim3(heads * chunks), dim3(1024), 0, st, slab, dtable, nwin, heads, g.T);
-  return rdst_launch_status("dtable_reduce");
+  rbatch::SumJob sj{};   // dtable[t*heads + h] = sum over the slab rows [heads][T], fixed order
+  sj.slab = slab; sj.nwg = nwin; sj.stride = (int64_t)heads * g.T; sj.tot = heads * g.T; sj.map = rbatch::MAP_DTABLE;
+  sj.out = dtable; sj.a = heads; sj.b = g.T;
+  return rbatch::sum(sj, st);
 }

@@ -185,7 +185,10 @@ def _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy, lddy, dx, lddx, 
         elif keep is not None:
             keep.append(wsp_w)
     elif wgrad or dgrad:
-        call(dx, dx_add, dw, db, dlw, dlb, _workspace(nbytes, dev))
+        wsp = _workspace(nbytes, dev)
+        if keep is not None:   # a reduction batch is open: the slabs are read when it ends
+            keep.append(wsp)
+        call(dx, dx_add, dw, db, dlw, dlb, wsp)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -379,6 +382,25 @@ class _SwinBlock(torch.autograd.Function):
         # end of this block's backward, so they overlap the whole data-gradient chain below.  Everything they
         # read (saved activations, dy, dh, dx1, dqkv, their workspaces) stays referenced until then.
         keep = []
+        # the slab reductions of the four ops below are recorded and run as two launches at the end (rdst_reduce_batch_*);
+        # their workspaces are locals of this function, alive until then
+        batched = not TWO_STREAM_BACKWARD
+        if batched:
+            _lib.check(lib.rdst_reduce_batch_begin(), "rdst_reduce_batch_begin")
+        try:
+            return _SwinBlock._backward_body(ctx, lib, dy_r, lddy, need, keep, dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w,
+                                             dn2b, dfc1w, dfc1b, dfc2w, dfc2b)
+        finally:
+            if batched:
+                _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
+
+    @staticmethod
+    def _backward_body(ctx, lib, dy_r, lddy, need, keep, dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b,
+                       dfc2w, dfc2b):
+        (x, stats1, qkv, a, x1, stats2, h, n1w, n1b, qkvw, qkvb, tab, projw, projb, n2w, n2b, fc1w, fc1b, fc2w,
+         fc2b) = ctx.saved_tensors
+        M, B, H, W, C, hid, heads, ws, shift, scale, ldx, code = ctx.meta
+        dev, dt = x.device, x.dtype
         dx1 = torch.empty_like(x1)
         # K7 when the forward was fused (h was never written) or whenever every Mlp gradient is wanted anyway
         fused_mlp = h is None or (MLP_FUSED and all(t is not None for t in (dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b))
@@ -394,6 +416,7 @@ class _SwinBlock(torch.autograd.Function):
                  out(dn2b, n2b)]
             nb = lib.rdst_mlp_bwd_workspace(M, C, hid)
             wsp_m = _workspace(nb, dev)
+            keep.append(wsp_m)   # read by the batched reductions at the end of backward()
             rc = lib.rdst_mlp_bwd(x1.data_ptr(), C, n2w.data_ptr(), n2b.data_ptr(), stats2.data_ptr(), fc1w.data_ptr(),
                                   _ptr(fc1b), fc2w.data_ptr(), dy_r.data_ptr(), lddy, dx1.data_ptr(), C,
                                   o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
@@ -419,6 +442,7 @@ class _SwinBlock(torch.autograd.Function):
         dtab = _grad_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, dev)
+        keep.append(wsp)
         _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), 3 * C, tab.data_ptr(), None, 0, da.data_ptr(), C,
                                       dqkv.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
                                       heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
