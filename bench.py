@@ -65,7 +65,7 @@ def _alg(name, a, elt):
         B, H, W, C = a[12:16]
         return B * H * W * 7 * C * elt, 10 * B * H * W * a[17] * a[17] * C
     if name == "rdst_ln_linear_fwd":
-        M, K, N = a[12:15]
+        M, K, N = a[14:17]
         return M * (K + N + (N if a[7] else 0)) * elt, (2 * M * K * N if a[5] else 0)
     if name == "rdst_ln_linear_bwd":
         M, K, N = a[19:22]

@@ -89,11 +89,15 @@ int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const fl
  *   Wt, bias  : fp32 (N,K) row-major as nn.Linear stores it / (N) or NULL
  *   R         : optional residual rows (may alias Y), ld_r elements
  *   stats     : fp32 (M,2) {mean, rstd} written by the forward when ln_w != NULL (kept for bwd)
+ *   workspace : rdst_ln_linear_fwd_workspace(K, N) bytes of 16-byte aligned device scratch for the bf16 fragment image
+ *               of the weights that the streaming kernels read (lin3_mfma.hip); NULL / 0 selects the kernels that
+ *               stage the fp32 weights themselves.
  */
+size_t rdst_ln_linear_fwd_workspace(int K, int N);
 int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
                        const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y,
-                       int64_t ld_y, float* stats, int64_t M, int K, int N, float out_scale,
-                       int dtype, void* stream);
+                       int64_t ld_y, float* stats, void* workspace, size_t workspace_bytes, int64_t M, int K,
+                       int N, float out_scale, int dtype, void* stream);
 
 /* Backward of rdst_ln_linear_fwd.  dY (M,N) -> dX (M,K) = dX_add + f'(...) where dX_add is an optional
  * (M,K) tensor added on the way out (NULL = none; it may alias dX for an in-place accumulate) - this is how

@@ -23,7 +23,8 @@ SIGNATURES = {
     "rdst_wattn_fwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rdst_wattn_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
     "rdst_wattn_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _l, _p, _l, _p, _l, _i, _i, _f, _i, _p]),
+    "rdst_ln_linear_fwd_workspace": (_z, [_i, _i]),
+    "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _l, _p, _l, _p, _p, _z, _l, _i, _i, _f, _i, _p]),
     "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
                                 _l, _i, _i, _f, _i, _p]),

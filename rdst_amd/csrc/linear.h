@@ -47,3 +47,10 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
                              const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,
                              int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
                              int64_t M, int K, int N, float s, hipStream_t st);
+
+// streaming forward for the E1 shapes, bf16 (lin3_mfma.hip); RDST_ENOTSUP for everything else.
+// wpack: lin3_pack_bytes(K, N) bytes of 16-byte aligned device scratch (NULL -> RDST_ENOTSUP).
+size_t lin3_pack_bytes(int K, int N);
+int lin3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt, const float* bias,
+                  const bf16* R, int64_t ldr, bf16* Y, int64_t ldy, float* stats, int64_t M, int K, int N, float s, void* wpack,
+                  hipStream_t st);

@@ -410,9 +410,15 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
 
 }  // namespace
 
+extern "C" size_t rdst_ln_linear_fwd_workspace(int K, int N) {
+  if (K <= 0 || N <= 0) return 16;
+  return lin3_pack_bytes(K, N);
+}
+
 extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
                                   const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y, int64_t ld_y,
-                                  float* stats, int64_t M, int K, int N, float out_scale, int dtype, void* stream) {
+                                  float* stats, void* workspace, size_t workspace_bytes, int64_t M, int K, int N,
+                                  float out_scale, int dtype, void* stream) {
   if (!X || !Y) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: null pointer");
   if (M < 0 || K <= 0 || N <= 0) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: bad dimensions");
   if ((ln_w == nullptr) != (ln_b == nullptr)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: ln_w/ln_b must come together");
@@ -423,6 +429,11 @@ extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: bad dtype %d", dtype);
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == RDST_BF16 && workspace && workspace_bytes >= rdst_ln_linear_fwd_workspace(K, N)) {
+    const int rc = lin3_fwd_bf16((const bf16*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, stats, M,
+                                 K, N, out_scale, workspace, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   if (dtype == RDST_F32)
     return fwd_t<float>((const float*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const float*)R, ld_r, (float*)Y, ld_y, stats, M, K, N, out_scale, st);
   return fwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, stats, M, K, N, out_scale, st);

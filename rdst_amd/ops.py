@@ -218,9 +218,11 @@ class _LnLinear(torch.autograd.Function):
                 raise TypeError("rdst_amd.ln_linear: residual dtype differs from the activation dtype")
             r_r, ldr = _rows(residual)
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if lw is not None else None
+        nws = lib.rdst_ln_linear_fwd_workspace(K, N)
+        wsp = _workspace(nws, x.device)
         _lib.check(lib.rdst_ln_linear_fwd(x_r.data_ptr(), ldx, _ptr(lw), _ptr(lb), int(in_act), _ptr(w), _ptr(b),
-                                          _ptr(r_r), ldr, y.data_ptr(), ldy, _ptr(stats), M, K, N, float(out_scale),
-                                          _dtype_code(x), _stream()), "rdst_ln_linear_fwd")
+                                          _ptr(r_r), ldr, y.data_ptr(), ldy, _ptr(stats), wsp.data_ptr(), nws, M, K, N,
+                                          float(out_scale), _dtype_code(x), _stream()), "rdst_ln_linear_fwd")
         ctx.save_for_backward(x_r, lw, lb, w, stats)
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.meta = (M, K, N, ldx, int(in_act), float(out_scale), bias is not None, residual is not None)
@@ -330,8 +332,11 @@ class _SwinBlock(torch.autograd.Function):
         st = _stream()
 
         def lin(xp, ld, lw, lb, act, w, b, rp, ldr, out, N, stats, K):
+            nws = lib.rdst_ln_linear_fwd_workspace(K, N)
+            wsp = _workspace(nws, dev)
             _lib.check(lib.rdst_ln_linear_fwd(xp, ld, _ptr(lw), _ptr(lb), act, w.data_ptr(), _ptr(b), rp, ldr,
-                                              out.data_ptr(), N, _ptr(stats), M, K, N, 1.0, code, st), "rdst_ln_linear_fwd")
+                                              out.data_ptr(), N, _ptr(stats), wsp.data_ptr(), nws, M, K, N, 1.0, code, st),
+                       "rdst_ln_linear_fwd")
 
         stats1 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n1w_ is not None else None
         qkv = torch.empty(lead + (3 * C,), dtype=dt, device=dev)
