@@ -183,3 +183,32 @@ def test_trainer_checkpoint_layout_and_resume_from_reference_style_checkpoint(tm
     tr.save_checkpoint(str(tmp_path / "ck2.tar"))
     back = torch.load(str(tmp_path / "ck2.tar"), weights_only=False)
     assert back["current_epoch"] == 3 and "scheduler_g" in back
+
+
+def test_metrics_psnr_ssim_definitions():
+    """rdst_amd.metrics restates skimage's PSNR / SSIM (metrics/sr_metrics.py:8-14); PSNR must equal the oracle's (which
+    the golden fixtures pin), SSIM is checked on closed-form cases (scikit-image is not installed: parity unpinned)."""
+    import numpy as np
+    from rdst_amd.metrics import SRMetrics, psnr, ssim
+    from oracle import rdst_oracle as O
+    rng = np.random.default_rng(0)
+    gt = rng.random((2, 1, 40, 32)).astype(np.float32)
+    pr = np.clip(gt + 0.05 * rng.standard_normal(gt.shape).astype(np.float32), 0, 1)
+    rep = SRMetrics("psnr ssim")(torch.from_numpy(gt), torch.from_numpy(pr), margin=4)
+    for i in range(2):
+        assert abs(rep["psnr"][i] - O.psnr(torch.from_numpy(gt[i:i + 1]), torch.from_numpy(pr[i:i + 1]), 4)) < 1e-9
+    assert ssim(gt[0, 0], gt[0, 0]) == pytest.approx(1.0, abs=1e-12)
+    # constant images a, b: every local variance is zero -> SSIM = (2ab + C1) / (a^2 + b^2 + C1)
+    a, b = 0.3, 0.5
+    want = (2 * a * b + 1e-4) / (a * a + b * b + 1e-4)
+    assert ssim(np.full((16, 16), a), np.full((16, 16), b)) == pytest.approx(want, rel=1e-12)
+    # y = x + c keeps the structure term at 1: SSIM = luminance term averaged over the windows
+    x = rng.random((24, 24))
+    s = ssim(x, x + 0.1)
+    assert 0.0 < s < 1.0 and ssim(x, x + 0.1) > ssim(x, x + 0.3)
+    assert psnr(np.zeros((8, 8)), np.full((8, 8), 0.1)) == pytest.approx(20.0, abs=1e-9)
+    # numpy (N, H, W, C) inputs and the mean mode, as the reference's docstring uses them
+    m = SRMetrics("psnr", "mean")(gt.transpose(0, 2, 3, 1), pr.transpose(0, 2, 3, 1), margin=0)
+    assert isinstance(m["psnr"], float)
+    with pytest.raises(ValueError):
+        SRMetrics("fid")

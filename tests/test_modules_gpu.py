@@ -253,3 +253,26 @@ def test_rdstb_dense_buffer_equals_cat(dtype, pre_norm):
     tol = 1e-6 if dtype == torch.float32 else 2e-2   # fp32: the same kernels on the same values; bf16: rounding of strided vs packed rows is identical too, the bound is slack
     for u, v in zip(a, b):
         assert (u - v).norm().item() <= tol * max(v.norm().item(), 1e-6)
+
+
+def test_tester_shell_whole_slices():
+    """SRTester (trans_sr_tester.py:124-166): eval + no_grad, split(batch_size * 4) chunks, PSNR / SSIM after the
+    ceil(s) border crop — against the reference fixture of the 40x32 whole-slice case."""
+    from rdst_amd.tester import SRTester
+    from rdst_amd.metrics import psnr
+    cfg, seed = NET_CASES["net_e1_eval_40x32"]
+    g = load_golden("net_e1_eval_40x32")
+    net = build_net(cfg)
+    net.load_state_dict(O.make_weights(cfg, seed), strict=True)
+    net.to(DEV)
+    x = torch.from_numpy(g["x"]).repeat(9, 1, 1, 1)          # 9 slices, batch_size 1 -> chunks of 4, 4, 1
+    t = SRTester(net, batch_size=1)
+    rec = t.inference(x)
+    assert rec.shape == (9, 1, 160, 128) and not net.training
+    assert np.abs(rec[0].cpu().numpy() - g["y"][0]).max() <= 1e-4
+    assert all(torch.equal(rec[i], rec[0]) for i in range(1, 9))
+    gt = torch.from_numpy(g["y"]).repeat(9, 1, 1, 1)
+    rep = t.evaluate(x, gt)
+    assert len(rep["psnr"]) == 9 and len(rep["ssim"]) == 9
+    want = psnr(g["y"][0, :, 4:-4, 4:-4], rec[0].cpu().numpy()[:, 4:-4, 4:-4])
+    assert rep["psnr"][0] == pytest.approx(want, rel=1e-9) and rep["ssim"][0] > 0.9999
