@@ -162,6 +162,29 @@ int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, cons
                   float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
                   int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
+/* ---- batched weight packing ------------------------------------------------------------------------------
+ * rdst_ln_linear_fwd and rdst_conv_fwd read their weights as bf16 fragment images that a small pack kernel writes into
+ * the op's `workspace` on every call.  rdst_pack_batch writes the images of MANY layers in a handful of launches (e.g.
+ * once at the start of a network's forward); an op is then called with workspace = that layer's image and
+ * workspace_bytes = RDST_PREPACKED and skips its own pack.  `out` needs rdst_ln_linear_fwd_workspace(K, N) /
+ * rdst_conv_fwd_workspace(Cin, Cout, 3) bytes, 16-byte aligned.  The weights must not change between the pack and the
+ * ops that use it.  Linear: W (N, K), gamma / beta (K) or NULL, bias (N) or NULL, s = out_scale.
+ * Conv forward: W (Cout = N, Cin = K, 3, 3), s = out_scale. */
+#define RDST_PREPACKED ((size_t)-1)
+#define RDST_PACK_LINEAR 0
+#define RDST_PACK_CONV3_FWD 1
+typedef struct rdst_pack_job {
+  int kind;
+  const float* W; const float* gamma; const float* beta; const float* bias;
+  void* out;
+  int N, K;
+  float s;
+} rdst_pack_job;
+int rdst_pack_batch(const rdst_pack_job* jobs, int njobs, void* stream);
+/* 1 if a call of that shape reads a packed image (so prepacking it is useful), else 0 */
+int rdst_ln_linear_fwd_packable(int K, int N, int has_ln, int has_residual, int in_act, int dtype);
+int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_r, int has_residual, int in_act, int dtype);
+
 /* ---- batched fixed-order reductions -------------------------------------------------------------------
  * Every backward entry point above that splits its contraction over workgroups ends with a deterministic sum of
  * per-workgroup partial slabs (and, behind a LayerNorm, a finish kernel).  Between _begin() and _end() those

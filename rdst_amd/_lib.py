@@ -38,6 +38,9 @@ SIGNATURES = {
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
     "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,
                            _f, _i, _i, _p]),
+    "rdst_pack_batch": (_i, [_p, _i, _p]),
+    "rdst_ln_linear_fwd_packable": (_i, [_i, _i, _i, _i, _i, _i]),
+    "rdst_conv_fwd_packable": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rdst_reduce_batch_begin": (_i, []),
     "rdst_reduce_batch_end": (_i, [_p]),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
@@ -47,6 +50,13 @@ SIGNATURES = {
     "rdst_stem_loss_bwd": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "rdst_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _p]),
 }
+
+PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
+
+
+class PackJob(C.Structure):   # rdst_pack_job
+    _fields_ = [("kind", _i), ("W", _p), ("gamma", _p), ("beta", _p), ("bias", _p), ("out", _p), ("N", _i), ("K", _i), ("s", _f)]
+
 
 _lib = None
 

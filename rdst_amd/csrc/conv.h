@@ -59,7 +59,7 @@ size_t conv_c1_slab_floats(int Cin);
 // wpack: conv3_pack_bytes(Cin, Cout) bytes of 16-byte aligned device scratch (NULL -> RDST_ENOTSUP).
 size_t conv3_pack_bytes(int Cin, int Cout);
 int conv3_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr,
-                   bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st);
+                   bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, bool prepacked, hipStream_t st);
 int conv3_dgrad_bf16(const float* Wc, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc,
                      int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st);
 size_t conv3_wgrad_slab_bytes(int Cin, int Cout);

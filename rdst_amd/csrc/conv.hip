@@ -129,10 +129,10 @@ int wgrad_splits(const ConvGeom& g) {
 
 template <typename T>
 int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr, T* Y,
-          int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st) {
+          int64_t ldy, const ConvGeom& g, float s, void* wpack, bool prepacked, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (int rc = conv_c1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
-    if (int rc = conv3_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, st); rc != RDST_ENOTSUP) return rc;
+    if (int rc = conv3_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, prepacked, st); rc != RDST_ENOTSUP) return rc;
   }
   if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
   ConvA<T> la{X, ldx, g, in_act};
@@ -241,6 +241,12 @@ __global__ void __launch_bounds__(256) rows_to_nchw_kernel(const T* __restrict__
 
 }  // namespace
 
+extern "C" int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_r, int has_residual, int in_act, int dtype) {
+  if (dtype != RDST_BF16 || ksize != 3 || in_act) return 0;
+  return (Cin == 150 && Cout == 60 && shuffle_r == 1) || (Cin == 60 && Cout == 60 && shuffle_r == 1) ||
+         (Cin == 60 && Cout == 240 && shuffle_r == 2 && !has_residual);
+}
+
 extern "C" size_t rdst_conv_fwd_workspace(int Cin, int Cout, int ksize) {
   if (Cin <= 0 || Cout <= 0 || ksize != 3) return 16;
   return conv3_pack_bytes(Cin, Cout);
@@ -258,8 +264,9 @@ extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const floa
   hipStream_t st = (hipStream_t)stream;
   void* wpack = (workspace && workspace_bytes >= rdst_conv_fwd_workspace(Cin, Cout, ksize)) ? workspace : nullptr;
   if (dtype == RDST_F32)
-    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, wpack, st);
-  return fwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, g, out_scale, wpack, st);
+    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, wpack, false, st);
+  return fwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, g, out_scale, wpack,
+                     workspace_bytes == RDST_PREPACKED, st);
 }
 
 extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {

@@ -29,48 +29,15 @@
 // Everything else (fp32, other channel counts, W % 32 != 0, input activation) stays on conv_mfma.hip.
 #include "conv.h"
 #include "mfma.h"
+#include "pack.h"
 #include <type_traits>
 
 namespace {
 
-constexpr int PK_FWD = 0, PK_DGRAD = 1, PK_DGRAD_UNSHUF = 2;
 
-// packed weights: fragment (ct, tap, ks) = 64 lanes x 8 bf16; lane (r, h): output channel n = 32 ct + r,
-// contraction k = 16 ks + 8 h + e.
-//   PK_FWD          : Wc[n][k][tap]
-//   PK_DGRAD        : Wc[k][n][8 - tap]                       (contraction over co, mirrored tap)
-//   PK_DGRAD_UNSHUF : Wc[4 c' + q][n][8 - tap], k = 60 q + c' (conv channel 4c'+q is sub-pixel q of channel c')
 __global__ void __launch_bounds__(256) conv3_pack_kernel(const float* __restrict__ Wc, bf16* __restrict__ out, int Cin,
                                                          int Cout, int K, int N, int ksteps, int ctiles, int mode, float s) {
-  const int i = blockIdx.x * 256 + threadIdx.x;          // one thread per 8 packed elements (16 B)
-  const int total = ctiles * 9 * ksteps * 64;
-  if (i >= total) return;
-  const int lane = i & 63, f = i >> 6;
-  const int ks = f % ksteps, tap = (f / ksteps) % 9, ct = f / (ksteps * 9);
-  const int n = ct * 32 + (lane & 31);
-  uint32_t w[4];
-#pragma unroll
-  for (int e2 = 0; e2 < 4; ++e2) {
-    float v[2];
-#pragma unroll
-    for (int e1 = 0; e1 < 2; ++e1) {
-      const int k = ks * 16 + (lane >> 5) * 8 + 2 * e2 + e1;
-      float x = 0.f;
-      if (n < N && k < K) {
-        if (mode == PK_FWD) x = Wc[((int64_t)n * Cin + k) * 9 + tap];
-        else if (mode == PK_DGRAD) x = Wc[((int64_t)k * Cin + n) * 9 + (8 - tap)];
-        else {
-          const int cq = Cout / 4, q = k / cq, c = k - q * cq;
-          x = Wc[((int64_t)(4 * c + q) * Cin + n) * 9 + (8 - tap)];
-        }
-      }
-      v[e1] = x * s;   // out_scale rides on the weights: (conv(W) + bias) s = conv(s W) + s bias
-    }
-    w[e2] = pack_bf16x2(v[0], v[1]);
-  }
-  u32x4_a4 o;
-  o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-  *reinterpret_cast<u32x4_a4*>(out + (int64_t)i * 8) = o;
+  conv3_pack_block((int)blockIdx.x, Wc, out, Cin, Cout, K, N, ksteps, ctiles, mode, s);
 }
 
 struct C3Args {
@@ -499,7 +466,7 @@ size_t conv3_pack_bytes(int Cin, int Cout) {
 
 // Forward.  RDST_ENOTSUP = not one of the covered shapes (the caller falls back to conv_mfma.hip).
 int conv3_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr,
-                   bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, hipStream_t st) {
+                   bf16* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, bool prepacked, hipStream_t st) {
   if (!wpack || g.ks != 3 || g.pad != 1 || in_act || g.W % 32 || ((uintptr_t)wpack & 15)) return RDST_ENOTSUP;
   const bool ps = g.r == 2;
   if (!(g.r == 1 || (ps && !R))) return RDST_ENOTSUP;
@@ -511,7 +478,8 @@ int conv3_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, cons
   else if (g.Cin == 60 && g.Cout == 240 && ps) shape = 3;
   if (!shape) return RDST_ENOTSUP;
   bf16* wp = reinterpret_cast<bf16*>(wpack);
-  if (int rc = pack(Wc, wp, g.Cin, g.Cout, g.Cin, g.Cout, PK_FWD, s, st)) return rc;
+  if (!prepacked)
+    if (int rc = pack(Wc, wp, g.Cin, g.Cout, g.Cin, g.Cout, PK_FWD, s, st)) return rc;
   const int64_t abytes = ((g.pixels() - 1) * ldx + g.Cin) * 2;
   const int64_t opix = g.pixels() * g.r * g.r;
   if (abytes >= (1ll << 31) || opix * ldy * 2 >= (1ll << 31) || (R && opix * ldr * 2 >= (1ll << 31))) return RDST_ENOTSUP;

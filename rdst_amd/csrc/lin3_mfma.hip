@@ -18,6 +18,7 @@
 // Linear into the dense buffer).  Everything else stays on linear_mfma.hip.
 #include "linear.h"
 #include "mfma.h"
+#include "pack.h"
 
 namespace {
 
@@ -30,54 +31,11 @@ constexpr int l3_stride(int K) {  // bytes: covers every k-step (no read leaves 
   return s;
 }
 
-// fragment (nt, ks) = 64 lanes x 8 bf16: lane (r, h): output n = 32 nt + r, input k = 16 ks + 8 h + e: W[n][k] gamma[k] s.
-// sb[0][n] = S[n] = sum_k of the rounded values, sb[1][n] = b'[n] = (bias[n] + sum_k W[n][k] beta[k]) s.
 __global__ void __launch_bounds__(256) lin3_pack_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ bias,
                                                         bf16* __restrict__ wp, float* __restrict__ sb, int N, int K, int ksteps,
                                                         int ntiles, float s) {
-  const int nfr = ntiles * ksteps * 64, nb1 = (nfr + 255) / 256;
-  if ((int)blockIdx.x < nb1) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nfr) return;
-    const int lane = i & 63, f = i >> 6;
-    const int ks = f % ksteps, nt = f / ksteps;
-    const int n = nt * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
-    uint32_t w[4];
-#pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) {
-      float v[2];
-#pragma unroll
-      for (int e1 = 0; e1 < 2; ++e1) {
-        const int k = k0 + 2 * e2 + e1;
-        v[e1] = (n < N && k < K) ? W[(int64_t)n * K + k] * (gamma ? gamma[k] : 1.f) * s : 0.f;
-      }
-      w[e2] = pack_bf16x2(v[0], v[1]);
-    }
-    u32x4_a4 o;
-    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-    *reinterpret_cast<u32x4_a4*>(wp + (int64_t)i * 8) = o;
-    return;
-  }
-  // S / b': one wave per output row (coalesced row reads, fixed shuffle tree)
-  const int n = ((int)blockIdx.x - nb1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int NP = ntiles * 32;
-  if (n >= NP) return;
-  float S = 0.f, bb = 0.f;
-  if (n < N) {
-    for (int k = lane; k < K; k += 64) {
-      const float w = W[(int64_t)n * K + k];
-      S += __bfloat162float(__float2bfloat16(w * (gamma ? gamma[k] : 1.f) * s));
-      if (beta) bb = fmaf(w, beta[k], bb);
-    }
-    S = wave_sum(S);
-    bb = wave_sum(bb);
-    bb = (bb + (bias ? bias[n] : 0.f)) * s;
-  }
-  if (lane == 0) {
-    sb[n] = S;
-    sb[NP + n] = bb;
-  }
+  lin3_pack_block((int)blockIdx.x, W, gamma, beta, bias, wp, sb, N, K, ksteps, ntiles, s);
 }
 
 struct L3Args {
@@ -333,7 +291,7 @@ size_t lin3_pack_bytes(int K, int N) {
 // RDST_ENOTSUP = not one of the covered shapes (the caller falls back to linear_mfma.hip)
 int lin3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt, const float* bias,
                   const bf16* R, int64_t ldr, bf16* Y, int64_t ldy, float* stats, int64_t M, int K, int N, float s, void* wpack,
-                  hipStream_t st) {
+                  bool prepacked, hipStream_t st) {
   if (!wpack || ((uintptr_t)wpack & 15) || in_act || !Wt || M <= 0) return RDST_ENOTSUP;
   const bool ln = ln_w != nullptr;
   if (!(K == 60 || K == 90 || K == 120)) return RDST_ENOTSUP;
@@ -348,7 +306,7 @@ int lin3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln
   const int nt = (N + 31) / 32, ks = (K + 15) / 16;
   bf16* wp = reinterpret_cast<bf16*>(wpack);
   float* sb = reinterpret_cast<float*>(reinterpret_cast<char*>(wpack) + (size_t)nt * ks * 1024);
-  {
+  if (!prepacked) {
     const int nfr = nt * ks * 64, nb1 = (nfr + 255) / 256, nb2 = (nt * 32 + 3) / 4;
     hipLaunchKernelGGL(lin3_pack_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, st, Wt, ln_w, ln_b, bias, wp, sb, N, K, ks, nt, s);
     if (int rc = rdst_launch_status("lin3_pack")) return rc;

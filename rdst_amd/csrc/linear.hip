@@ -410,6 +410,11 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
 
 }  // namespace
 
+extern "C" int rdst_ln_linear_fwd_packable(int K, int N, int has_ln, int has_residual, int in_act, int dtype) {
+  if (dtype != RDST_BF16 || in_act || !(K == 60 || K == 90 || K == 120)) return 0;
+  return (has_ln && !has_residual && (N == 3 * K || N == 30)) || (!has_ln && has_residual && N == K);
+}
+
 extern "C" size_t rdst_ln_linear_fwd_workspace(int K, int N) {
   if (K <= 0 || N <= 0) return 16;
   return lin3_pack_bytes(K, N);
@@ -431,8 +436,8 @@ extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w
   hipStream_t st = (hipStream_t)stream;
   if (dtype == RDST_BF16 && workspace && workspace_bytes >= rdst_ln_linear_fwd_workspace(K, N)) {
     const int rc = lin3_fwd_bf16((const bf16*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, stats, M,
-                                 K, N, out_scale, workspace, st);
-    if (rc != RDST_ENOTSUP) return rc;
+                                 K, N, out_scale, workspace, workspace_bytes == RDST_PREPACKED, st);
+    if (rc != RDST_ENOTSUP) return rc;   // (a prepacked image the call cannot use is simply ignored)
   }
   if (dtype == RDST_F32)
     return fwd_t<float>((const float*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const float*)R, ld_r, (float*)Y, ld_y, stats, M, K, N, out_scale, st);

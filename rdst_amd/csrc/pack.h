@@ -1,0 +1,106 @@
+// Weight packing for the register-stationary kernels (lin3_mfma.hip, conv3_mfma.hip): the device bodies, shared by the
+// per-call pack kernels and by the batched one (pack_batch.hip: every layer of a network in a handful of launches).
+#pragma once
+#include "common.h"
+#include "mfma.h"
+
+constexpr int PK_FWD = 0, PK_DGRAD = 1, PK_DGRAD_UNSHUF = 2;
+
+// fragment (nt, ks) = 64 lanes x 8 bf16: lane (r, h): output n = 32 nt + r, input k = 16 ks + 8 h + e: W[n][k] gamma[k] s.
+// sb[0][n] = S[n] = sum_k of the rounded values, sb[1][n] = b'[n] = (bias[n] + sum_k W[n][k] beta[k]) s.
+__device__ __forceinline__ void lin3_pack_block(int bid, const float* __restrict__ W, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ bias,
+                                                        bf16* __restrict__ wp, float* __restrict__ sb, int N, int K, int ksteps,
+                                                        int ntiles, float s) {
+  const int nfr = ntiles * ksteps * 64, nb1 = (nfr + 255) / 256;
+  if (bid < nb1) {
+    const int i = bid * 256 + threadIdx.x;
+    if (i >= nfr) return;
+    const int lane = i & 63, f = i >> 6;
+    const int ks = f % ksteps, nt = f / ksteps;
+    const int n = nt * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+    uint32_t w[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int e1 = 0; e1 < 2; ++e1) {
+        const int k = k0 + 2 * e2 + e1;
+        v[e1] = (n < N && k < K) ? W[(int64_t)n * K + k] * (gamma ? gamma[k] : 1.f) * s : 0.f;
+      }
+      w[e2] = pack_bf16x2(v[0], v[1]);
+    }
+    u32x4_a4 o;
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    *reinterpret_cast<u32x4_a4*>(wp + (int64_t)i * 8) = o;
+    return;
+  }
+  // S / b': one wave per output row (coalesced row reads, fixed shuffle tree)
+  const int n = (bid - nb1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int NP = ntiles * 32;
+  if (n >= NP) return;
+  float S = 0.f, bb = 0.f;
+  if (n < N) {
+    for (int k = lane; k < K; k += 64) {
+      const float w = W[(int64_t)n * K + k];
+      S += __bfloat162float(__float2bfloat16(w * (gamma ? gamma[k] : 1.f) * s));
+      if (beta) bb = fmaf(w, beta[k], bb);
+    }
+    S = wave_sum(S);
+    bb = wave_sum(bb);
+    bb = (bb + (bias ? bias[n] : 0.f)) * s;
+  }
+  if (lane == 0) {
+    sb[n] = S;
+    sb[NP + n] = bb;
+  }
+}
+
+
+// packed weights: fragment (ct, tap, ks) = 64 lanes x 8 bf16; lane (r, h): output channel n = 32 ct + r,
+// contraction k = 16 ks + 8 h + e.
+//   PK_FWD          : Wc[n][k][tap]
+//   PK_DGRAD        : Wc[k][n][8 - tap]                       (contraction over co, mirrored tap)
+//   PK_DGRAD_UNSHUF : Wc[4 c' + q][n][8 - tap], k = 60 q + c' (conv channel 4c'+q is sub-pixel q of channel c')
+__device__ __forceinline__ void conv3_pack_block(int bid, const float* __restrict__ Wc, bf16* __restrict__ out, int Cin,
+                                                         int Cout, int K, int N, int ksteps, int ctiles, int mode, float s) {
+  const int i = bid * 256 + threadIdx.x;          // one thread per 8 packed elements (16 B)
+  const int total = ctiles * 9 * ksteps * 64;
+  if (i >= total) return;
+  const int lane = i & 63, f = i >> 6;
+  const int ks = f % ksteps, tap = (f / ksteps) % 9, ct = f / (ksteps * 9);
+  const int n = ct * 32 + (lane & 31);
+  uint32_t w[4];
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2) {
+    float v[2];
+#pragma unroll
+    for (int e1 = 0; e1 < 2; ++e1) {
+      const int k = ks * 16 + (lane >> 5) * 8 + 2 * e2 + e1;
+      float x = 0.f;
+      if (n < N && k < K) {
+        if (mode == PK_FWD) x = Wc[((int64_t)n * Cin + k) * 9 + tap];
+        else if (mode == PK_DGRAD) x = Wc[((int64_t)k * Cin + n) * 9 + (8 - tap)];
+        else {
+          const int cq = Cout / 4, q = k / cq, c = k - q * cq;
+          x = Wc[((int64_t)(4 * c + q) * Cin + n) * 9 + (8 - tap)];
+        }
+      }
+      v[e1] = x * s;   // out_scale rides on the weights: (conv(W) + bias) s = conv(s W) + s bias
+    }
+    w[e2] = pack_bf16x2(v[0], v[1]);
+  }
+  u32x4_a4 o;
+  o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+  *reinterpret_cast<u32x4_a4*>(out + (int64_t)i * 8) = o;
+}
+
+
+static inline int lin3_pack_blocks(int K, int N) {
+  const int nt = (N + 31) / 32, ks = (K + 15) / 16;
+  return (nt * ks * 64 + 255) / 256 + (nt * 32 + 3) / 4;
+}
+static inline int conv3_pack_blocks(int K, int N) {
+  const int ks = (K + 15) / 16, ct = (N + 31) / 32;
+  return (ct * 9 * ks * 64 + 255) / 256;
+}

@@ -345,6 +345,10 @@ class RDSTSR(nn.Module):
         return ops.rows_to_nchw(_norm_only(t, self.norm).view(B, H, W, E))
 
     def forward(self, x, sr_scale=None):
+        with ops.pack_scope(self):    # the packed weight images of all layers: one batched pack per forward
+            return self._forward(x, sr_scale)
+
+    def _forward(self, x, sr_scale=None):
         rows = ops.nchw_to_rows(x, self.compute_dtype)          # (B,H,W,nc)
         rows = self.sub_mean.forward_rows(rows)
         feat = self.head.forward_rows(rows)                      # (B,H,W,E)

@@ -94,6 +94,115 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# ------------------------------------------------------------------------------------------------
+# Prepacked weights: one rdst_pack_batch per network forward instead of a pack kernel in front of every op
+# ------------------------------------------------------------------------------------------------
+class PackPlan:
+    """The bf16 fragment images of all the weights a network's forward reads (rdst_pack_batch, include/rdst_hip.h).
+    Discovered on one forward (every op reports the pack it just did for itself), then refreshed as a whole at the start
+    of each later forward; an op that finds its weights in the plan passes the image with workspace_bytes = PREPACKED.
+    A plan is only used while every recorded tensor still lives at its recorded address."""
+
+    def __init__(self):
+        self.keys, self.specs, self.tensors = {}, [], []
+        self.arena = None
+        self.jobs = None
+        self.misses = 0
+
+    @staticmethod
+    def _key(kind, w, lw, lb, b, N, K, s):
+        return (kind, w.data_ptr(), _ptr(lw) or 0, _ptr(lb) or 0, _ptr(b) or 0, N, K, float(s))
+
+    def record(self, kind, w, lw, lb, b, N, K, s, nbytes):
+        k = self._key(kind, w, lw, lb, b, N, K, s)
+        if k not in self.keys:
+            self.keys[k] = len(self.specs)
+            self.specs.append((kind, N, K, float(s), (int(nbytes) + 255) // 256 * 256))
+            self.tensors.append((w, lw, lb, b))
+
+    def finalize(self, device):
+        if not self.specs:
+            return False
+        total = sum(sp[4] for sp in self.specs)
+        self.arena = torch.empty(total, dtype=torch.uint8, device=device)
+        self.jobs = (_lib.PackJob * len(self.specs))()
+        self.offsets, off = [], 0
+        for i, ((kind, N, K, s, nb), (w, lw, lb, b)) in enumerate(zip(self.specs, self.tensors)):
+            j = self.jobs[i]
+            j.kind, j.W, j.gamma, j.beta, j.bias = kind, w.data_ptr(), _ptr(lw), _ptr(lb), _ptr(b)
+            j.out, j.N, j.K, j.s = self.arena.data_ptr() + off, N, K, s
+            self.offsets.append(off)
+            off += nb
+        self.ptrs = [tuple(_ptr(t) or 0 for t in ts) for ts in self.tensors]
+        return True
+
+    def valid(self):
+        return all(tuple(_ptr(t) or 0 for t in ts) == p for ts, p in zip(self.tensors, self.ptrs))
+
+    def run(self):
+        import ctypes
+        _lib.check(_lib.load().rdst_pack_batch(ctypes.cast(self.jobs, ctypes.c_void_p), len(self.specs), _stream()),
+                   "rdst_pack_batch")
+
+    def lookup(self, kind, w, lw, lb, b, N, K, s):
+        i = self.keys.get(self._key(kind, w, lw, lb, b, N, K, s))
+        if i is None:
+            self.misses += 1
+            return None
+        return self.arena.data_ptr() + self.offsets[i]
+
+
+_plan_active: Optional[PackPlan] = None
+_plan_recording: Optional[PackPlan] = None
+PACK_LINEAR, PACK_CONV3_FWD = 0, 1
+
+
+class pack_scope:
+    """``with ops.pack_scope(module):`` around a network forward (RDSTSR.forward does it)."""
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        global _plan_active, _plan_recording
+        self.outer = (_plan_active, _plan_recording)
+        if self.outer != (None, None):     # nested network forwards share the outer scope
+            return self
+        plan = getattr(self.owner, "_rdst_pack_plan", None)
+        if plan is not None and plan.valid():
+            plan.misses = 0
+            plan.run()
+            _plan_active = plan
+        else:
+            _plan_recording = PackPlan()
+        return self
+
+    def __exit__(self, *exc):
+        global _plan_active, _plan_recording
+        if self.outer != (None, None):
+            return False
+        rec, act = _plan_recording, _plan_active
+        _plan_active = _plan_recording = None
+        if rec is not None and exc[0] is None:
+            dev = next(self.owner.parameters()).device
+            self.owner._rdst_pack_plan = rec if rec.finalize(dev) else None
+        if act is not None and act.misses:
+            self.owner._rdst_pack_plan = None    # the forward took another path than the recorded one: rediscover
+        return False
+
+
+def _packed_workspace(kind, w, lw, lb, b, N, K, s, nbytes, device):
+    """(workspace pointer holder, pointer, workspace_bytes) for an op that reads a packed image of (w, lw, lb, b)."""
+    if _plan_active is not None:
+        p = _plan_active.lookup(kind, w, lw, lb, b, N, K, s)
+        if p is not None:
+            return None, p, _lib.PREPACKED
+    if _plan_recording is not None:
+        _plan_recording.record(kind, w, lw, lb, b, N, K, s, nbytes)
+    wsp = _workspace(nbytes, device)
+    return wsp, wsp.data_ptr(), int(nbytes)
+
+
 # The weight-gradient branch and the data-gradient branch of a Linear / conv backward are independent
 # and each under-fills the chip, so they run concurrently: wgrad on a side HIP stream, dgrad on the
 # current one, joined before the op returns (fork/join is capturable into a HIP graph).
@@ -218,11 +327,15 @@ class _LnLinear(torch.autograd.Function):
                 raise TypeError("rdst_amd.ln_linear: residual dtype differs from the activation dtype")
             r_r, ldr = _rows(residual)
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if lw is not None else None
-        nws = lib.rdst_ln_linear_fwd_workspace(K, N)
-        wsp = _workspace(nws, x.device)
+        code = _dtype_code(x)
+        if w is not None and lib.rdst_ln_linear_fwd_packable(K, N, int(lw is not None), int(r_r is not None), int(in_act), code):
+            _wsp, wptr, nws = _packed_workspace(PACK_LINEAR, w, lw, lb, b, N, K, out_scale,
+                                                lib.rdst_ln_linear_fwd_workspace(K, N), x.device)
+        else:
+            _wsp, wptr, nws = None, None, 0
         _lib.check(lib.rdst_ln_linear_fwd(x_r.data_ptr(), ldx, _ptr(lw), _ptr(lb), int(in_act), _ptr(w), _ptr(b),
-                                          _ptr(r_r), ldr, y.data_ptr(), ldy, _ptr(stats), wsp.data_ptr(), nws, M, K, N,
-                                          float(out_scale), _dtype_code(x), _stream()), "rdst_ln_linear_fwd")
+                                          _ptr(r_r), ldr, y.data_ptr(), ldy, _ptr(stats), wptr, nws, M, K, N,
+                                          float(out_scale), code, _stream()), "rdst_ln_linear_fwd")
         ctx.save_for_backward(x_r, lw, lb, w, stats)
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.meta = (M, K, N, ldx, int(in_act), float(out_scale), bias is not None, residual is not None)
@@ -332,10 +445,12 @@ class _SwinBlock(torch.autograd.Function):
         st = _stream()
 
         def lin(xp, ld, lw, lb, act, w, b, rp, ldr, out, N, stats, K):
-            nws = lib.rdst_ln_linear_fwd_workspace(K, N)
-            wsp = _workspace(nws, dev)
+            if lib.rdst_ln_linear_fwd_packable(K, N, int(lw is not None), int(rp is not None), act, code):
+                _wsp, wptr, nws = _packed_workspace(PACK_LINEAR, w, lw, lb, b, N, K, 1.0, lib.rdst_ln_linear_fwd_workspace(K, N), dev)
+            else:
+                _wsp, wptr, nws = None, None, 0
             _lib.check(lib.rdst_ln_linear_fwd(xp, ld, _ptr(lw), _ptr(lb), act, w.data_ptr(), _ptr(b), rp, ldr,
-                                              out.data_ptr(), N, _ptr(stats), wsp.data_ptr(), nws, M, K, N, 1.0, code, st),
+                                              out.data_ptr(), N, _ptr(stats), wptr, nws, M, K, N, 1.0, code, st),
                        "rdst_ln_linear_fwd")
 
         stats1 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n1w_ is not None else None
@@ -494,11 +609,15 @@ class _ConvRows(torch.autograd.Function):
             if residual.dtype != x.dtype or tuple(residual.shape) != tuple(y.shape):
                 raise ValueError("rdst_amd.conv_rows: residual must match the output shape/dtype")
             r_r, ldr = _rows(residual)
-        nws = lib.rdst_conv_fwd_workspace(Cin, Cout, k)
-        wsp = _workspace(nws, x.device)
+        code = _dtype_code(x)
+        if lib.rdst_conv_fwd_packable(Cin, Cout, k, r, int(r_r is not None), int(in_act), code):
+            _wsp, wptr, nws = _packed_workspace(PACK_CONV3_FWD, w, None, None, None, Cout, Cin, out_scale,
+                                                lib.rdst_conv_fwd_workspace(Cin, Cout, k), x.device)
+        else:
+            _wsp, wptr, nws = None, None, 0
         _lib.check(lib.rdst_conv_fwd(x_r.data_ptr(), ldx, int(in_act), w.data_ptr(), _ptr(b), _ptr(r_r), ldr,
-                                     y.data_ptr(), cy, wsp.data_ptr(), nws, B, H, W, Cin, Cout, k, float(out_scale), r,
-                                     _dtype_code(x), _stream()), "rdst_conv_fwd")
+                                     y.data_ptr(), cy, wptr, nws, B, H, W, Cin, Cout, k, float(out_scale), r,
+                                     code, _stream()), "rdst_conv_fwd")
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.save_for_backward(x_r, w)
         ctx.meta = (B, H, W, Cin, Cout, k, ldx, int(in_act), float(out_scale), r, bias is not None,
