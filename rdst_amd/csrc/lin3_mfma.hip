@@ -41,157 +41,200 @@ __global__ void __launch_bounds__(256) lin3_pack_kernel(const float* __restrict_
 struct L3Args {
   const bf16* X; int64_t ldx; int x_bytes;
   const bf16* Wp; const float* sb;
-  const bf16* R; int64_t ldr;
+  const bf16* R; int64_t ldr; int r_bytes;
   bf16* Y; int64_t ldy;
   float* stats;
   int M, N, ntiles;
 };
+
+constexpr int l3_nw(int NT) { return (NT >= 4 && NT <= 12) ? NT : 8; }
 
 template <int K, int NT, bool LN, bool RES>
 struct L3Cfg {
   static constexpr int KSTEPS = (K + 15) / 16;
   static constexpr int XS = l3_stride(K), XSLOTS = XS / 16, XD = (2 * K + 15) / 16;
   static constexpr int TP = (L3_TT * XSLOTS + 63) / 64, TILEB = TP * 1024;
-  static constexpr int NBUF = 4;
-  static constexpr int ITEMS = NT * 4, NJ = (ITEMS + 7) / 8;
-  static constexpr int PERIOD = NT / l3_gcd(8, NT), ND = NJ < PERIOD ? NJ : PERIOD;
-  static constexpr int STAT_OFF = NBUF * TILEB;                       // [NBUF][128][2] floats
+  // residual tile (RES): [128 tokens][NT * 32 channels] bf16, 8 slots per 32 channels, + 1 slot: odd slot count
+  static constexpr int RS = RES ? NT * 64 + 16 : 0, RSLOTS = RS / 16, RP = RES ? (L3_TT * RSLOTS + 63) / 64 : 0, RTILEB = RP * 1024;
+  // tiles in flight per workgroup; up to 8 waves, two workgroups share a CU (more waves to hide the epilogues)
+  static constexpr int WGCU = l3_nw(NT) > 8 ? 1 : 2;
+  static constexpr int NBUF = RES ? 1 : (WGCU == 1 ? 4 : 2);
+  // waves: one output tile per wave where there are 4..12 of them (4 items = the 4 token sub-tiles, one fragment set),
+  // else 8 waves dealing the NT * 4 items round-robin
+  static constexpr int NW = l3_nw(NT);
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int ITEMS = NT * 4, NJ = (ITEMS + NW - 1) / NW;
+  static constexpr int PERIOD = NT / l3_gcd(NW, NT), ND = NJ < PERIOD ? NJ : PERIOD;
+  static constexpr int CNT = (TP + NW - 1) / NW + (RES ? (RP + NW - 1) / NW : 0);   // DMA pieces per wave and tile
+  static constexpr int R_OFF = NBUF * TILEB;
+  static constexpr int STAT_OFF = R_OFF + NBUF * RTILEB;              // [NBUF][128][2] floats
   static constexpr int SB_OFF = STAT_OFF + NBUF * L3_TT * 2 * 4;      // [2][NT*32] floats
-  static constexpr int SMEM = SB_OFF + 2 * NT * 32 * 4;
+  static constexpr int SMEM = SB_OFF + (2 * NT * 32 * 4 + 1023) / 1024 * 1024;
   static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert(CNT * (NBUF - 1) < 64, "vmcnt is a 6-bit counter");
+  static_assert(TP >= NW && (!RES || RP >= NW), "every wave owns at least one piece of a tile");
 };
 
 template <int K, int NT, bool LN, bool RES>
-__global__ void __launch_bounds__(512, 2) lin3_kernel(const L3Args p) {
+__global__ void __launch_bounds__(64 * l3_nw(NT), l3_nw(NT) > 8 ? 1 : (2 * l3_nw(NT) + 3) / 4) lin3_kernel(const L3Args p) {
   using CF = L3Cfg<K, NT, LN, RES>;
-  constexpr int KSTEPS = CF::KSTEPS, XS = CF::XS, NBUF = CF::NBUF, ND = CF::ND, NJ = CF::NJ;
+  constexpr int KSTEPS = CF::KSTEPS, XS = CF::XS, NBUF = CF::NBUF, ND = CF::ND, NJ = CF::NJ, NW = CF::NW, NTHR = CF::NTHR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* statL = reinterpret_cast<float*>(smem + CF::STAT_OFF);
-  float* sbL = reinterpret_cast<float*>(smem + CF::SB_OFF);
+  const float* sbL = reinterpret_cast<const float*>(smem + CF::SB_OFF);
 
   typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
-  u32x4s_t rsrc;
-  rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p.X);
-  rsrc.y = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p.X >> 32) & 0xffffu);
-  rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)p.x_bytes);
-  rsrc.w = 0x00020000u;
+  auto make_rsrc = [&](const void* ptr, uint32_t bytes) {
+    u32x4s_t q;
+    q.x = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ptr);
+    q.y = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)ptr >> 32) & 0xffffu);
+    q.z = __builtin_amdgcn_readfirstlane(bytes);
+    q.w = 0x00020000u;
+    return q;
+  };
+  const u32x4s_t rsx = make_rsrc(p.X, (uint32_t)p.x_bytes), rsr = make_rsrc(RES ? (const void*)p.R : (const void*)p.X, (uint32_t)p.r_bytes),
+                 rsb = make_rsrc(p.sb, 2 * NT * 32 * 4);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  auto dma = [&](uint32_t ldst, int off) {   // inline asm: see conv3_mfma.hip
+  auto dma = [&](const u32x4s_t& rs, uint32_t ldst, int off) {   // inline asm: see conv3_mfma.hip
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rsrc) : "memory");
+                 : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
   };
   const int grid = gridDim.x;
-  // ---- the whole first round of tiles goes in flight before anything else ---------------------------------------
+  // ---- this wave's weight fragments: item j of the wave is (nt, tt) = ((wave + NW j) % NT, (wave + NW j) / NT) ------
+  // Loaded BEFORE the tiles go in flight (memory operations retire in issue order, so every later wait for a tile also
+  // covers them) and by inline asm: the compiler must not know about any load here, or it drains the whole queue
+  // (vmcnt(0)) at the first use.  The same goes for spill reloads: the kernel must not spill.
+  typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
+  u32x4v_t wfr[ND][KSTEPS];
+#pragma unroll
+  for (int jd = 0; jd < ND; ++jd) {
+    const int nt = (wave + NW * jd) % NT;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const char* src = reinterpret_cast<const char*>(p.Wp) + (((int64_t)nt * KSTEPS + ks) * 64 + lane) * 16;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wfr[jd][ks]) : "v"(src) : "memory");
+    }
+  }
+  {  // S / b' (2 x NT x 32 floats) by LDS-DMA as well: piece wave % NSBP (duplicates write the same bytes)
+    constexpr int NSBP = (2 * NT * 32 * 4 + 1023) / 1024;
+    const int pc = wave % NSBP;
+    dma(rsb, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(CF::SB_OFF + pc * 1024)), pc * 1024 + lane * 16);
+  }
+  // ---- a round = NBUF tiles, all in flight at once.  Every wave issues exactly CNT pieces per tile (a wave whose
+  // share is one short repeats its last piece; tiles past the end are all-zero pieces), so "tile b has landed" is
+  // the COUNTED wait vmcnt(CNT * (NBUF - 1 - b)): the younger tiles stay in flight while tile b is multiplied and
+  // stored (reads and writes of a launch overlap instead of forming two bursts).
+  constexpr int CNT = CF::CNT;
   auto issue_round = [&](int tile0) {
 #pragma unroll
     for (int b = 0; b < NBUF; ++b) {
       const int tile = tile0 + b * grid;
-      if (tile < p.ntiles) {
-        for (int q = wave; q < CF::TP; q += 8) {
+#pragma unroll
+      for (int i = 0; i < (CF::TP + NW - 1) / NW; ++i) {
+        int q = wave + NW * i;
+        q = q < CF::TP ? q : q - NW;
+        const int sidx = q * 64 + lane;
+        const int tok = sidx / CF::XSLOTS, sl = sidx - tok * CF::XSLOTS;
+        const int grow = tile * L3_TT + tok;
+        const bool ok = tile < p.ntiles && tok < L3_TT && sl < CF::XD && grow < p.M;
+        dma(rsx, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(b * CF::TILEB + q * 1024)),
+            ok ? grow * ((int)p.ldx * 2) + sl * 16 : p.x_bytes);   // (extents < 2^31 bytes)
+      }
+      if constexpr (RES) {   // the residual rows of the tile: 16-B chunks of the N output channels
+#pragma unroll
+        for (int i = 0; i < (CF::RP + NW - 1) / NW; ++i) {
+          int q = wave + NW * i;
+          q = q < CF::RP ? q : q - NW;
           const int sidx = q * 64 + lane;
-          const int tok = sidx / CF::XSLOTS, sl = sidx - tok * CF::XSLOTS;
+          const int tok = sidx / CF::RSLOTS, sl = sidx - tok * CF::RSLOTS;
           const int grow = tile * L3_TT + tok;
-          const bool ok = tok < L3_TT && sl < CF::XD && grow < p.M;
-          const int off = ok ? grow * ((int)p.ldx * 2) + sl * 16 : p.x_bytes;   // (extent < 2^31 bytes)
-          dma(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(b * CF::TILEB + q * 1024)), off);
+          const bool ok = tile < p.ntiles && tok < L3_TT && sl * 8 < p.N && grow < p.M;
+          dma(rsr, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(CF::R_OFF + b * CF::RTILEB + q * 1024)),
+              ok ? grow * ((int)p.ldr * 2) + sl * 16 : p.r_bytes);
         }
       }
     }
   };
-  issue_round(blockIdx.x);
-
-  // ---- this wave's weight fragments: item j of the wave is (nt, tt) = ((wave + 8 j) % NT, (wave + 8 j) / NT) ------
-  Pack16 wf[ND][KSTEPS];
-#pragma unroll
-  for (int jd = 0; jd < ND; ++jd) {
-    const int nt = (wave + 8 * jd) % NT;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.Wp) +
-                                                             (((int64_t)nt * KSTEPS + ks) * 64 + lane) * 16);
-      wf[jd][ks].w[0] = v.x; wf[jd][ks].w[1] = v.y; wf[jd][ks].w[2] = v.z; wf[jd][ks].w[3] = v.w;
-    }
-  }
-  for (int i = tid; i < 2 * NT * 32; i += 512) sbL[i] = p.sb[i];
 
   for (int tile0 = blockIdx.x; tile0 < p.ntiles; tile0 += grid * NBUF) {
-    if (tile0 != (int)blockIdx.x) issue_round(tile0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    issue_round(tile0);
 #pragma unroll 1
     for (int b = 0; b < NBUF; ++b) {
       const int tile = tile0 + b * grid;
       if (tile >= p.ntiles) break;
+      switch (NBUF - 1 - b) {   // the wait's count is an instruction immediate
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT * 3) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT * 2) : "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT * 1) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      }
+#pragma unroll
+      for (int jd = 0; jd < ND; ++jd)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) asm volatile("" : "+v"(wfr[jd][ks]));   // every use of a fragment is behind a wait
+      __syncthreads();
       const char* tb = smem + b * CF::TILEB;
+      const char* rb = smem + CF::R_OFF + b * CF::RTILEB;
       float* st = statL + b * L3_TT * 2;
       if constexpr (LN) {
         // (mean, rstd) of every token of the tile: 4 lanes per token, two passes over the row's 16-B slots
-        const int tok = tid >> 2, part = tid & 3;
-        constexpr int NSL = (CF::XD + 3) / 4;
-        float xv[NSL][8];
-        float sum = 0.f;
+        for (int tok = tid >> 2; tok < L3_TT; tok += NTHR / 4) {
+          const int part = tid & 3;
+          constexpr int NSL = (CF::XD + 3) / 4;
+          float xv[NSL][8];
+          float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NSL; ++i) {
-          const int sl = part + 4 * i;
-          const Pack16 q = *reinterpret_cast<const Pack16*>(tb + tok * XS + (sl < CF::XD ? sl : 0) * 16);
-          Mma<bf16>::unpack(q, xv[i]);
+          for (int i = 0; i < NSL; ++i) {
+            const int sl = part + 4 * i;
+            const Pack16 q = *reinterpret_cast<const Pack16*>(tb + tok * XS + (sl < CF::XD ? sl : 0) * 16);
+            Mma<bf16>::unpack(q, xv[i]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const bool valid = sl < CF::XD && sl * 8 + e < K;
-            xv[i][e] = valid ? xv[i][e] : 0.f;
-            sum += xv[i][e];
+            for (int e = 0; e < 8; ++e) {
+              const bool valid = sl < CF::XD && sl * 8 + e < K;
+              xv[i][e] = valid ? xv[i][e] : 0.f;
+              sum += xv[i][e];
+            }
           }
-        }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        const float mean = sum * (1.0f / K);
-        float sq = 0.f;
+          sum += __shfl_xor(sum, 1, 64);
+          sum += __shfl_xor(sum, 2, 64);
+          const float mean = sum * (1.0f / K);
+          float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < NSL; ++i) {
-          const int sl = part + 4 * i;
+          for (int i = 0; i < NSL; ++i) {
+            const int sl = part + 4 * i;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const bool valid = sl < CF::XD && sl * 8 + e < K;
-            const float d = xv[i][e] - mean;
-            sq = valid ? fmaf(d, d, sq) : sq;
+            for (int e = 0; e < 8; ++e) {
+              const bool valid = sl < CF::XD && sl * 8 + e < K;
+              const float d = xv[i][e] - mean;
+              sq = valid ? fmaf(d, d, sq) : sq;
+            }
           }
-        }
-        sq += __shfl_xor(sq, 1, 64);
-        sq += __shfl_xor(sq, 2, 64);
-        const float rstd = rsqrtf(sq * (1.0f / K) + 1e-5f);
-        if (part == 0) {
-          st[tok * 2] = mean;
-          st[tok * 2 + 1] = rstd;
-          const int grow = tile * L3_TT + tok;
-          if (grow < p.M) *reinterpret_cast<float2*>(p.stats + (int64_t)grow * 2) = make_float2(mean, rstd);
+          sq += __shfl_xor(sq, 1, 64);
+          sq += __shfl_xor(sq, 2, 64);
+          const float rstd = rsqrtf(sq * (1.0f / K) + 1e-5f);
+          if (part == 0) {
+            st[tok * 2] = mean;
+            st[tok * 2 + 1] = rstd;
+            const int grow = tile * L3_TT + tok;
+            if (grow < p.M) *reinterpret_cast<float2*>(p.stats + (int64_t)grow * 2) = make_float2(mean, rstd);
+          }
         }
         __syncthreads();
       }
+      // items j = jd, jd + ND, ... share the output tile (and the registers) of fragment set jd: one unrolled body per
+      // set, a rolled loop over its token sub-tiles
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int item = wave + 8 * j;
-        if (item >= CF::ITEMS) continue;                      // wave-uniform
+      for (int jd = 0; jd < ND; ++jd)
+#pragma unroll 1
+      for (int j = jd; j < NJ; j += ND) {
+        const int item = wave + NW * j;
+        if (item >= CF::ITEMS) break;                         // wave-uniform
         const int nt = item % NT, tt = item / NT;
         const int tok = tt * 32 + r;
         const int grow = tile * L3_TT + tok;
-        uint32_t rpre[2][4];
-        if constexpr (RES) {
-#pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            const int cb = nt * 32 + 8 * (2 * gp + h), nv = p.N - cb;
-            const bf16* rp = p.R + ((grow < p.M ? grow : 0) * (int)p.ldr + (nv > 0 ? cb : 0));
-            if (nv >= 8) {
-              const u32x4_a4 q4 = *reinterpret_cast<const u32x4_a4*>(rp);
-              rpre[gp][0] = q4.x; rpre[gp][1] = q4.y; rpre[gp][2] = q4.z; rpre[gp][3] = q4.w;
-            } else {
-#pragma unroll
-              for (int d = 0; d < 4; ++d) rpre[gp][d] = (2 * d + 2 <= nv) ? *reinterpret_cast<const uint32_t*>(rp + 2 * d) : 0u;
-            }
-          }
-        }
         f32x16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
@@ -206,7 +249,7 @@ __global__ void __launch_bounds__(512, 2) lin3_kernel(const L3Args p) {
 #pragma unroll
             for (int d = 0; d < 4; ++d) bq.w[d] = (2 * d < (h ? c1 : c0)) ? bq.w[d] : 0u;
           }
-          Mma<bf16>::mma(acc, wf[j % ND][ks], bq);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfr[jd][ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
         }
         // epilogue: register group g4 holds outputs n = 32 nt + 8 g4 + 4 h + (0..3)
         float mean = 0.f, rstd = 1.f;
@@ -228,6 +271,11 @@ __global__ void __launch_bounds__(512, 2) lin3_kernel(const L3Args p) {
           } else {
             acc[4 * g4] += B4.x; acc[4 * g4 + 1] += B4.y; acc[4 * g4 + 2] += B4.z; acc[4 * g4 + 3] += B4.w;
           }
+          if constexpr (RES) {   // + the residual's 4 channels of this group: 8 B of the token's row in the R tile
+            const u32x2_a4 rr = *reinterpret_cast<const u32x2_a4*>(rb + tok * CF::RS + n0 * 2);
+            acc[4 * g4] += bf16lo(rr.x); acc[4 * g4 + 1] += bf16hi(rr.x);
+            acc[4 * g4 + 2] += bf16lo(rr.y); acc[4 * g4 + 3] += bf16hi(rr.y);
+          }
         }
         if (grow < p.M) {
 #pragma unroll
@@ -243,10 +291,6 @@ __global__ void __launch_bounds__(512, 2) lin3_kernel(const L3Args p) {
             const int cb = nt * 32 + 8 * (2 * gp + h);          // the lane's 8 consecutive outputs
             const int nv = p.N - cb;                            // valid outputs from cb on (N is even)
             if (nv <= 0) continue;
-            if constexpr (RES) {
-#pragma unroll
-              for (int d = 0; d < 4; ++d) { c8[2 * d] += bf16lo(rpre[gp][d]); c8[2 * d + 1] += bf16hi(rpre[gp][d]); }
-            }
             bf16* yp = p.Y + (grow * (int)p.ldy + cb);
             if (nv >= 8) {
               u32x4_a4 u;
@@ -270,14 +314,15 @@ template <int K, int NT, bool LN, bool RES>
 int launch_l3(L3Args& p, hipStream_t st, const char* what) {
   using CF = L3Cfg<K, NT, LN, RES>;
   p.ntiles = (p.M + L3_TT - 1) / L3_TT;
-  const int grid = p.ntiles < 256 ? p.ntiles : 256;
+  int grid = (p.ntiles + CF::NBUF - 1) / CF::NBUF;
+  if (grid > 256 * CF::WGCU) grid = 256 * CF::WGCU;
   auto kern = lin3_kernel<K, NT, LN, RES>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), CF::SMEM, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CF::NTHR), CF::SMEM, st, p);
   return rdst_launch_status(what);
 }
 
@@ -312,7 +357,8 @@ int lin3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln
     if (int rc = rdst_launch_status("lin3_pack")) return rc;
   }
   L3Args p{};
-  p.X = X; p.ldx = ldx; p.x_bytes = (int)xb; p.Wp = wp; p.sb = sb; p.R = R; p.ldr = ldr; p.Y = Y; p.ldy = ldy; p.stats = stats;
+  p.X = X; p.ldx = ldx; p.x_bytes = (int)xb; p.Wp = wp; p.sb = sb; p.R = R; p.ldr = ldr;
+  p.r_bytes = R ? (int)(((M - 1) * ldr + N) * 2) : 0; p.Y = Y; p.ldy = ldy; p.stats = stats;
   p.M = (int)M; p.N = N;
 #define L3_CASE(KK)                                                                                   \
   if (K == KK) {                                                                                      \
