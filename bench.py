@@ -72,7 +72,7 @@ def _alg(name, a, elt):
         return (M * (K + N + (K if a[9] else 0) + (K if a[11] else 0)) * elt,
                 2 * M * K * N * ((1 if a[9] else 0) + (1 if a[13] else 0)) if a[6] else 0)
     if name == "rdst_mlp_fwd":
-        M, C, hid = a[11:14]
+        M, C, hid = a[13:16]
         return 2 * M * C * elt, 4 * M * C * hid
     if name == "rdst_mlp_bwd":
         M, C, hid = a[20:23]

@@ -125,9 +125,15 @@ int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const flo
 int rdst_mlp_fused_supported(int C, int hid, int dtype);
 /* Forward: Y (M, C) = X + fc2(GELU(fc1(LayerNorm(X)))) in one pass; the hidden activations never reach HBM and
  * nothing but `stats` (M, 2) {mean, rstd} is kept for the backward.  b1 / b2 may be NULL.  Y may not alias X. */
+/* workspace: rdst_mlp_fwd_workspace(C, hid) bytes (16-byte aligned) for the packed weight images [fc1: Linear image of
+ * (W1, ln_w, ln_b, b1)][fc2: Linear image of (W2, b2)] that the streaming kernel (mlp3_mfma.hip) reads; NULL / 0 selects
+ * the kernel that stages the fp32 weights itself; RDST_PREPACKED = the two images are already there (rdst_pack_batch
+ * with two RDST_PACK_LINEAR jobs whose `out` are workspace and workspace + rdst_ln_linear_fwd_workspace(C, hid)). */
+size_t rdst_mlp_fwd_workspace(int C, int hid);
+int rdst_mlp_fwd_packable(int C, int hid, int dtype);
 int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* W1,
                  const float* b1, const float* W2, const float* b2, void* Y, int64_t ld_y, float* stats,
-                 int64_t M, int C, int hid, int dtype, void* stream);
+                 void* workspace, size_t workspace_bytes, int64_t M, int C, int hid, int dtype, void* stream);
 size_t rdst_mlp_bwd_workspace(int64_t M, int C, int hid);
 int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
                  const float* W1, const float* b1, const float* W2, const void* dY, int64_t ld_dy, void* dX,

@@ -29,7 +29,9 @@ SIGNATURES = {
     "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
                                 _l, _i, _i, _f, _i, _p]),
     "rdst_mlp_fused_supported": (_i, [_i, _i, _i]),
-    "rdst_mlp_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _i, _i, _i, _p]),
+    "rdst_mlp_fwd_workspace": (_z, [_i, _i]),
+    "rdst_mlp_fwd_packable": (_i, [_i, _i, _i]),
+    "rdst_mlp_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _z, _l, _i, _i, _i, _p]),
     "rdst_mlp_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_mlp_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p, _z, _l, _i, _i, _i,
                           _p]),

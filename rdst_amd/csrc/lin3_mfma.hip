@@ -328,6 +328,17 @@ int launch_l3(L3Args& p, hipStream_t st, const char* what) {
 
 }  // namespace
 
+// image of one Linear layer at `out`: [fragments (N/32 tiles x K/16 steps) x 1 KB][S (NP floats)][b' (NP floats)]
+int lin3_pack_launch(const float* W, const float* gamma, const float* beta, const float* bias, void* out, int N, int K, float s,
+                     hipStream_t st) {
+  const int nt = (N + 31) / 32, ks = (K + 15) / 16;
+  bf16* wp = reinterpret_cast<bf16*>(out);
+  float* sb = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + (size_t)nt * ks * 1024);
+  const int nfr = nt * ks * 64, nb1 = (nfr + 255) / 256, nb2 = (nt * 32 + 3) / 4;
+  hipLaunchKernelGGL(lin3_pack_kernel, dim3((unsigned)(nb1 + nb2)), dim3(256), 0, st, W, gamma, beta, bias, wp, sb, N, K, ks, nt, s);
+  return rdst_launch_status("lin3_pack");
+}
+
 size_t lin3_pack_bytes(int K, int N) {
   const int nt = (N + 31) / 32, ks = (K + 15) / 16;
   return (size_t)nt * ks * 1024 + (size_t)2 * nt * 32 * 4 + 256;

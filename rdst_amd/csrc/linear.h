@@ -54,3 +54,10 @@ size_t lin3_pack_bytes(int K, int N);
 int lin3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt, const float* bias,
                   const bf16* R, int64_t ldr, bf16* Y, int64_t ldy, float* stats, int64_t M, int K, int N, float s, void* wpack,
                   bool prepacked, hipStream_t st);
+int lin3_pack_launch(const float* W, const float* gamma, const float* beta, const float* bias, void* out, int N, int K, float s,
+                     hipStream_t st);
+// fused Mlp forward on the same skeleton (mlp3_mfma.hip): wpack = mlp3_pack_bytes(C, hid) bytes = [fc1 image][fc2 image]
+size_t mlp3_pack_bytes(int C, int hid);
+int mlp3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2,
+                  const float* b2, bf16* Y, int64_t ldy, float* stats, int64_t M, int C, int hid, void* wpack, bool prepacked,
+                  hipStream_t st);

@@ -1263,15 +1263,28 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   return wgrad_ln_finish_launch(G, W1, ln_w, ln_b, hid, C, 1.0f, dW1, db1, dln_w, dln_b, st);
 }
 
+extern "C" size_t rdst_mlp_fwd_workspace(int C, int hid) {
+  if (C <= 0 || hid <= 0) return 16;
+  return mlp3_pack_bytes(C, hid);
+}
+extern "C" int rdst_mlp_fwd_packable(int C, int hid, int dtype) {
+  return dtype == RDST_BF16 && hid == 2 * C && (C == 60 || C == 90 || C == 120);
+}
+
 extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* W1, const float* b1,
-                            const float* W2, const float* b2, void* Y, int64_t ld_y, float* stats, int64_t M, int C, int hid,
-                            int dtype, void* stream) {
+                            const float* W2, const float* b2, void* Y, int64_t ld_y, float* stats, void* workspace,
+                            size_t workspace_bytes, int64_t M, int C, int hid, int dtype, void* stream) {
   if (!X || !ln_w || !ln_b || !W1 || !W2 || !Y || !stats) return rdst_fail(RDST_EINVAL, "rdst_mlp_fwd: null pointer");
   if (M < 0 || C <= 0 || hid <= 0 || ld_x < C || ld_y < C) return rdst_fail(RDST_EINVAL, "rdst_mlp_fwd: bad dimensions");
   if (!rdst_mlp_fused_supported(C, hid, dtype)) return RDST_ENOTSUP;
   if (((uintptr_t)X & 3) || ((uintptr_t)Y & 3) || (ld_x & 1) || (ld_y & 1) || hid < 8) return RDST_ENOTSUP;
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && workspace_bytes >= rdst_mlp_fwd_workspace(C, hid)) {   // streaming kernel on pre-packed weights (mlp3_mfma.hip)
+    const int rc = mlp3_fwd_bf16((const bf16*)X, ld_x, ln_w, ln_b, W1, b1, W2, b2, (bf16*)Y, ld_y, stats, M, C, hid, workspace,
+                                 workspace_bytes == RDST_PREPACKED, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   const int nct = mlp_nct(C, hid);
   MlpFwdArgs p{};
   p.X = (const bf16*)X; p.ldx = ld_x; p.lnw = ln_w; p.lnb = ln_b; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2;

@@ -113,12 +113,27 @@ class PackPlan:
     def _key(kind, w, lw, lb, b, N, K, s):
         return (kind, w.data_ptr(), _ptr(lw) or 0, _ptr(lb) or 0, _ptr(b) or 0, N, K, float(s))
 
-    def record(self, kind, w, lw, lb, b, N, K, s, nbytes):
-        k = self._key(kind, w, lw, lb, b, N, K, s)
+    def record(self, kind, w, lw, lb, b, N, K, s, nbytes, key=None):
+        k = key if key is not None else self._key(kind, w, lw, lb, b, N, K, s)
         if k not in self.keys:
             self.keys[k] = len(self.specs)
-            self.specs.append((kind, N, K, float(s), (int(nbytes) + 255) // 256 * 256))
+            self.specs.append((kind, N, K, float(s), int(nbytes)))
             self.tensors.append((w, lw, lb, b))
+
+    def record_mlp(self, w1, lw, lb, b1, w2, b2, C, hid, nb1, nb2):
+        """Two consecutive Linear images (fc1 with the LayerNorm folded in, fc2) = the workspace layout of rdst_mlp_fwd."""
+        k = ("mlp", w1.data_ptr(), w2.data_ptr(), _ptr(lw) or 0, _ptr(lb) or 0, _ptr(b1) or 0, _ptr(b2) or 0)
+        if k not in self.keys:
+            self.record(PACK_LINEAR, w1, lw, lb, b1, hid, C, 1.0, nb1, key=k)
+            self.record(PACK_LINEAR, w2, None, None, b2, C, hid, 1.0, (nb2 + 255) // 256 * 256, key=k + ("fc2",))
+
+    def lookup_mlp(self, w1, lw, lb, b1, w2, b2):
+        k = ("mlp", w1.data_ptr(), w2.data_ptr(), _ptr(lw) or 0, _ptr(lb) or 0, _ptr(b1) or 0, _ptr(b2) or 0)
+        i = self.keys.get(k)
+        if i is None:
+            self.misses += 1
+            return None
+        return self.arena.data_ptr() + self.offsets[i]
 
     def finalize(self, device):
         if not self.specs:
@@ -198,7 +213,7 @@ def _packed_workspace(kind, w, lw, lb, b, N, K, s, nbytes, device):
         if p is not None:
             return None, p, _lib.PREPACKED
     if _plan_recording is not None:
-        _plan_recording.record(kind, w, lw, lb, b, N, K, s, nbytes)
+        _plan_recording.record(kind, w, lw, lb, b, N, K, s, (int(nbytes) + 255) // 256 * 256)
     wsp = _workspace(nbytes, device)
     return wsp, wsp.data_ptr(), int(nbytes)
 
@@ -467,8 +482,20 @@ class _SwinBlock(torch.autograd.Function):
         fused_mlp = MLP_FUSED and n2w_ is not None and bool(lib.rdst_mlp_fused_supported(C, hid, code))
         if fused_mlp:
             # K7: the whole Mlp half in one kernel; the hidden activations are not kept (the backward recomputes them)
+            wptr, nws, _wsp = None, 0, None
+            if lib.rdst_mlp_fwd_packable(C, hid, code):
+                nb1, nb2 = lib.rdst_ln_linear_fwd_workspace(C, hid), lib.rdst_ln_linear_fwd_workspace(hid, C)
+                if _plan_active is not None:
+                    wptr = _plan_active.lookup_mlp(fc1w_, n2w_, n2b_, fc1b_, fc2w_, fc2b_)
+                    nws = _lib.PREPACKED
+                if wptr is None:
+                    if _plan_recording is not None:
+                        _plan_recording.record_mlp(fc1w_, n2w_, n2b_, fc1b_, fc2w_, fc2b_, C, hid, nb1, nb2)
+                    nws = lib.rdst_mlp_fwd_workspace(C, hid)
+                    _wsp = _workspace(nws, dev)
+                    wptr = _wsp.data_ptr()
             rc = lib.rdst_mlp_fwd(x1.data_ptr(), C, n2w_.data_ptr(), n2b_.data_ptr(), fc1w_.data_ptr(), _ptr(fc1b_),
-                                  fc2w_.data_ptr(), _ptr(fc2b_), y.data_ptr(), C, stats2.data_ptr(), M, C, hid, code, st)
+                                  fc2w_.data_ptr(), _ptr(fc2b_), y.data_ptr(), C, stats2.data_ptr(), wptr, nws, M, C, hid, code, st)
             if rc == _lib.ENOTSUP:
                 fused_mlp = False
             else:

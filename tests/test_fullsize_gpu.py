@@ -101,8 +101,10 @@ def test_mlp_fused_bf16_4096_tiles(C):
     st = torch.cuda.current_stream().cuda_stream
     y = torch.full_like(xg, float("nan"))
     stats = torch.full((M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    nwf = lib.rdst_mlp_fwd_workspace(C, hid)
+    wsf = torch.empty(max(nwf, 16), dtype=torch.uint8, device=DEV)
     _lib.check(lib.rdst_mlp_fwd(xg.data_ptr(), C, P[0].data_ptr(), P[1].data_ptr(), P[2].data_ptr(), P[3].data_ptr(),
-                                P[4].data_ptr(), P[5].data_ptr(), y.data_ptr(), C, stats.data_ptr(), M, C, hid, _lib.BF16,
+                                P[4].data_ptr(), P[5].data_ptr(), y.data_ptr(), C, stats.data_ptr(), wsf.data_ptr(), nwf, M, C, hid, _lib.BF16,
                                 st), "rdst_mlp_fwd")
     dx = torch.full_like(xg, float("nan"))
     G = [torch.full_like(t, float("nan")) for t in (P[2], P[3], P[4], P[5], P[0], P[1])]   # dW1 db1 dW2 db2 dlw dlb

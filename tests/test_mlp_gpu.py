@@ -84,8 +84,10 @@ def test_mlp_fwd_fused(M, C, hid):
     y = torch.full_like(xg, float("nan"))
     stats = torch.full((M, 2), float("nan"), dtype=torch.float32, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
+    nwf = lib.rdst_mlp_fwd_workspace(C, hid)
+    wsf = torch.empty(max(nwf, 16), dtype=torch.uint8, device=DEV)
     _lib.check(lib.rdst_mlp_fwd(xg.data_ptr(), C, P[0].data_ptr(), P[1].data_ptr(), P[2].data_ptr(), P[3].data_ptr(),
-                                P[4].data_ptr(), P[5].data_ptr(), y.data_ptr(), C, stats.data_ptr(), M, C, hid, _lib.BF16,
+                                P[4].data_ptr(), P[5].data_ptr(), y.data_ptr(), C, stats.data_ptr(), wsf.data_ptr(), nwf, M, C, hid, _lib.BF16,
                                 st), "rdst_mlp_fwd")
     torch.cuda.synchronize()
     # bf16 operands, fp32 accumulation, bf16 output: the bound test_ops_gpu.py uses for the unfused bf16 kernels
