@@ -169,10 +169,17 @@ def _pmc_traffic(kernel_key, files):
         return None, f"no PMC collection ({type(e).__name__})"
 
 
-def build_net(device, dtype):
+# BASELINE.json configs[3]: RDST x2, 3-channel (BraTS-style), 128x128 -> 256x256, window 16 (`--config ws16`; a parity /
+# stress configuration, not the headline workload: its window attention runs on the shape-generic kernels)
+WS16 = dict(E1, img_size=128, in_chans=3, sr_scale=2, window_size=[16] * 8)
+CONFIGS = {"e1": (E1, 64, 1, 4, "RDST-E1 x4 (RDST_E1_OASIS_example_SRx4.ini), 1x64x64 LR patches -> 256x256"),
+           "ws16": (WS16, 128, 3, 2, "RDST x2 3-channel, window 16 (BASELINE configs[3]), 3x128x128 LR patches -> 256x256")}
+
+
+def build_net(device, dtype, cfg=None):
     from rdst_amd.networks.rdst_variations import RDSTSR
     torch.manual_seed(0)                       # seeded default init, as SURVEY.md §8d prescribes
-    net = RDSTSR(**E1)
+    net = RDSTSR(**(cfg or E1))
     net.to(device).train().set_compute_dtype(dtype)
     return net
 
@@ -226,7 +233,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="patches per GPU (default 32; 8 for --config ws16)")
+    ap.add_argument("--config", default="e1", choices=sorted(CONFIGS), help="e1 = the BASELINE.json metric (default)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -249,15 +257,20 @@ def main():
 
     from rdst_amd import dp, ops, optim
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    net = build_net(device, dtype)
+    cfg, lr_size, in_ch, sr, cfg_name = CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = 32 if args.config == "e1" else 8
+    if args.config != "e1":
+        args.no_roofline = True               # the per-op table and K1 roofline are defined for the headline workload
+    net = build_net(device, dtype, cfg)
     dp.broadcast_parameters(net)
     bucket = dp.FlatGradBucket(net.parameters())
     # utils/optim.py:30-53 with the ini's hyper-parameters; one fused HIP launch over the flat buffers
     opt = optim.FlatAdam(bucket.params, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, bucket=bucket)
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
-    x = torch.rand(B, 1, 64, 64, generator=g).to(device)
-    tgt = torch.rand(B, 1, 256, 256, generator=g).to(device)
+    x = torch.rand(B, in_ch, lr_size, lr_size, generator=g).to(device)
+    tgt = torch.rand(B, in_ch, lr_size * sr, lr_size * sr, generator=g).to(device)
     loss_buf = torch.zeros((), device=device)
 
     def fwd_bwd():
@@ -328,15 +341,15 @@ def main():
     loss_val = float(loss_buf.item())
 
     out = {
-        "metric": "SR patches/sec fwd+bwd, RDST-E1 x4 64->256",
+        "metric": "SR patches/sec fwd+bwd, RDST-E1 x4 64->256" if args.config == "e1" else
+                  "SR patches/sec fwd+bwd, RDST x2 window-16 128->256 (BASELINE configs[3])",
         "value": round(world * B * args.steps / elapsed, 3),
         "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "RDST-E1 x4 (RDST_E1_OASIS_example_SRx4.ini), 1x64x64 LR patches -> 256x256, "
-                               "step = fwd + L1 + bwd + flat-bucket grad all-reduce + Adam",
+        "config": {"workload": cfg_name + ", step = fwd + L1 + bwd + flat-bucket grad all-reduce + Adam",
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "hip_graph": graph is not None, "grad_bucket_bytes": bucket.nbytes},
         "loss": round(loss_val, 6),

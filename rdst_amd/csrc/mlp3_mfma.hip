@@ -31,6 +31,7 @@ struct M3Args {
   bf16* Y; int64_t ldy;
   float* stats;
   int M, ntiles;
+  unsigned long long* stamps;   // debug build: [grid][8] cycle counters (RDST_M3_STAMPS), else null
 };
 
 constexpr int m3_nw(int C) { return ((2 * C + 31) / 32) % 3 == 0 ? 6 : 8; }   // hidden tiles 4 / 6 / 8 -> 8 / 6 / 8 waves
@@ -59,6 +60,7 @@ struct M3Cfg {
   static constexpr int WGCU = SMEM <= 80 * 1024 ? 2 : 1;
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(TP >= NW, "every wave owns at least one piece of a tile");
+  static_assert(CNT + 1 + 2 * ((NT2 * 4) / NW) < 64, "vmcnt is a 6-bit counter");
 };
 
 template <int C>
@@ -91,6 +93,14 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
                  : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
   };
   const int grid = gridDim.x;
+  unsigned long long tprev = RDST_DBGV(p.stamps) ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_ADD(k)                                                   \
+  if (RDST_DBGV(p.stamps)) {                                           \
+    const unsigned long long tn_ = __builtin_readcyclecounter();       \
+    tacc[k] += tn_ - tprev;                                            \
+    tprev = tn_;                                                       \
+  }
   // ---- weight fragments (inline-asm loads, issued before the tiles: see lin3_mfma.hip) ---------------------------
   typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
   u32x4v_t w1[ND1][KS1], w2[ND2][KS2];
@@ -135,13 +145,16 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
   // tiles of this workgroup: blockIdx.x + k * grid; tile k lives in buffer k & 1; tile k + 1 is in flight while k is computed
   issue_tile(blockIdx.x, 0);
   issue_tile(blockIdx.x + grid, 1);
-  // Waits: tile 0 by a counted wait (tile 1 stays in flight); tile k + 1 is waited for inside iteration k, in front of
-  // phase 2 — i.e. BEFORE this iteration's stores are issued, so the wait never has to sit out a store's round trip
-  // (memory operations retire in issue order; stores and loads share the counter).
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+  // Waits (memory operations retire in issue order; loads, stores and LDS-DMA share one counter): when iteration k
+  // starts, the operations YOUNGER than tile k's pieces are tile k + 1's CNT pieces and — from the second iteration on —
+  // the previous iteration's statistics store and its phase-2 stores, at least NST of them in every wave.  Waiting for
+  // "all but that many" therefore never waits for a store's round trip and never lets tile k slip.
+  constexpr int NST = 1 + 2 * ((NT2 * 4) / NW);
   int kk = 0;
   for (int tile = blockIdx.x; tile < p.ntiles; tile += grid, ++kk) {
     const int b = kk & 1;
+    if (kk == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT + NST) : "memory");
 #pragma unroll
     for (int jd = 0; jd < ND1; ++jd)
 #pragma unroll
@@ -151,6 +164,7 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) asm volatile("" : "+v"(w2[jd][ks]));
     __syncthreads();   // B0: tile landed (and: every wave is done with the previous tile's h)
+    STAMP_ADD(0);
     const char* tb = smem + b * CF::TILEB;
     float* st = statL + b * M3_TT * 2;
     for (int tok = tid >> 2; tok < M3_TT; tok += CF::NTHR / 4) {  // (mean, rstd): 4 lanes per token, two passes over the row's 16-B slots
@@ -195,6 +209,7 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
       }
     }
     __syncthreads();   // B1: statistics visible
+    STAMP_ADD(1);
     // ---- phase 1: h = GELU(LN(x) W1^T + b1) -> LDS -----------------------------------------------------------
 #pragma unroll
     for (int jd = 0; jd < ND1; ++jd)
@@ -226,6 +241,7 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
           const int n0 = nt * 32 + 8 * g4 + 4 * h;
           const float4 S4 = *reinterpret_cast<const float4*>(sb1L + n0);
           const float4 B4 = *reinterpret_cast<const float4*>(sb1L + NT1 * 32 + n0);
+          // (packed fp32 arithmetic, v_pk_fma_f32, was tried here: same time — the phase runs at the vector-issue rate)
           const float h0 = gelu_fast(fmaf(rstd, acc[4 * g4], fmaf(nrm, S4.x, B4.x)));
           const float h1 = gelu_fast(fmaf(rstd, acc[4 * g4 + 1], fmaf(nrm, S4.y, B4.y)));
           const float h2 = gelu_fast(fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4.z, B4.z)));
@@ -235,8 +251,9 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
           if (n0 * 2 + 8 <= HS) *reinterpret_cast<u32x2_a4*>(hrow + n0 * 2) = u;   // (padded hidden units past the row are dropped)
         }
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile k + 1 (issued an iteration ago) has landed
+    STAMP_ADD(2);
     __syncthreads();   // B2: h complete
+    STAMP_ADD(3);
     // ---- phase 2: y = x + h W2^T + b2 -------------------------------------------------------------------------
 #pragma unroll
     for (int jd = 0; jd < ND2; ++jd)
@@ -296,9 +313,14 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
           }
         }
       }
+    STAMP_ADD(4);
     __syncthreads();   // B3: the x tile (residual reads) and h are free: buffer b may take tile k + 2
     issue_tile(tile + 2 * grid, b);
+    STAMP_ADD(5);
   }
+  if (RDST_DBGV(p.stamps) && tid == 0)
+    for (int k = 0; k < 8; ++k) p.stamps[(size_t)blockIdx.x * 8 + k] = tacc[k];
+#undef STAMP_ADD
 }
 
 template <int C>
@@ -314,7 +336,9 @@ int launch_m3(M3Args& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
     attr = true;
   }
+  p.stamps = rdst_stamps_begin("RDST_M3_STAMPS", grid, 8, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CF::NTHR), CF::SMEM, st, p);
+  rdst_stamps_end("mlp3_fwd: 0 wait+B0, 1 stats, 2 phase 1, 3 wait+B2, 4 phase 2, 5 B3+issue", p.stamps, grid, 8, st);
   return rdst_launch_status("mlp3_fwd");
 }
 
