@@ -441,16 +441,20 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
   }
   if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
   // ---- epilogue: the workgroup's partial weight gradients
-  float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
-  float* my2 = my + (int64_t)hid * (C + 1);
+  // bf16 slabs in groups of 4 rows (reduce_batch.h, "G4"): the lane's 4 consecutive rows of a register group = one 8-B store.
+  // region 1: G1 [hid][C+1]; region 2: dW2^T [hid+1][C] (row hid = d(b2)); p.slab_stride counts 8-byte groups
+  uint2* my = reinterpret_cast<uint2*>(p.slab) + (int64_t)blockIdx.x * p.slab_stride;
+  uint2* my2 = my + (int64_t)((hid + 3) / 4) * (C + 1);
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
     const int c = 32 * ct + r;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int jj = 32 * wave + acc_row(v, hh);
-      if (jj < hid && c <= C) my[(int64_t)jj * (C + 1) + c] = G1[ct][v];
-      if (jj <= hid && c < C) my2[(int64_t)jj * C + c] = W2g[ct][v];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int j0 = 32 * wave + 8 * g4 + 4 * hh;   // rows j0 .. j0 + 3
+      if (j0 < hid && c <= C)
+        my[(int64_t)(j0 >> 2) * (C + 1) + c] = make_uint2(pack_bf16x2(G1[ct][4 * g4], G1[ct][4 * g4 + 1]), pack_bf16x2(G1[ct][4 * g4 + 2], G1[ct][4 * g4 + 3]));
+      if (j0 <= hid && c < C)
+        my2[(int64_t)(j0 >> 2) * C + c] = make_uint2(pack_bf16x2(W2g[ct][4 * g4], W2g[ct][4 * g4 + 1]), pack_bf16x2(W2g[ct][4 * g4 + 2], W2g[ct][4 * g4 + 3]));
     }
   }
   if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
@@ -1144,15 +1148,17 @@ __global__ void __launch_bounds__(768, 3) lnlin_bwd_kernel(const LnLinArgs p) {
     stamp();   // 3b
   }
   if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // slot 14: loop done
-  float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
+  // bf16 slab in groups of 4 rows (reduce_batch.h, "G4"): G [N][K+1]; p.slab_stride counts 8-byte groups
+  uint2* my = reinterpret_cast<uint2*>(p.slab) + (int64_t)blockIdx.x * p.slab_stride;
   if (wave < NW)
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
     const int c = 32 * ct + r;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int n = 32 * wave + acc_row(v, hh);
-      if (n < N && c <= K) my[(int64_t)n * (K + 1) + c] = G[ct][v];
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n0 = 32 * wave + 8 * g4 + 4 * hh;
+      if (n0 < N && c <= K)
+        my[(int64_t)(n0 >> 2) * (K + 1) + c] = make_uint2(pack_bf16x2(G[ct][4 * g4], G[ct][4 * g4 + 1]), pack_bf16x2(G[ct][4 * g4 + 2], G[ct][4 * g4 + 3]));
     }
   }
   if (RDST_DBGV(p.stamps) && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // slot 15: kernel end
@@ -1216,8 +1222,9 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
   grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   p.slab = (float*)workspace;
-  p.slab_stride = (int64_t)hid * (C + 1) + (int64_t)(hid + 1) * C;
-  float* G = p.slab + 512 * p.slab_stride;
+  // bf16 G4 slabs: (hid/4) x (C+1) groups of region 1 + (hid/4 + 1) x C groups of region 2, 8 bytes each (2 floats)
+  p.slab_stride = (int64_t)((hid + 3) / 4) * (C + 1) + (int64_t)((hid + 4) / 4) * C;
+  float* G = p.slab + 512 * ((int64_t)hid * (C + 1) + (int64_t)(hid + 1) * C);   // (behind the fp32-sized slab region)
 #define RDST_MLPB(NC)                                                                                                \
   {                                                                                                                  \
     auto kern = split ? mlp_bwd_kernel<NC, true> : mlp_bwd_kernel<NC, false>;                                                                                \
@@ -1255,10 +1262,15 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   if (int rc = rdst_launch_status("mlp_bwd")) return rc;
   const int tot = (int)p.slab_stride;
   {
-    rbatch::SumJob sj{};
-    sj.slab = p.slab; sj.nwg = (int)grid; sj.stride = p.slab_stride; sj.tot = tot; sj.map = rbatch::MAP_MLP;
-    sj.out = G; sj.out2 = dW2; sj.out3 = db2; sj.a = C; sj.b = hid;
-    if (int rc = rbatch::sum(sj, st)) return rc;
+    (void)tot;
+    rbatch::SumJob s1{};   // region 1 -> G [hid][C+1] for the LayerNorm finish
+    s1.slab = p.slab; s1.nwg = (int)grid; s1.stride = p.slab_stride; s1.g4 = 1; s1.a2 = hid; s1.b2 = C + 1;
+    s1.tot = ((hid + 3) / 4) * (C + 1); s1.map = rbatch::MAP_COPY; s1.out = G;
+    if (int rc = rbatch::sum(s1, st)) return rc;
+    rbatch::SumJob s2{};   // region 2 -> dW2 (C, hid) transposed back, row hid -> db2
+    s2.slab = p.slab + 2 * (int64_t)((hid + 3) / 4) * (C + 1); s2.nwg = (int)grid; s2.stride = p.slab_stride; s2.g4 = 1;
+    s2.a2 = hid + 1; s2.b2 = C; s2.tot = ((hid + 4) / 4) * C; s2.map = rbatch::MAP_T; s2.out = dW2; s2.out2 = db2; s2.a = hid;
+    if (int rc = rbatch::sum(s2, st)) return rc;
   }
   return wgrad_ln_finish_launch(G, W1, ln_w, ln_b, hid, C, 1.0f, dW1, db1, dln_w, dln_b, st);
 }
@@ -1377,7 +1389,7 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
   grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
   p.slab = slab;
-  p.slab_stride = (int64_t)N * (K + 1);
+  p.slab_stride = (int64_t)((N + 3) / 4) * (K + 1);   // bf16 G4 slab: 8-byte groups
 #define RDST_LNLIN(NC)                                                                                               \
   {                                                                                                                  \
     auto kern = ln ? lnlin_bwd_kernel<NC, true> : lnlin_bwd_kernel<NC, false>;                                       \
@@ -1410,7 +1422,13 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
     free(hst);
   }
   if (int rc = rdst_launch_status("lnlin_bwd")) return rc;
-  if (!ln) return wgrad_reduce_launch(slab, (int)grid, N, K, 1.0f, dW, dbias, st);
-  if (int rc = wgrad_sum_launch(slab, (int)grid, N * (K + 1), G, st)) return rc;
+  rbatch::SumJob sj{};
+  sj.slab = slab; sj.nwg = (int)grid; sj.stride = p.slab_stride; sj.g4 = 1; sj.a2 = N; sj.b2 = K + 1; sj.tot = ((N + 3) / 4) * (K + 1);
+  if (!ln) {
+    sj.map = rbatch::MAP_LINEAR; sj.out = dW; sj.out2 = dbias; sj.a = K; sj.b = K + 1; sj.s = 1.0f;
+    return rbatch::sum(sj, st);
+  }
+  sj.map = rbatch::MAP_COPY; sj.out = G;
+  if (int rc = rbatch::sum(sj, st)) return rc;
   return wgrad_ln_finish_launch(G, Wt, ln_w, ln_b, N, K, 1.0f, dW, dbias, dln_w, dln_b, st);
 }

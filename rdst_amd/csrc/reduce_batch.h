@@ -15,9 +15,17 @@ enum SumMap {
   MAP_LINEAR = 1,    // i = n * Kx + k: k < K -> dW[n*K + k] = s * sum, k == K -> dbias[n] = s * sum
   MAP_MLP = 2,       // i < hid*(C+1) -> G[i]; then [hid+1][C]: dW2[c*hid + j] / db2[c]
   MAP_DTABLE = 3,    // i = h * T + t -> dtable[t * heads + h]
+  MAP_T = 4,         // element (j, c) of a [a+1][b] matrix: j < a -> out[c * a + j] (a transposed weight), j == a -> out2[c]
 };
+// Slab element formats: plain fp32 [tot], or G4 = bf16 in groups of 4 ROWS: element (n, c) of a [rows][W] matrix lives at
+// ((n >> 2) * W + c) * 4 + (n & 3) (in bf16 units), i.e. a lane that owns column c of an MFMA accumulator tile dumps the
+// 4 consecutive rows of a register group as ONE 8-byte store.  The partial sums of one workgroup (512 tokens of 131072)
+// are rounded to bf16 there; the sum over the workgroups runs in fp32 (error ~2^-9 / sqrt(#workgroups) of a partial:
+// far below the bf16 activations' own noise) and halves the slab traffic, the largest avoidable HBM stream of a step.
 struct SumJob {
   const float* slab; int nwg; int64_t stride; int tot; int map;
+  int g4;                                  // 0: fp32 slab, stride / tot in floats;  1: G4 bf16 slab: rows = a2, W = b2,
+  int a2, b2;                              //    stride in 8-byte groups, tot = ceil(rows / 4) * W groups
   float* out; float* out2; float* out3;   // MAP_LINEAR: dW, dbias;  MAP_MLP: G, dW2, db2;  MAP_DTABLE: dtable
   int a, b;                               // MAP_LINEAR: K, Kx;  MAP_MLP: C, hid;  MAP_DTABLE: heads, T
   float s;

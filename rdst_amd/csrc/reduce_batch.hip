@@ -13,49 +13,82 @@ thread_local bool g_active = false;
 thread_local std::vector<SumJob> g_sums;
 thread_local std::vector<FinJob> g_fins;
 
-// sum of the slabs in fixed order: 32 outputs per block, 8 slab groups x 8 loads in flight, two fixed-order levels
+// one summed element -> its destination(s)
+__device__ __forceinline__ void emit(const SumJob& J, int n, int c, int i, float a) {
+  if (J.map == MAP_COPY) {
+    J.out[J.g4 ? n * J.b2 + c : i] = a;
+  } else if (J.map == MAP_LINEAR) {
+    const int K = J.a, Kx = J.b;
+    if (!J.g4) { n = i / Kx; c = i - n * Kx; }
+    if (c < K) { if (J.out) J.out[(int64_t)n * K + c] = a * J.s; }
+    else if (c == K && J.out2) J.out2[n] = a * J.s;
+  } else if (J.map == MAP_MLP) {
+    const int C = J.a, hid = J.b, n1 = hid * (C + 1);
+    if (i < n1) J.out[i] = a;
+    else {
+      const int i2 = i - n1, jj = i2 / C, cc = i2 - jj * C;
+      if (jj < hid) J.out2[(int64_t)cc * hid + jj] = a;
+      else J.out3[cc] = a;
+    }
+  } else if (J.map == MAP_T) {
+    const int rows = J.a;   // n = j, c = channel
+    if (n < rows) J.out[(int64_t)c * rows + n] = a;
+    else if (n == rows) J.out2[c] = a;
+  } else {
+    const int heads = J.a, T = J.b, hh = i / T, t = i - hh * T;
+    J.out[t * heads + hh] = a;
+  }
+}
+
+// sum of the slabs in fixed order: 32 outputs (fp32) or 32 groups of 4 (G4) per block, 8 slab groups x 8 loads in flight,
+// two fixed-order levels
 __global__ void __launch_bounds__(256) batched_sum_kernel(const SumBatch bt) {
-  __shared__ float part[8][33];
+  __shared__ float part[4][8][33];
   int k = 0;
 #pragma unroll
   for (int q = 1; q < MAXJ; ++q) k += (q < bt.n && (int)blockIdx.x >= bt.first[q]) ? 1 : 0;
   const SumJob& J = bt.j[k];
   const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
   const int i = ((int)blockIdx.x - bt.first[k]) * 32 + o;
-  float a = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (i < J.tot) {
-    // slab element of output i (MAP_DTABLE: the slab rows are [heads][T] like the output index i = h * T + t)
-    for (int w0 = sg; w0 < J.nwg; w0 += 8 * 8) {
-      float v[8];
+    if (J.g4) {
+      const uint2* sl = reinterpret_cast<const uint2*>(J.slab);
+      for (int w0 = sg; w0 < J.nwg; w0 += 8 * 8) {
+        uint2 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < J.nwg) ? J.slab[(int64_t)(w0 + 8 * u) * J.stride + i] : 0.f;
+        for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < J.nwg) ? sl[(int64_t)(w0 + 8 * u) * J.stride + i] : make_uint2(0u, 0u);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += v[u];
+        for (int u = 0; u < 8; ++u) {
+          a0 += __uint_as_float(v[u].x << 16); a1 += __uint_as_float(v[u].x & 0xffff0000u);
+          a2 += __uint_as_float(v[u].y << 16); a3 += __uint_as_float(v[u].y & 0xffff0000u);
+        }
+      }
+    } else {
+      for (int w0 = sg; w0 < J.nwg; w0 += 8 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (w0 + 8 * u < J.nwg) ? J.slab[(int64_t)(w0 + 8 * u) * J.stride + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0 += v[u];
+      }
     }
   }
-  part[sg][o] = a;
+  part[0][sg][o] = a0; part[1][sg][o] = a1; part[2][sg][o] = a2; part[3][sg][o] = a3;
   __syncthreads();
   if (sg != 0 || i >= J.tot) return;
-  a = 0.f;
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < 8; ++q) a += part[q][o];
-  if (J.map == MAP_COPY) {
-    J.out[i] = a;
-  } else if (J.map == MAP_LINEAR) {
-    const int K = J.a, Kx = J.b, n = i / Kx, kk = i - n * Kx;
-    if (kk < K) { if (J.out) J.out[(int64_t)n * K + kk] = a * J.s; }
-    else if (kk == K && J.out2) J.out2[n] = a * J.s;
-  } else if (J.map == MAP_MLP) {
-    const int C = J.a, hid = J.b, n1 = hid * (C + 1);
-    if (i < n1) J.out[i] = a;
-    else {
-      const int i2 = i - n1, jj = i2 / C, c = i2 - jj * C;
-      if (jj < hid) J.out2[(int64_t)c * hid + jj] = a;
-      else J.out3[c] = a;
-    }
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[e] += part[e][q][o];
+  if (J.g4) {
+    const int W = J.b2, ng = i / W, c = i - ng * W;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * ng + e < J.a2) emit(J, 4 * ng + e, c, 0, r[e]);
   } else {
-    const int heads = J.a, T = J.b, hh = i / T, t = i - hh * T;
-    J.out[t * heads + hh] = a;
+    emit(J, 0, 0, i, r[0]);
   }
 }
 
