@@ -208,11 +208,13 @@ __global__ void __launch_bounds__(512, 2) conv3_wgrad_kernel(const W3Args p) {
     }
   }
   // ---- dump the accumulators: slab[wg][wave][tile][reg][lane] ---------------------------------------------------
-  float* my = p.slab + (size_t)blockIdx.x * CF::SLABF + (size_t)wave * TPW * 1024;
+  // as bf16 pairs (registers v, v + 1 = two consecutive output channels of the lane's column): the partial sums of one
+  // workgroup are rounded, the sum over the workgroups runs in fp32 (see reduce_batch.h on the G4 slabs)
+  uint32_t* my = reinterpret_cast<uint32_t*>(p.slab) + (size_t)blockIdx.x * (CF::SLABF / 2) + (size_t)wave * TPW * 512;
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) my[(t * 16 + v) * 64 + lane] = acc[t][v];
+    for (int v = 0; v < 16; v += 2) my[(t * 8 + (v >> 1)) * 64 + lane] = pack_bf16x2(acc[t][v], acc[t][v + 1]);
 }
 
 // dW[co][ci][tap] = s * sum_g slab[g][...], dbias[co] likewise (column 0 of the bias tile); one thread per accumulator
@@ -221,35 +223,41 @@ template <int CI, int CO, bool UNSHUF>
 __global__ void __launch_bounds__(256) conv3_wgrad_reduce_kernel(const float* __restrict__ slab, int npg, float s,
                                                                  float* __restrict__ dW, float* __restrict__ dbias) {
   using CF = W3Cfg<CI, CO, UNSHUF>;
+  // one thread per bf16 PAIR of the role-major dump (registers 2 vp, 2 vp + 1 of one lane): 4-byte loads
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= CF::ROLES * CF::SLABF) return;
-  const int role = i / CF::SLABF, e = i - role * CF::SLABF;
-  const int lane = e & 63, v = (e >> 6) & 15, t = (e >> 10) % CF::TPW, wave = (e >> 10) / CF::TPW;
+  if (i >= CF::ROLES * CF::SLABF / 2) return;
+  const int role = i / (CF::SLABF / 2), e = i - role * (CF::SLABF / 2);
+  const int lane = e & 63, vp = (e >> 6) & 7, t = (e >> 9) % CF::TPW, wave = (e >> 9) / CF::TPW;
   const int ctl = wave / CF::WPC, wq = wave % CF::WPC;
   const int n = wq * CF::TPW + t;
   if (n > 9 * CF::CIT) return;
-  const int m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);          // row of the accumulator tile
   const int col = lane & 31;
-  int co = (role * CF::CT + ctl) * 32 + m;
-  if (co >= CO) return;
-  if (UNSHUF) co = 4 * (co % (CO / 4)) + co / (CO / 4);            // k' = (CO/4) q + c'  ->  conv channel 4 c' + q
   const bool is_b = n == 9 * CF::CIT;
   const int tap = n / CF::CIT, ci = (n - tap * CF::CIT) * 32 + col;
   if (is_b ? col != 0 : ci >= CI) return;
-  float a = 0.f;
-  const float* src = slab + (size_t)role * CF::SLABF + e;
-  const size_t gstride = (size_t)CF::ROLES * CF::SLABF;
+  float a0 = 0.f, a1 = 0.f;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(slab) + (size_t)role * (CF::SLABF / 2) + e;
+  const size_t gstride = (size_t)CF::ROLES * (CF::SLABF / 2);
   for (int g0 = 0; g0 < npg; g0 += 16) {   // 16 loads in flight, summed in the same fixed order
-    float x[16];
+    uint32_t x[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) x[u] = (g0 + u < npg) ? src[(size_t)(g0 + u) * gstride] : 0.f;
+    for (int u = 0; u < 16; ++u) x[u] = (g0 + u < npg) ? src[(size_t)(g0 + u) * gstride] : 0u;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) a += x[u];
+    for (int u = 0; u < 16; ++u) { a0 += __uint_as_float(x[u] << 16); a1 += __uint_as_float(x[u] & 0xffff0000u); }
   }
-  if (is_b) {
-    if (dbias) dbias[co] = a * s;
-  } else if (dW) {
-    dW[((int64_t)co * CI + ci) * 9 + tap] = a * s;
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int v = 2 * vp + hf;
+    const int m = (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);          // row of the accumulator tile
+    int co = (role * CF::CT + ctl) * 32 + m;
+    if (co >= CO) continue;
+    if (UNSHUF) co = 4 * (co % (CO / 4)) + co / (CO / 4);            // k' = (CO/4) q + c'  ->  conv channel 4 c' + q
+    const float a = hf ? a1 : a0;
+    if (is_b) {
+      if (dbias) dbias[co] = a * s;
+    } else if (dW) {
+      dW[((int64_t)co * CI + ci) * 9 + tap] = a * s;
+    }
   }
 }
 
@@ -275,7 +283,7 @@ int launch_w3(W3Args& p, float s, float* dW, float* dbias, hipStream_t st, const
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), CF::SMEM, st, p);
   if (int rc = rdst_launch_status(what)) return rc;
-  const int tot = CF::ROLES * CF::SLABF;
+  const int tot = CF::ROLES * CF::SLABF / 2;
   hipLaunchKernelGGL((conv3_wgrad_reduce_kernel<CI, CO, UNSHUF>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, p.slab,
                      p.npg, s, dW, dbias);
   return rdst_launch_status("conv3_wgrad_reduce");
