@@ -366,5 +366,9 @@ int wattn_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, i
     const int rc = wattn_fwd_mfma_hd(qkv, ld, table, out, ldo, g, scale, st);
     if (rc != RDST_ENOTSUP) return rc;
   }
+  {  // 16x16 windows
+    const int rc = wattn16_fwd_mfma(qkv, ld, table, out, ldo, g, scale, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   return launch_fwd<bf16>((const bf16*)qkv, ld, table, (bf16*)out, ldo, g, scale, st);
 }

@@ -102,3 +102,43 @@ def test_wattn_bad_args():
         ops.window_attention(qkv, table, 12, 16, 6, 8, 0, 1.0)   # H not a multiple of ws
     with pytest.raises(RuntimeError):
         ops.window_attention(qkv.cpu(), table.cpu(), 16, 16, 6, 8, 0, 1.0)  # CPU tensors: no fallback
+
+
+WS16_CASES = [
+    # B, H, W, C, shift
+    (1, 32, 32, 60, 0),
+    (1, 32, 32, 60, 8),      # 2 x 2 windows, every mask case (last row, last column, corner)
+    (1, 32, 48, 90, 8),      # head dim 15 (12-byte chunks), non-square
+    (2, 48, 32, 120, 8),     # head dim 20
+    (1, 16, 16, 120, 5),     # one window per image: all four regions in it, odd shift
+    (2, 64, 64, 60, 8),      # 32 windows: the XCD-aware block mapping (window count % 8 == 0)
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,shift", WS16_CASES)
+def test_wattn16_bf16(B, H, W, C, shift):
+    """16 x 16 windows on the matrix-core kernels (wattn16_mfma.hip) vs the oracle, forward and backward."""
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    heads, ws = 6, 16
+    scale = (C // heads) ** -0.5
+    qkv = _rand((B, H, W, 3 * C), 11).bfloat16()
+    table = _rand(((2 * ws - 1) ** 2, heads), 12, 0.5)
+    gout = _rand((B, H, W, C), 13).bfloat16()
+
+    q_ref = qkv.float().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout.float())
+
+    q = qkv.to(dev).requires_grad_(True)
+    t = table.to(dev).requires_grad_(True)
+    o = ops.window_attention(q, t, H, W, heads, ws, shift, scale)
+    o.backward(gout.to(dev))
+    torch.cuda.synchronize()
+    assert (o.float().cpu() - o_ref).abs().max().item() <= 2e-2
+    assert (o.float().cpu() - o_ref).norm().item() <= 5e-3 * o_ref.norm().item()
+    assert (q.grad.float().cpu() - q_ref.grad).abs().max().item() <= 6e-2
+    assert (q.grad.float().cpu() - q_ref.grad).norm().item() <= 2e-2 * q_ref.grad.norm().item()
+    rel = (t.grad.cpu() - t_ref.grad).norm().item() / t_ref.grad.norm().item()
+    assert rel <= 2e-2, rel
