@@ -57,6 +57,8 @@ int wattn_fwd_mfma_hd(const void* qkv, int64_t ld, const float* table, void* out
 // 16x16 windows, bf16, 6 heads of dim 10/15/20 (wattn16_mfma.hip); RDST_ENOTSUP otherwise
 int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
                      float scale, hipStream_t st);
+int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
+                     int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
 int wattn_bwd_mfma_hd(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
                       int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
 int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,

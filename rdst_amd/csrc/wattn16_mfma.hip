@@ -309,6 +309,442 @@ int launch_fwd16(const W16Args& p, hipStream_t st) {
   return rdst_launch_status("wattn16_fwd");
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward.  One 8-wave workgroup per (window, head pair), all of Q / K / V / dO of the pair in LDS, two passes:
+//   pass 1 (wave = query tile, the forward's orientation: keys in the accumulator registers): S^T -> P^T (normalised,
+//     128 registers), dP^T = V.dO^T per key tile, delta = rowsum(P.dP), dS^T = P^T.(dP^T - delta) -> dQ^T += K^T.dS^T
+//     and d(table) (LDS float adds into the reversed layout of the bias table); (-scale2.max, 1/l, delta) per query go
+//     to LDS for pass 2; dP^T is formed twice (1-2 MFMAs per tile) instead of being kept (128 more registers);
+//   pass 2 (wave = key tile, queries in the accumulator registers, keys on the lanes): S, P, dP, dS recomputed tile by
+//     tile from the saved row statistics, dV^T += dO^T.P and dK^T += Q^T.dS accumulate in registers over the 8 query
+//     tiles (the tiles ARE the B operands; Q / dO are read transposed).
+// dQ^T tiles stay in registers across pass 2 and overwrite the wave's own (then dead) Q rows, dK / dV its K / V rows;
+// rows leave coalesced.
+// d(table)[dy][dx] = sum of dS over the pairs with (yi - yj, xi - xj) = (dy, dx), deterministic (LDS float atomics measured
+// 180 cycles per wave instruction: 370 thousand cycles per workgroup): in pass 1 a lane row is one query row (fixed yi,
+// xi = lane & 15) and a register one key, so the x-diagonals are lane SHIFTS by a compile-time amount: two DPP adds per
+// element (row_shr / row_shl into a low and a high 16-column accumulator per key row), the two lane halves (keys 4
+// columns apart) merged by one half swap + shifted adds, and the 31-column row sums of (wave, query row, key row) go to
+// a private LDS slot; after a barrier one thread per table entry adds its <= 16 slots in fixed order.
+template <int D>
+struct W16B {
+  using CF = W16<D>;
+  static constexpr int SEC = CF::SEC;
+  static constexpr int OFF_TABR = 4 * SEC + 64;                       // reversed table (pass 1): [head][copy][31][32]
+  static constexpr int OFF_TABN = OFF_TABR + 2 * 2 * CF::TABF * 4;    // natural table (pass 2)
+  static constexpr int OFF_STAT = OFF_TABN + 2 * 2 * CF::TABF * 4;    // [head][nm | inv | delta][256]
+  static constexpr int OFF_PART = OFF_STAT + 2 * 3 * 256 * 4;         // d(table) row sums of one head: [yi 16][yj 16][32]
+  static constexpr size_t SMEM = (size_t)OFF_PART + 16 * 16 * 32 * 4;
+};
+
+struct W16BCtx {
+  W16Ctx sc;                     // pass 1 score context (Qp = own query rows, Kp = key rows, tb = reversed table)
+  lds_cp dOp, Vrow, Ktr;         // pass 1: dO^T pack base, V rows as A operand, K^T transposed reads
+  LDS_AS float* part;            // pass 1: the lane's slot row [yi][.][lane & 15] of the d(table) row sums
+  LDS_AS float* stat;            // statistics base
+  lds_cp QA, dOA, Qtr, dOtr, Kown, Vown, Kst, Vst;   // pass 2
+  const LDS_AS f32x2* tb2;       // pass 2: lane base into the natural table copy of its parity
+  int kt;
+  float scale;
+};
+
+__device__ __forceinline__ Pack16 tr_pack(lds_cp p, int ldt) { return lds_tr_pack(p, p + 8 * ldt); }
+
+// lane i of every 16-lane row reads lane i - N (shr) / i + N (shl) of its row, 0 outside
+template <int N> __device__ __forceinline__ float dpp_row_shr(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xf, 0xf, true));
+}
+template <int N> __device__ __forceinline__ float dpp_row_shl(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float other_half(float x, int h) {   // the value of lane ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(h ? r[0] : r[1]);
+}
+
+template <int D, int HL>
+__device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
+  using CF = W16<D>;
+  constexpr int ldt = CF::LDT;
+  constexpr int c_lo = HL * D, c_hi = c_lo + D;
+  constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
+  constexpr int RL = c_lo & ~3;
+  const int h = c.sc.h;
+  f32x16 X[8];
+  w16_scores<D, HL>(X, c.sc);
+  float m = X[0][0];
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) m = __builtin_fmaxf(m, X[kt][v]);
+  m = half_swap_max(m);
+  const float nm = -c.sc.scale2 * m;
+  float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+      const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(X[kt][v], c.sc.scale2, nm));
+      const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(X[kt][v + 1], c.sc.scale2, nm));
+      l0 += e0;
+      l1 += e1;
+      X[kt][v] = e0;
+      X[kt][v + 1] = e1;
+    }
+  const float inv = __builtin_amdgcn_rcpf(half_swap_sum(l0 + l1));
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) X[kt][v] *= inv;
+
+  Pack16 dob[NT];   // dO^T of the lane's query, the head's channels only
+#pragma unroll
+  for (int t = t_lo; t <= t_hi; ++t) {
+    dob[t - t_lo] = lds_pack(c.dOp + t * 32);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t mA = qmask_bits(t * 16 + 2 * e, c_lo, c_hi), mB = qmask_bits(t * 16 + 8 + 2 * e, c_lo, c_hi);
+      dob[t - t_lo].w[e] &= h ? mB : mA;
+    }
+  }
+  auto dp_tile = [&](int kt, f32x16& dp) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dp[v] = 0.f;
+#pragma unroll
+    for (int t = t_lo; t <= t_hi; ++t) Mma<bf16>::mma(dp, lds_pack(c.Vrow + kt * 32 * ldt + t * 32), dob[t - t_lo]);
+  };
+  float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    f32x16 dp;
+    dp_tile(kt, dp);
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+      d0 = __builtin_fmaf(X[kt][v], dp[v], d0);
+      d1 = __builtin_fmaf(X[kt][v + 1], dp[v + 1], d1);
+    }
+  }
+  const float delta = half_swap_sum(d0 + d1);
+  if (h == 0) {
+    LDS_AS float* st = c.stat + HL * 3 * 256 + c.sc.qt * 32 + c.sc.r;
+    st[0] = nm;
+    st[256] = inv;
+    st[512] = delta;
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) dq[v] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    f32x16 dp;
+    dp_tile(kt, dp);
+    // register v: key (yj = 2 kt + (v >> 3), xj = XL + 4 h) with XL = 8 ((v >> 2) & 1) + (v & 3); column c' = xi - XL + 15
+    // of the key row's sums goes to lane c' of `lo` (c' < 16) / lane c' - 16 of `hi`; true column = c' - 4 h
+    float lo[2] = {0.f, 0.f}, hi[2] = {0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float ds = X[kt][v] * (dp[v] - delta);
+      dp[v] = ds;
+      const int yl = v >> 3;
+      switch (8 * ((v >> 2) & 1) + (v & 3)) {
+#define RDST_W16_DIAG(XL) case XL: lo[yl] += dpp_row_shr<15 - XL>(ds); hi[yl] += dpp_row_shl<XL + 1>(ds); break;
+        RDST_W16_DIAG(0) RDST_W16_DIAG(1) RDST_W16_DIAG(2) RDST_W16_DIAG(3)
+        RDST_W16_DIAG(8) RDST_W16_DIAG(9) RDST_W16_DIAG(10) RDST_W16_DIAG(11)
+#undef RDST_W16_DIAG
+        default: break;
+      }
+    }
+#pragma unroll
+    for (int yl = 0; yl < 2; ++yl) {   // lane half 1 holds the same row sums 4 columns further right: merge into half 0
+      const float l1 = other_half(lo[yl], h), h1 = other_half(hi[yl], h);
+      const float nl = lo[yl] + dpp_row_shl<4>(l1) + dpp_row_shr<12>(h1);
+      const float nh = hi[yl] + dpp_row_shl<4>(h1);
+      if (h == 0) {
+        c.part[(2 * kt + yl) * 32] = nl;
+        c.part[(2 * kt + yl) * 32 + 16] = nh;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Pack16 pb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pb.w[e] = pack_bf16x2(dp[8 * s + 2 * e], dp[8 * s + 2 * e + 1]);
+      Mma<bf16>::mma(dq, tr_pack(c.Ktr + RL * 2 + (kt * 32 + 16 * s) * ldt, ldt), pb);   // rows = channels (K^T), cols = queries
+    }
+  }
+}
+
+// fixed-order sum of the row sums of one head: entry (dy, dx) <- sum over yi - yj = dy - 15 of part[yi][yj][dx]
+template <int D>
+__device__ __forceinline__ void w16_dtable_out(const float* part, float* slab_row, int tid) {
+  for (int idx = tid; idx < 961; idx += 512) {
+    const int ry = idx / 31, rx = idx - ry * 31;
+    float sum = 0.f;
+    for (int yi = 0; yi < 16; ++yi) {
+      const int yj = yi + 15 - ry;
+      if (yj >= 0 && yj < 16) sum += part[(yi * 16 + yj) * 32 + rx];
+    }
+    slab_row[idx] = sum;
+  }
+}
+
+template <int D, int HL>
+__device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
+  using CF = W16<D>;
+  constexpr int ldt = CF::LDT;
+  constexpr int c_lo = HL * D, c_hi = c_lo + D;
+  constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
+  constexpr int RL = c_lo & ~3;
+  const int h = c.sc.h, r = c.sc.r;
+  Pack16 kb[NT], vb[NT];   // K^T / V^T of the lane's key, the head's channels only
+#pragma unroll
+  for (int t = t_lo; t <= t_hi; ++t) {
+    kb[t - t_lo] = lds_pack(c.Kown + t * 32);
+    vb[t - t_lo] = lds_pack(c.Vown + t * 32);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t mA = qmask_bits(t * 16 + 2 * e, c_lo, c_hi), mB = qmask_bits(t * 16 + 8 + 2 * e, c_lo, c_hi);
+      kb[t - t_lo].w[e] &= h ? mB : mA;
+      vb[t - t_lo].w[e] &= h ? mB : mA;
+    }
+  }
+  Pack16 mKc;   // one-hot region of the lane's key, times 100 / scale
+  const int xk = r & 15;
+  const int rxk = (c.sc.mcol && xk >= c.sc.thr) ? 1 : 0;
+  if (c.sc.masked) onehot4(2 * ((c.sc.mrow && 2 * c.kt + (r >> 4) >= c.sc.thr) ? 1 : 0) + rxk, c.sc.cbits, h, mKc);
+  f32x16 dk, dv;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { dk[v] = 0.f; dv[v] = 0.f; }
+  const LDS_AS f32x2* tbh = c.tb2 + HL * CF::TABF;
+  const LDS_AS char* stb = (const LDS_AS char*)(c.stat + HL * 3 * 256) + h * 16;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int qt = 0; qt < 8; ++qt) {
+    // S tile: rows = queries of tile qt (yi = 2 qt + (v >> 3), xi = 8 ((v >> 2) & 1) + 4 h + (v & 3)), cols = the lane's key
+    f32x16 X, dp;
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+      const f32x2 b2 = tbh[((2 * qt + (v >> 3)) * CF::TROW + 8 * ((v >> 2) & 1) + (v & 3)) / 2];
+      X[v] = b2.x;
+      X[v + 1] = b2.y;
+      dp[v] = 0.f;
+      dp[v + 1] = 0.f;
+    }
+#pragma unroll
+    for (int t = t_lo; t <= t_hi; ++t) {
+      Mma<bf16>::mma(X, lds_pack(c.QA + qt * 32 * ldt + t * 32), kb[t - t_lo]);
+      Mma<bf16>::mma(dp, lds_pack(c.dOA + qt * 32 * ldt + t * 32), vb[t - t_lo]);
+    }
+    if (c.sc.masked) {
+      Pack16 mQr;   // rows = queries of tile qt: row r is query (2 qt + (r >> 4), r & 15)
+      onehot4(2 * ((c.sc.mrow && 2 * qt + (r >> 4) >= c.sc.thr) ? 1 : 0) + rxk, 0x3f80u, h, mQr);
+      Mma<bf16>::mma(X, mQr, mKc);
+    }
+    f32x16 P, S;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4v nm = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (qt * 32 + 8 * g4) * 4);
+      const f32x4v iv = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (256 + qt * 32 + 8 * g4) * 4);
+      const f32x4v de = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (512 + qt * 32 + 8 * g4) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int v = 4 * g4 + e;
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(X[v], c.sc.scale2, nm[e])) * iv[e];
+        P[v] = pv;
+        S[v] = pv * (dp[v] - de[e]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Pack16 pp, ps;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pp.w[e] = pack_bf16x2(P[8 * s + 2 * e], P[8 * s + 2 * e + 1]);
+        ps.w[e] = pack_bf16x2(S[8 * s + 2 * e], S[8 * s + 2 * e + 1]);
+      }
+      Mma<bf16>::mma(dv, tr_pack(c.dOtr + RL * 2 + (qt * 32 + 16 * s) * ldt, ldt), pp);   // dV^T += dO^T . P
+      Mma<bf16>::mma(dk, tr_pack(c.Qtr + RL * 2 + (qt * 32 + 16 * s) * ldt, ldt), ps);    // dK^T += Q^T . dS
+    }
+  }
+  store_tile_rows<RL, c_lo, c_hi>(c.Kst, dk, c.scale, h);
+  store_tile_rows<RL, c_lo, c_hi>(c.Vst, dv, 1.0f, h);
+}
+
+template <int D>
+__global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using CF = W16<D>;
+  using BF = W16B<D>;
+  using CH = typename Chunk<CF::GRAN>::type;
+  constexpr int ldt = CF::LDT, GRAN = CF::GRAN, CPS = CF::CPS, CPR = 3 * CPS, RPI = 64 / CPR, NI = 32 / RPI;
+  constexpr int RPD = 64 / CPS, ND = (32 + RPD - 1) / RPD;   // dO: rows per instruction, instructions
+  const WinGeom g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* Qs = smem;
+  char* Ks = Qs + CF::SEC;
+  char* Vs = Ks + CF::SEC;
+  char* dOs = Vs + CF::SEC;
+  float* tabR = reinterpret_cast<float*>(smem + BF::OFF_TABR);
+  float* tabN = reinterpret_cast<float*>(smem + BF::OFF_TABN);
+  float* stat = reinterpret_cast<float*>(smem + BF::OFF_STAT);
+  float* part = reinterpret_cast<float*>(smem + BF::OFF_PART);
+
+  const int nW = g.nWh * g.nWw, nwin = g.B * nW;
+  int win, grp;
+  w16_locate(nwin, win, grp);
+  const int b = win / nW, wi = win - b * nW, wr = wi / g.nWw, wc = wi - wr * g.nWw;
+
+  // ---- this wave's 32 token rows of qkv and dO -> registers
+  const int lr0 = lane / CPR, ch = lane - lr0 * CPR;
+  const bool act = lr0 < RPI;
+  const int lr = act ? lr0 : RPI - 1;
+  const int sec = ch / CPS, cw = ch - sec * CPS;
+  CH regs[NI], dreg[ND];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int t = wv * 32 + i * RPI + lr;
+    const int64_t tok = win_token16(b, wr, wc, t, g);
+    const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld) + sec * (CF::C * 2) + grp * CF::PB + cw * GRAN;
+    regs[i] = *reinterpret_cast<const CH*>(src);
+  }
+  const int dr0 = lane / CPS, dc = lane - dr0 * CPS;
+  const bool dact0 = dr0 < RPD;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    int rr = i * RPD + (dact0 ? dr0 : RPD - 1);
+    rr = rr < 32 ? rr : 31;
+    const int64_t tok = win_token16(b, wr, wc, wv * 32 + rr, g);
+    const char* src = reinterpret_cast<const char*>(p.dout + tok * p.ldd) + grp * CF::PB + dc * GRAN;
+    dreg[i] = *reinterpret_cast<const CH*>(src);
+  }
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float rscale = 1.0f / p.scale;
+  {  // the pair's bias tables / scale: reversed (pass 1) and natural (pass 2), each with a copy shifted by one float
+    constexpr int NSRC = 2 * 961, NLD = (NSRC + 511) / 512;
+    float tv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int j = tid + 512 * k;
+      const int jj = j < NSRC ? j : NSRC - 1;
+      const int hl = jj >= 961 ? 1 : 0, rel = jj - 961 * hl;
+      tv[k] = p.table[rel * CF::HEADS + grp * 2 + hl];
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int j = tid + 512 * k;
+      if (j < NSRC) {
+        const int hl = j >= 961 ? 1 : 0, rel = j - 961 * hl;
+        const int ry = rel / 31, rx = rel - ry * 31;
+        const float v = tv[k] * rscale;
+        const int ir = (30 - ry) * CF::TROW + (30 - rx), in = ry * CF::TROW + rx;
+        float* A = tabR + hl * 2 * CF::TABF;
+        A[ir] = v;
+        if (ir >= 1) A[CF::TABF + ir - 1] = v;
+        float* N = tabN + hl * 2 * CF::TABF;
+        N[in] = v;
+        if (in >= 1) N[CF::TABF + in - 1] = v;
+      }
+    }
+  }
+  if (tid < 16) *reinterpret_cast<uint32_t*>(dOs + CF::SEC + 4 * tid) = 0u;   // guard behind the last dO row
+  if constexpr (ldt > CF::PB) {   // zero the pad bytes of every staged row
+    constexpr int padw = (ldt - CF::PB) / 4;
+    for (int idx = tid; idx < 4 * 256 * padw; idx += 512) {
+      const int row = idx / padw, w = idx - row * padw;
+      *reinterpret_cast<uint32_t*>(Qs + (size_t)row * ldt + CF::PB + 4 * w) = 0u;
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = wv * 32 + i * RPI + lr;
+      chunk_to_lds<CH>(smem + sec * CF::SEC + t * ldt + cw * GRAN, regs[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int rr = i * RPD + dr0;
+    if (dact0 && rr < 32) chunk_to_lds<CH>(dOs + (wv * 32 + rr) * ldt + dc * GRAN, dreg[i]);
+  }
+  __syncthreads();
+
+  W16BCtx c;
+  c.sc.h = h; c.sc.r = r;
+  c.sc.thr = g.ws - g.shift;
+  c.sc.mrow = g.shift > 0 && wr == g.nWh - 1;
+  c.sc.mcol = g.shift > 0 && wc == g.nWw - 1;
+  c.sc.masked = c.sc.mrow || c.sc.mcol;
+  c.sc.cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
+  c.sc.scale2 = p.scale * LOG2E;
+  c.scale = p.scale;
+  c.stat = (LDS_AS float*)stat;
+  const int trofs = (4 * h + ((lane & 15) >> 2)) * ldt + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // transposed-read lane offset
+  const int y0 = 2 * wv + (r >> 4), x0 = r & 15;   // the lane's query (pass 1) / key (pass 2)
+  const int u0 = (15 - y0) * CF::TROW + 15 - x0 + 4 * h;
+  {  // pass 1: wave = query tile wv
+    c.sc.qt = wv;
+    c.sc.Qp = (lds_cp)(Qs + (wv * 32 + r) * ldt + h * 16);
+    c.sc.Kp = (lds_cp)(Ks + r * ldt + h * 16);
+    c.sc.tb = (const LDS_AS f32x2*)((u0 & 1) ? tabR + CF::TABF + (u0 - 1) : tabR + u0);
+    c.dOp = (lds_cp)(dOs + (wv * 32 + r) * ldt + h * 16);
+    c.Vrow = (lds_cp)(Vs + r * ldt + h * 16);
+    c.Ktr = (lds_cp)(Ks + trofs);
+    c.part = (LDS_AS float*)(part + (2 * wv + (r >> 4)) * 16 * 32 + (r & 15));
+  }
+  f32x16 dq0, dq1;
+  float* slab_row = p.slab + ((int64_t)win * CF::HEADS + grp * 2) * 961;
+  w16_bwd_p1<D, 0>(c, dq0);
+  __syncthreads();
+  w16_dtable_out<D>(part, slab_row, tid);
+  __syncthreads();
+  w16_bwd_p1<D, 1>(c, dq1);
+  __syncthreads();
+  w16_dtable_out<D>(part, slab_row + 961, tid);
+  {  // pass 2: wave = key tile wv
+    c.kt = wv;
+    c.QA = (lds_cp)(Qs + r * ldt + h * 16);
+    c.dOA = (lds_cp)(dOs + r * ldt + h * 16);
+    c.Qtr = (lds_cp)(Qs + trofs);
+    c.dOtr = (lds_cp)(dOs + trofs);
+    c.Kown = (lds_cp)(Ks + (wv * 32 + r) * ldt + h * 16);
+    c.Vown = (lds_cp)(Vs + (wv * 32 + r) * ldt + h * 16);
+    c.Kst = (lds_cp)(Ks + (wv * 32 + r) * ldt);
+    c.Vst = (lds_cp)(Vs + (wv * 32 + r) * ldt);
+    c.tb2 = (const LDS_AS f32x2*)((u0 & 1) ? tabN + CF::TABF + (u0 - 1) : tabN + u0);
+    w16_bwd_p2<D, 0>(c);
+    w16_bwd_p2<D, 1>(c);
+  }
+  __syncthreads();   // every wave is done with Q as an operand: the wave's own query rows take dQ
+  {
+    const lds_cp qrow = (lds_cp)(Qs + (wv * 32 + r) * ldt);
+    store_tile_rows<0, 0, D>(qrow, dq0, p.scale, h);
+    store_tile_rows<(D & ~3), D, 2 * D>(qrow, dq1, p.scale, h);
+  }
+  __syncthreads();
+  // dQ | dK | dV (in place of Q / K / V) -> global rows of this wave's 32 tokens
+#pragma unroll 1
+  for (int idx = lane; idx < 32 * CPR; idx += 64) {
+    const int row = idx / CPR, k3 = idx - row * CPR;
+    const int s3 = k3 / CPS, k = k3 - s3 * CPS;
+    const int t = wv * 32 + row;
+    const int64_t tok = win_token16(b, wr, wc, t, g);
+    char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq) + s3 * (CF::C * 2) + grp * CF::PB + k * GRAN;
+    const char* src = smem + s3 * CF::SEC + (size_t)t * ldt + k * GRAN;
+    *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(src);
+  }
+}
+
+template <int D>
+int launch_bwd16(const W16Args& p, hipStream_t st) {
+  auto kern = wattn16_bwd_kernel<D>;
+  constexpr size_t smem = W16B<D>::SMEM;
+  static_assert(smem <= 160 * 1024, "LDS");
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int64_t nwin = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(3 * nwin)), dim3(512), smem, st, p);
+  return rdst_launch_status("wattn16_bwd");
+}
+
 bool al(const void* a, int64_t lda_bytes, int gsz) { return (uintptr_t)a % gsz == 0 && lda_bytes % gsz == 0; }
 
 }  // namespace
@@ -324,5 +760,24 @@ int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out,
   if (d == 10 && al(qkv, ld * 2, 8) && al(out, ldo * 2, 8)) return launch_fwd16<10>(p, st);
   if (d == 15 && al(qkv, ld * 2, 4) && al(out, ldo * 2, 4)) return launch_fwd16<15>(p, st);
   if (d == 20 && al(qkv, ld * 2, 16) && al(out, ldo * 2, 16)) return launch_fwd16<20>(p, st);
+  return RDST_ENOTSUP;
+}
+
+// slab: [windows][6][961] partial d(table), one row per window (*nslab = windows)
+int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
+                     int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st) {
+  if (g.ws != 16 || g.heads != 6 || g.mask || !(scale > 0.f) || g.C % 6) return RDST_ENOTSUP;
+  const int64_t nwin = (int64_t)g.B * g.nWh * g.nWw;
+  if (nwin * 3 > 0x7fffffff || slab_rows < nwin) return RDST_ENOTSUP;
+  W16Args p{};
+  p.qkv = (const bf16*)qkv; p.ld = ld; p.table = table; p.dout = (const bf16*)dout; p.ldd = ldd;
+  p.dqkv = (bf16*)dqkv; p.ldq = ldq; p.slab = slab; p.g = g; p.scale = scale;
+  *nslab = (int)nwin;
+  const int d = g.C / 6;
+  const int a = d == 10 ? 8 : d == 15 ? 4 : 16;
+  if (!(al(qkv, ld * 2, a) && al(dout, ldd * 2, a) && al(dqkv, ldq * 2, a))) return RDST_ENOTSUP;
+  if (d == 10) return launch_bwd16<10>(p, st);
+  if (d == 15) return launch_bwd16<15>(p, st);
+  if (d == 20) return launch_bwd16<20>(p, st);
   return RDST_ENOTSUP;
 }

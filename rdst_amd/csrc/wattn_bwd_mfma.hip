@@ -473,6 +473,10 @@ int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* 
     const int rc = wattn_bwd_mfma_hd(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
     if (rc != RDST_ENOTSUP) return rc;
   }
+  {  // 16x16 windows
+    const int rc = wattn16_bwd_mfma(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
   return launch_bwd<bf16>((const bf16*)qkv, ld, table, (const bf16*)dout, ldd, (bf16*)dqkv, ldq, slab, slab_rows, g, scale,
                           nslab, st);
 }
