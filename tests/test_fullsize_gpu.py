@@ -72,6 +72,43 @@ def test_wattn_bf16_2048_windows_vs_oracle(C, shift):
     assert per_win.max().item() <= 2 * TOL
 
 
+@pytest.mark.parametrize("C,shift", [(60, 8), (90, 0), (120, 8)])
+def test_wattn16_bf16_bench_size_vs_oracle(C, shift):
+    """Window 16 at the size of `bench.py --config ws16` (8 x 128 x 128 tokens = 512 windows = 1536 workgroups of
+    wattn16_mfma.hip), per-window error bounds so that a misplaced window / head pair cannot hide in the norm."""
+    from rdst_amd import ops
+    heads, ws, B, HW16 = 6, 16, 8, 128
+    scale = (C // heads) ** -0.5
+    qkv = _bf(rand((B, HW16, HW16, 3 * C), 300 + C))
+    table = rand(((2 * ws - 1) ** 2, heads), 2, 0.5)
+    gout = _bf(rand((B, HW16, HW16, C), 3))
+
+    q_ref = qkv.clone().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout)
+
+    q = qkv.to(DEV).bfloat16().requires_grad_(True)
+    t = table.to(DEV).requires_grad_(True)
+    o = ops.window_attention(q, t, HW16, HW16, heads, ws, shift, scale)
+    o.backward(gout.to(DEV).bfloat16())
+    torch.cuda.synchronize()
+    ro, rq, rt = _rel(o, o_ref.detach()), _rel(q.grad, q_ref.grad), _rel(t.grad, t_ref.grad)
+    print(f"\nwattn16 bf16 C={C} shift={shift}: rel L2 out {ro:.2e}  dqkv {rq:.2e}  dtable {rt:.2e}")
+    assert ro <= TOL and rq <= TOL and rt <= TOL
+    nw = HW16 // ws
+    for got, want, width in ((o, o_ref.detach(), C), (q.grad, q_ref.grad, 3 * C)):
+        d = (got.float().cpu() - want).view(B, nw, ws, nw, ws, width)
+        per_win = d.pow(2).sum(dim=(2, 4, 5)).sqrt() / want.view(B, nw, ws, nw, ws, width).pow(2).sum(dim=(2, 4, 5)).sqrt()
+        assert per_win.max().item() <= 2 * TOL
+    # run-to-run determinism of the d(table) sums (no atomics in the kernel)
+    q2 = qkv.to(DEV).bfloat16().requires_grad_(True)
+    t2 = table.to(DEV).requires_grad_(True)
+    ops.window_attention(q2, t2, HW16, HW16, heads, ws, shift, scale).backward(gout.to(DEV).bfloat16())
+    torch.cuda.synchronize()
+    assert torch.equal(t.grad, t2.grad) and torch.equal(q.grad, q2.grad)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # K7 (mlp_mfma.hip): 4096 tiles, resident dW accumulators
 # ------------------------------------------------------------------------------------------------------------------
