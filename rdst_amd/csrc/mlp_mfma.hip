@@ -1345,6 +1345,25 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
 
 int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float* dW, float* dbias, hipStream_t st);
 
+int lnlin3_bwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* stats, const float* Wt, const bf16* dY,
+                    int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc, float* slab, int64_t slab_stride,
+                    int64_t M, int K, int N, int64_t max_wgs, int* grid_out, hipStream_t st);
+
+// fixed-order sums of the per-workgroup bf16 G4 slabs (+ the LayerNorm finish) of the one-pass Linear backward kernels
+static int lnlin_bwd_reduce(float* slab, int grid, int64_t slab_stride, bool ln, const float* Wt, const float* ln_w,
+                            const float* ln_b, float* dW, float* dbias, float* dln_w, float* dln_b, float* G, int N, int K,
+                            hipStream_t st) {
+  rbatch::SumJob sj{};
+  sj.slab = slab; sj.nwg = grid; sj.stride = slab_stride; sj.g4 = 1; sj.a2 = N; sj.b2 = K + 1; sj.tot = ((N + 3) / 4) * (K + 1);
+  if (!ln) {
+    sj.map = rbatch::MAP_LINEAR; sj.out = dW; sj.out2 = dbias; sj.a = K; sj.b = K + 1; sj.s = 1.0f;
+    return rbatch::sum(sj, st);
+  }
+  sj.map = rbatch::MAP_COPY; sj.out = G;
+  if (int rc = rbatch::sum(sj, st)) return rc;
+  return wgrad_ln_finish_launch(G, Wt, ln_w, ln_b, N, K, 1.0f, dW, dbias, dln_w, dln_b, st);
+}
+
 // Linear backward in one pass over (x, dY), with (ln_w != NULL) or without a LayerNorm in front: bf16, K+1 <= 128,
 // N <= 384, out_scale 1, no input activation; RDST_ENOTSUP otherwise
 int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
@@ -1370,6 +1389,14 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
       (lddx & 1) || (ldacc & 1))
     return RDST_ENOTSUP;
   if ((uint64_t)M * (uint64_t)(lddy > ldx ? (lddy > ldacc ? lddy : ldacc) : (ldx > ldacc ? ldx : ldacc)) * 2 >= (1ull << 31)) return RDST_ENOTSUP;   // 32-bit byte offsets in the loader
+  const int64_t slab_stride = (int64_t)((N + 3) / 4) * (K + 1);   // bf16 G4 slab: 8-byte groups
+  {  // the re-cut kernel for the E1 shapes (lnlin3_mfma.hip)
+    int g3 = 0;
+    const int rc3 = lnlin3_bwd_bf16(X, ldx, ln_w, stats, Wt, dY, lddy, dX, lddx, acc, ldacc, slab, slab_stride, M, K, N,
+                                    linear_wgrad_max_wgs(N), &g3, st);
+    if (rc3 == 0) return lnlin_bwd_reduce(slab, g3, slab_stride, ln, Wt, ln_w, ln_b, dW, dbias, dln_w, dln_b, G, N, K, st);
+    if (rc3 != RDST_ENOTSUP) return rc3;
+  }
   const int CP = 32 * nct, LDW = nct == 4 ? 288 : CP * 2 + 16, LDX = nct == 4 ? 336 : CP * 2 + 16, NP = 32 * NW, LDY = lnlin_ldy(NP);
   const int smem = NP * LDW + 2 * 32 * LDX + 32 * LDY + 128 + nct * 32 * 8;
   if (smem > 160 * 1024) return RDST_ENOTSUP;
@@ -1422,13 +1449,5 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
     free(hst);
   }
   if (int rc = rdst_launch_status("lnlin_bwd")) return rc;
-  rbatch::SumJob sj{};
-  sj.slab = slab; sj.nwg = (int)grid; sj.stride = p.slab_stride; sj.g4 = 1; sj.a2 = N; sj.b2 = K + 1; sj.tot = ((N + 3) / 4) * (K + 1);
-  if (!ln) {
-    sj.map = rbatch::MAP_LINEAR; sj.out = dW; sj.out2 = dbias; sj.a = K; sj.b = K + 1; sj.s = 1.0f;
-    return rbatch::sum(sj, st);
-  }
-  sj.map = rbatch::MAP_COPY; sj.out = G;
-  if (int rc = rbatch::sum(sj, st)) return rc;
-  return wgrad_ln_finish_launch(G, Wt, ln_w, ln_b, N, K, 1.0f, dW, dbias, dln_w, dln_b, st);
+  return lnlin_bwd_reduce(slab, (int)grid, p.slab_stride, ln, Wt, ln_w, ln_b, dW, dbias, dln_w, dln_b, G, N, K, st);
 }
