@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Collect hardware counters for the kernels of ONE training step of bench.py and write profiles/pmc_latest.json.
 
-Run on the GPU box (through gpurun), from the repo root:   python3 tools/pmc_collect.py [tag]
+Run on the GPU box (through gpurun), from the repo root:   python3 tools/pmc_collect.py [tag [config]]
 
 Method (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): one rocprofv3 run PER counter set, `--kernel-trace --pmc`
 only (no other trace domain), the program itself behind `--`:
@@ -37,7 +37,13 @@ KERNELS = {
     "mlp_fwd_kernel": ("mlp_fwd_kernel", ["mlp_mfma.hip"]),
     "mlp_bwd_kernel": ("mlp_bwd_kernel", ["mlp_mfma.hip"]),
     "lnlin_bwd_kernel": ("lnlin_bwd_kernel", ["mlp_mfma.hip"]),
+    "lnlin3_bwd_kernel": ("lnlin3_bwd_kernel", ["lnlin3_mfma.hip"]),
+    "lin3_kernel": ("lin3_kernel", ["lin3_mfma.hip"]),
+    "mlp3_fwd_kernel": ("mlp3_fwd_kernel", ["mlp3_mfma.hip"]),
+    "wattn16_fwd_kernel": ("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
+    "wattn16_bwd_kernel": ("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
 }
+CONFIG = sys.argv[2] if len(sys.argv) > 2 else "e1"   # bench.py --config (ws16: the window-16 kernels)
 
 
 def source_hash(files):
@@ -53,7 +59,7 @@ def run_pass(counters, outdir):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", outdir, "-o", "p", "--",
            "python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--graph", "0", "--no-roofline",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--config", CONFIG]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0:
         print(r.stderr[-2000:], file=sys.stderr)
