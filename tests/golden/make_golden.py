@@ -105,8 +105,13 @@ def check_layout(net, cfg, name):
     print(f"[{name}] layout ok: {len(ref_layout)} entries, {n_params} params ({n_train} trainable)")
 
 
-def run_net_case(rv, name, cfg, x, seed, mean=None, std=None, train=True, grad_keys=()):
-    """Full-network case: reference fwd (+bwd of L1 vs seeded target)."""
+ONLY = None   # `python make_golden.py --only NAME [NAME ...]`: regenerate just these fixtures
+
+
+def run_net_case(rv, name, cfg, x, seed, mean=None, std=None, train=True, grad_keys=(), adam_keys=None):
+    """Full-network case: reference fwd (+bwd of L1 vs seeded target).  grad_keys = "all": every gradient elementwise."""
+    if ONLY is not None and name not in ONLY:
+        return
     net = build_ref(rv, cfg, mean, std)
     check_layout(net, cfg, name)
     sd = O.make_weights(cfg, seed, mean, std)
@@ -149,6 +154,8 @@ def run_net_case(rv, name, cfg, x, seed, mean=None, std=None, train=True, grad_k
         out["grad_keys"] = np.array(keys)
         out["grad_l2"] = np.array([grads[k].double().norm().item() for k in keys])
         out["grad_sum"] = np.array([grads[k].double().sum().item() for k in keys])
+        if grad_keys == "all":
+            grad_keys = keys
         for k in grad_keys:
             out["grad::" + k] = grads[k].numpy()
         # parameters after ONE Adam step with the ini's hyper-parameters
@@ -156,7 +163,7 @@ def run_net_case(rv, name, cfg, x, seed, mean=None, std=None, train=True, grad_k
         opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4,
                                betas=(0.9, 0.99), eps=1e-8, weight_decay=0)
         opt.step()
-        for k in grad_keys:
+        for k in (grad_keys if adam_keys is None else adam_keys):
             out["adam1::" + k] = dict(net.named_parameters())[k].detach().numpy()
     else:
         net.eval()
@@ -172,6 +179,8 @@ def run_net_case(rv, name, cfg, x, seed, mean=None, std=None, train=True, grad_k
 
 def run_block_case(st, name, C, heads, ws, shift, res, x_size, B, seed):
     """One reference SwinTransformerBlock fwd+bwd (pins norm1/qkv/attention/proj/mlp)."""
+    if ONLY is not None and name not in ONLY:
+        return
     blk = st.SwinTransformerBlock(dim=C, input_resolution=res, num_heads=heads, window_size=ws,
                                   shift_size=shift, mlp_ratio=2.0)
     rng_sd = {}
@@ -215,6 +224,8 @@ def run_block_case(st, name, C, heads, ws, shift, res, x_size, B, seed):
 
 def run_model_case(rv, st, name):
     """'Next'-row models (SwinIR baseline, RDSTSR_N): fixtures straight from the reference module."""
+    if ONLY is not None and name not in ONLY:
+        return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import MODEL_CASES, seeded_fill
     kind, kw, xshape, seed, train = MODEL_CASES[name]
@@ -244,6 +255,9 @@ def run_model_case(rv, st, name):
 
 
 def main():
+    global ONLY
+    if "--only" in sys.argv:
+        ONLY = set(sys.argv[sys.argv.index("--only") + 1:])
     torch.manual_seed(0)
     torch.set_num_threads(8)
     rv, st = _import_reference()
@@ -261,6 +275,8 @@ def main():
                "body.1.body.2.body.blocks.0.attn.qkv.weight", "body.0.conv.weight", "tail.1.weight",
                "body.1.body.1.tail.1.weight", "norm.weight"]
     run_net_case(rv, "net_tiny_64", O.CFG_TINY, seeded((1, 1, 64, 64), 101), 1, grad_keys=gk_tiny)
+    # BASELINE.json configs[0] at its stated shape (4 x 1 x 64 x 64), EVERY gradient elementwise
+    run_net_case(rv, "net_tiny_b4", O.CFG_TINY, seeded((4, 1, 64, 64), 106), 1, grad_keys="all", adam_keys=gk_tiny)
     gk_e1 = ["head.weight", "body.7.body.2.body.blocks.1.attn.relative_position_bias_table",
              "body.3.body.1.body.blocks.0.mlp.fc1.weight", "body.0.conv.bias", "tail.0.2.weight"]
     run_net_case(rv, "net_e1_16", O.CFG_E1, seeded((1, 1, 16, 16), 102), 2, grad_keys=gk_e1)

@@ -39,7 +39,7 @@ def test_swin_block_vs_reference_fixture(name):
         assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 2e-4 * max(np.linalg.norm(ref), 1e-12), k
 
 
-@pytest.mark.parametrize("name", ["net_tiny_64", "net_e1_16", "net_ws16_32", "net_3conv_x3"])
+@pytest.mark.parametrize("name", ["net_tiny_64", "net_tiny_b4", "net_e1_16", "net_ws16_32", "net_3conv_x3"])
 def test_network_train_step_vs_reference_fixture(name):
     cfg, seed = NET_CASES[name]
     g = load_golden(name)

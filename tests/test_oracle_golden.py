@@ -28,7 +28,7 @@ def test_block_fixture(name):
             assert np.linalg.norm(got - v) <= 1e-4 * max(np.linalg.norm(v), 1e-12), k
 
 
-@pytest.mark.parametrize("name", ["net_tiny_64", "net_e1_16", "net_ws16_32", "net_3conv_x3"])
+@pytest.mark.parametrize("name", ["net_tiny_64", "net_tiny_b4", "net_e1_16", "net_ws16_32", "net_3conv_x3"])
 def test_net_fixture_train(name):
     cfg, seed = NET_CASES[name]
     g = load_golden(name)
@@ -46,6 +46,10 @@ def test_net_fixture_train(name):
     assert abs(O.psnr(tgt, y, border=cfg["sr_scale"]) - float(g["psnr"])) <= 5e-5   # PSNR gate, SURVEY.md §8d
     for k, l2 in zip(keys, g["grad_l2"]):
         assert abs(sd[k].grad.double().norm().item() - l2) <= 2e-4 * max(l2, 1e-9), k
+    for k, ref in g.items():      # the gradients the fixture holds elementwise (net_tiny_b4: all of them)
+        if k.startswith("grad::"):
+            got = sd[k[6:]].grad.numpy()
+            assert np.linalg.norm(got - ref) <= 2e-4 * max(np.linalg.norm(ref), 1e-12), k
 
 
 def test_net_fixture_eval_nonsquare():

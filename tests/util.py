@@ -10,6 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 NET_CASES = {
     "net_tiny_64": (O.CFG_TINY, 1),
+    "net_tiny_b4": (O.CFG_TINY, 1),      # BASELINE.json configs[0] at its stated shape 4 x 1 x 64 x 64, all gradients elementwise
     "net_e1_16": (O.CFG_E1, 2),
     "net_e1_eval_40x32": (O.CFG_E1, 2),
     "net_ws16_32": (O.make_cfg(**{**O.CFG_WS16, "img_size": 32, "dense_layer_depths": [2, 2], "num_heads": [6, 6],
