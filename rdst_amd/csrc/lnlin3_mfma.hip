@@ -55,6 +55,8 @@ struct LB3 {
   static constexpr int W_SY = cdiv(NY, NTW), W_SX = cdiv(NX, NTW), W_SA = (WIDE && !ACC_BY_W) ? 0 : cdiv(NX, NTW);
   static constexpr int D_SY = WIDE ? 0 : W_SY, D_SX = WIDE ? 0 : W_SX, D_SA = ACC_BY_W ? 0 : cdiv(NX, NTD);
   static constexpr int CP = 32 * NCT;
+  // (strides of 64 / 192 (mod 256) bytes — the four rows of a transposed read on disjoint bank quarters — were measured:
+  // qkv / proj unchanged within noise, the tails 1-3 us slower (the 8-byte slice reads of the epilogue collide): not the limit)
   static constexpr int LDX = NCT == 4 ? 336 : CP * 2 + 16;
   static constexpr int LDY = lb3_ldy(32 * NW);
   static constexpr int OFF_AC = 32 * LDX, OFF_DY = 64 * LDX, OFF_SM = OFF_DY + 32 * LDY, BUF = OFF_SM + 128;
