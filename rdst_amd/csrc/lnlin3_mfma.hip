@@ -62,9 +62,11 @@ struct LB3 {
   static constexpr int OFF_AC = 32 * LDX, OFF_DY = 64 * LDX, OFF_SM = OFF_DY + 32 * LDY, BUF = OFF_SM + 128;
   static constexpr int OFF_RED = 2 * BUF;
   static constexpr int SMEM = OFF_RED + 2 * NCT * 256;
+  // workgroups per CU: at most 2 (measured: up to 4 for the 3-5-wave shapes changes the tails by -1.0 / +2.3 / 0 us and
+  // proj 60 by +1.2 us — more slabs and prologues, no more bandwidth)
   static constexpr int PERCU0 = 12 / NWV < 1 ? 1 : 12 / NWV;
   static constexpr int PERCU1 = PERCU0 > 2 ? 2 : PERCU0;
-  static constexpr int PERCU = PERCU1 * SMEM > 160 * 1024 ? 1 : PERCU1;   // workgroups per CU
+  static constexpr int PERCU = PERCU1 * SMEM > 160 * 1024 ? 1 : PERCU1;
   static constexpr int WPS = (NWV * PERCU + 3) / 4;                          // waves per SIMD (the launch bound)
 };
 
