@@ -568,6 +568,16 @@ class _SwinBlock(torch.autograd.Function):
                                   _ptr(fc1b), fc2w.data_ptr(), dy_r.data_ptr(), lddy, dx1.data_ptr(), C,
                                   o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
                                   o[5].data_ptr(), wsp_m.data_ptr(), nb, M, C, hid, code, _stream())
+            if rc == _lib.ENOTSUP and h is None:
+                # The forward ran fused (h was never written), so there is no composed path to fall back to; what the
+                # kernel can refuse at this point is the ALIGNMENT of dy (a strided gradient slice with an odd channel
+                # offset): hand it an aligned contiguous copy (ld = C) — same kernel, same result.
+                dy_c = dy_r.clone(memory_format=torch.contiguous_format)
+                keep.append(dy_c)
+                rc = lib.rdst_mlp_bwd(x1.data_ptr(), C, n2w.data_ptr(), n2b.data_ptr(), stats2.data_ptr(), fc1w.data_ptr(),
+                                      _ptr(fc1b), fc2w.data_ptr(), dy_c.data_ptr(), C, dx1.data_ptr(), C,
+                                      o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(), o[4].data_ptr(),
+                                      o[5].data_ptr(), wsp_m.data_ptr(), nb, M, C, hid, code, _stream())
             if rc == _lib.ENOTSUP and h is not None:
                 fused_mlp = False
             else:

@@ -135,3 +135,43 @@ def test_mlp_unsupported_shapes_say_so():
     assert lib.rdst_mlp_fused_supported(126, 254, _lib.BF16) == 0   # the forward's weight images exceed the LDS
     assert lib.rdst_mlp_fused_supported(60, 200, _lib.BF16) == 0    # hidden width beyond the wave count
     assert lib.rdst_mlp_fused_supported(61, 120, _lib.BF16) == 0    # odd rows are not dword aligned
+
+
+def test_swin_block_backward_with_misaligned_gradient():
+    """the fused Mlp backward refuses a dy whose rows are not dword aligned (a strided gradient slice with an
+    odd channel offset); with the forward fused there is no composed fallback, so the block retries on an aligned copy."""
+    from rdst_amd import ops
+    C, hid, H, W, heads, ws = 60, 120, 16, 16, 6, 8
+    torch.manual_seed(1)
+    x = torch.randn(2, H * W, C, device=DEV).bfloat16()
+    prm = [1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C), torch.randn(3 * C, C) * C ** -0.5, 0.1 * torch.randn(3 * C),
+           0.02 * torch.randn((2 * ws - 1) ** 2, heads), torch.randn(C, C) * C ** -0.5, 0.1 * torch.randn(C),
+           1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C), torch.randn(hid, C) * C ** -0.5, 0.1 * torch.randn(hid),
+           torch.randn(C, hid) * hid ** -0.5, 0.1 * torch.randn(C)]
+    from rdst_amd import _lib
+    lib = _lib.load()
+    real, codes = lib.rdst_mlp_bwd, []
+
+    def spy(*args):
+        codes.append(real(*args))
+        return codes[-1]
+
+    wide = torch.randn(2, H * W, C + 3, device=DEV).bfloat16()
+    res, seen = [], []
+    lib.rdst_mlp_bwd = spy
+    try:
+        for gy in (wide[..., 1:C + 1], wide[..., 1:C + 1].contiguous()):   # rows 2-byte aligned only / compact copy
+            del codes[:]
+            xs = x.clone().requires_grad_(True)
+            ps = [t.to(DEV).requires_grad_(True) for t in prm]
+            y = ops.swin_block(xs, *ps, H, W, heads, ws, 0, (C // heads) ** -0.5)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append([xs.grad.float()] + [t.grad.float() for t in ps])
+            seen.append(list(codes))
+    finally:
+        lib.rdst_mlp_bwd = real
+    assert seen[0] == [_lib.ENOTSUP, 0], seen   # refused once, accepted on the aligned copy: the retry path really ran
+    assert seen[1] == [0], seen
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
