@@ -209,6 +209,15 @@ int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int B, int C, i
 int rdst_rows_to_nchw(const void* rows, int64_t ld, float* nchw, int B, int C, int H, int W,
                       int dtype, void* stream);
 
+/* ---- nearest-neighbour x2 upsampling of token-major rows (SwinIR 'nearest+conv' reconstruction) --------
+ * y (B, 2H, 2W, C) = torch.nn.functional.interpolate(x, scale_factor=2, mode='nearest') of x (B, H, W, C) rows
+ * (networks/swin_transformer_sr.py:801-802); backward: dx[b, i, j] = sum of the four dy[b, 2i+{0,1}, 2j+{0,1}]
+ * (fixed order).  ld_* in elements; dtype RDST_F32 / RDST_BF16. */
+int rdst_upsample2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, int dtype,
+                       void* stream);
+int rdst_upsample2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int B, int H, int W, int C, int dtype,
+                       void* stream);
+
 /* ---- fused Adam over flat buffers ------------------------------------------------
  * One launch updates all `n` fp32 parameters in place with torch.optim.Adam's rule (amsgrad off),
  * the optimizer utils/optim.py:30-53 builds and models/trans_sr_trainer.py:170-173 steps:

@@ -47,6 +47,8 @@ SIGNATURES = {
     "rdst_reduce_batch_end": (_i, [_p]),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
+    "rdst_upsample2_fwd": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "rdst_upsample2_bwd": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_stem_loss_workspace": (_z, [_i, _i, _i]),
     "rdst_stem_loss_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
     "rdst_stem_loss_bwd": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),

@@ -742,6 +742,36 @@ class _RowsToNchw(torch.autograd.Function):
         return _NchwToRows.apply(dout, ctx.dtype)
 
 
+class _Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows):
+        _need_gpu(rows)
+        lib = _lib.load()
+        B, H, W, C = rows.shape
+        r, ld = _rows(rows)
+        out = torch.empty((B, 2 * H, 2 * W, C), dtype=rows.dtype, device=rows.device)
+        _lib.check(lib.rdst_upsample2_fwd(r.data_ptr(), ld, out.data_ptr(), C, B, H, W, C, _dtype_code(rows), _stream()),
+                   "rdst_upsample2_fwd")
+        ctx.geom = (B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, H, W, C = ctx.geom
+        d, ld = _rows(dy)
+        dx = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+        _lib.check(lib.rdst_upsample2_bwd(d.data_ptr(), ld, dx.data_ptr(), C, B, H, W, C, _dtype_code(dy), _stream()),
+                   "rdst_upsample2_bwd")
+        return dx
+
+
+def upsample_nearest2(rows: torch.Tensor) -> torch.Tensor:
+    """token-major rows (B,H,W,C) -> (B,2H,2W,C): F.interpolate(scale_factor=2, mode='nearest') of the reference's
+    'nearest+conv' reconstruction (networks/swin_transformer_sr.py:801-802)."""
+    return _Upsample2.apply(rows)
+
+
 def nchw_to_rows(x: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """fp32 NCHW image -> token-major rows (B,H,W,C) of `dtype` (PatchEmbed's flatten+transpose,
     networks/swin_transformer_sr.py:515-516, done once at the module boundary)."""

@@ -296,7 +296,7 @@ def main():
     run_net_case(rv, "net_3conv_x3", cfg3, seeded((2, 1, 16, 16), 105), 4,
                  grad_keys=["body.0.conv.0.weight", "body.0.body.0.tail.0.weight"])
     # --- "next" rows: SwinIR baseline and the RDSTSR_N bottleneck variant ----------------------------
-    for name in ("swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "rdstsr_n_mlp", "rdstsr_n_conv"):
+    for name in ("swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "swinir_nearest_x4", "rdstsr_n_mlp", "rdstsr_n_conv"):
         run_model_case(rv, st, name)
 
 

@@ -53,8 +53,14 @@ def test_init_matches_reference_rules():
     net = build_net(O.CFG_TINY)
     for m in net.modules():
         if isinstance(m, nn.Linear):
-            # trunc_normal_(std=.02) with timm's absolute cut at +-2 (rdst_variations.py:1311) ~ N(0, .02)
-            assert 0.015 < m.weight.std().item() < 0.025 and torch.all(m.bias == 0)
+            # trunc_normal_(std=.02) with timm's absolute cut at +-2 (rdst_variations.py:1311) ~ N(0, .02).  timm's
+            # recipe (uniform_(-1, 1) -> erfinv -> clamp) maps the closed lower end of the uniform to -inf and the clamp
+            # turns it into a weight of exactly -2: about one construction in 150 holds such an element (measured), and
+            # ONE of them lifts the std of a 72 x 144 matrix from 0.020 to 0.028 — so the spread is checked on the bulk.
+            w = m.weight.detach()
+            assert w.abs().max().item() <= 2.0
+            bulk = w[w.abs() < 0.5]
+            assert bulk.numel() >= w.numel() - 2 and 0.015 < bulk.std().item() < 0.025 and torch.all(m.bias == 0)
         if isinstance(m, nn.LayerNorm):
             assert torch.all(m.weight == 1) and torch.all(m.bias == 0)
     assert all(not p.requires_grad for p in list(net.sub_mean.parameters()) + list(net.add_mean.parameters()))
@@ -109,7 +115,7 @@ def test_package_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dp, fn)
 
 
-@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "rdstsr_n_mlp", "rdstsr_n_conv"])
+@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "swinir_nearest_x4", "rdstsr_n_mlp", "rdstsr_n_conv"])
 def test_next_row_models_state_dict_layout(name):
     """SwinIR baseline and RDSTSR_N ("next" rows): same state-dict keys / order / shapes / dtypes as the reference."""
     from util import MODEL_CASES

@@ -141,7 +141,7 @@ def test_standalone_window_attention_with_explicit_mask():
     assert (got.cpu() - ref).abs().max().item() <= 5e-5
 
 
-@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "rdstsr_n_mlp", "rdstsr_n_conv"])
+@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "swinir_nearest_x4", "rdstsr_n_mlp", "rdstsr_n_conv"])
 def test_next_row_models_vs_reference_fixture(name):
     """SwinIR baseline / RDSTSR_N on the HIP primitives vs outputs, loss and gradient norms of the reference."""
     from util import MODEL_CASES, seeded_fill

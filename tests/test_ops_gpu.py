@@ -201,3 +201,31 @@ def test_ln_linear_bwd_dx_add(M, K, N, ln, dtype):
     assert rel(dW, pr[2].grad) <= tol and rel(db, pr[3].grad) <= tol
     if ln:
         assert rel(dlw, pr[0].grad) <= tol and rel(dlb, pr[1].grad) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 5, 7, 48), (1, 16, 16, 64), (3, 4, 6, 61)])
+def test_upsample_nearest2_vs_torch(B, H, W, C, dtype):
+    """rdst_upsample2_fwd / _bwd (csrc/upsample.hip) vs F.interpolate(scale_factor=2, mode='nearest') and its autograd
+    (swin_transformer_sr.py:801-802): the forward is a copy (bit-exact), the backward a 4-term sum (fp32: exact to rounding
+    order, bf16: one rounding of the fp32 sum)."""
+    from rdst_amd import ops
+    x = rand((B, H, W, C), 31).to(dtype)
+    gy = rand((B, 2 * H, 2 * W, C), 32).to(dtype)
+    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.upsample_nearest2(xg)
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(y.detach().float().cpu(), yr.detach().permute(0, 2, 3, 1))
+    want = xr.grad.permute(0, 2, 3, 1)
+    if dtype == torch.float32:
+        assert (xg.grad.cpu() - want).abs().max().item() <= 1e-6
+    else:
+        assert torch.equal(xg.grad.cpu(), want.bfloat16())
+    # a strided source (rows inside a wider buffer) gives the same result
+    wide = torch.zeros(B, H, W, C + 8, dtype=dtype, device=DEV)
+    wide[..., 4:4 + C] = x.to(DEV)
+    assert torch.equal(ops.upsample_nearest2(wide[..., 4:4 + C]), y.detach())

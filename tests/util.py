@@ -86,6 +86,9 @@ MODEL_CASES = {
     "swinir_denoise": ("swinir", dict(img_size=16, in_chans=1, embed_dim=48, depths=[2], num_heads=[6], window_size=8,
                                       mlp_ratio=2., upscale=1, img_range=1., upsampler="", drop_path_rate=0.),
                        (1, 1, 16, 16), 23, True),
+    "swinir_nearest_x4": ("swinir", dict(img_size=16, in_chans=3, embed_dim=48, depths=[2], num_heads=[6], window_size=8,
+                                         mlp_ratio=2., upscale=4, img_range=1., upsampler="nearest+conv", drop_path_rate=0.),
+                          (1, 3, 16, 16), 26, True),
     "rdstsr_n_mlp": ("rdstsr_n", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2, 2],
                                       num_heads=[6, 6], window_size=[8, 8], rdb_depths=[2, 2], mlp_ratio=2.,
                                       growth_rate=24, pre_norm=True, global_bottleneck=True, global_bottleneck_ratio=1.,
