@@ -303,3 +303,57 @@ def test_e1_bf16_train_step_all_gradients_vs_oracle():
     assert dpsnr < 0.05 and abs(loss.item() - oloss.item()) <= 2e-3
     assert total <= 2e-2
     assert not bad, bad[:10]
+
+
+def test_ws16_bf16_train_step_all_gradients_vs_oracle():
+    """BASELINE configs[3] (3-channel x2, 128x128 -> 256x256, window 16, the E1 widths) in the bf16 mode: every trainable
+    tensor's gradient against the fp32 oracle, batch 2 (128 windows per layer: wattn16_mfma.hip forward and backward in all
+    48 Swin blocks, shifted and not, with the region masks of the last window row / column).  Same stated tolerances as the
+    E1 test: rel L2 <= 5e-2 per tensor, total <= 2e-2, |dPSNR| < 0.05 dB."""
+    from util import build_net
+    cfg = O.CFG_WS16
+    B = 2
+    sd = O.make_weights(cfg, 12)
+    net = build_net(cfg)
+    net.load_state_dict(sd, strict=True)
+    net.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(4321)
+    x = torch.rand(B, 3, 128, 128, generator=g)
+    tgt = torch.rand(B, 3, 256, 256, generator=g)
+    y = net(x.to(DEV))
+    loss = F.l1_loss(y, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    params = dict(net.named_parameters())
+    osd = {k: (v.clone().requires_grad_(True) if (k in params and params[k].requires_grad) else v) for k, v in sd.items()}
+    oy = O.rdstsr_forward(x, osd, cfg)
+    oloss = F.l1_loss(oy, tgt)
+    oloss.backward()
+
+    yc = y.detach().float().cpu()
+    dpsnr = abs(O.psnr(tgt, yc, 2) - O.psnr(tgt, oy.detach(), 2))
+    worst, tot_d, tot_r, n, bad = (0.0, None), 0.0, 0.0, 0, []
+    for k, p in params.items():
+        if not p.requires_grad:
+            continue
+        ref = osd[k].grad
+        assert p.grad is not None and ref is not None, k
+        d = (p.grad.float().cpu() - ref).norm().item()
+        rn = ref.norm().item()
+        tot_d += d * d
+        tot_r += rn * rn
+        n += 1
+        rel = d / max(rn, 1e-12)
+        if rel > worst[0]:
+            worst = (rel, k)
+        if rel > 5e-2:
+            bad.append((k, rel))
+    total = (tot_d / tot_r) ** 0.5
+    print(f"\nws16 bf16 B={B}: |dPSNR| {dpsnr:.2e} dB  out max|d| {(yc - oy.detach()).abs().max().item():.2e}  "
+          f"loss {loss.item():.6f} vs {oloss.item():.6f}  {n} gradients: total rel L2 {total:.2e}, worst {worst[0]:.2e} "
+          f"({worst[1]})")
+    assert n == sum(1 for v in osd.values() if v.requires_grad) == 748   # one PixelShuffle stage (x2): two tensors fewer than E1
+    assert dpsnr < 0.05 and abs(loss.item() - oloss.item()) <= 2e-3
+    assert total <= 2e-2
+    assert not bad, bad[:10]
