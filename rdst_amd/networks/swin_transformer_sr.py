@@ -32,6 +32,33 @@ def _no_dropout(p, what):
             "the reference's RDSTSR never forwards drop_path_rate to its blocks)")
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath, which networks/swin_transformer_sr.py:8 imports): in
+    training a residual branch is dropped for a whole sample with probability ``drop_prob`` and the kept ones are
+    scaled by 1 / (1 - drop_prob); identity in eval().  timm itself is not in this image and the random stream is
+    device-specific anyway: parity with the reference is unpinned for the DRAWS, the arithmetic given a mask is tested."""
+
+    def __init__(self, drop_prob=0., scale_by_keep=True):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def mask(self, x):
+        keep = 1.0 - self.drop_prob
+        m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            m.div_(keep)
+        return m
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        return x * self.mask(x)
+
+    def extra_repr(self):
+        return f"drop_prob={round(self.drop_prob, 3):0.3f}"
+
+
 def _ln_params(norm):
     """(weight, bias) of an nn.LayerNorm, or (None, None) for nn.Identity (rdst_layer_norm False)."""
     if isinstance(norm, nn.LayerNorm):
@@ -152,13 +179,12 @@ class SwinTransformerBlock(nn.Module):
             self.shift_size = 0
             self.window_size = min(self.input_resolution)
         assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
-        _no_dropout(drop_path, "drop_path")
 
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(
             dim, window_size=to_2tuple(self.window_size), num_heads=num_heads,
             qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path and drop_path > 0. else nn.Identity()
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         # kept for strict state-dict parity; the kernel derives the mask from (H, W, ws, shift)
@@ -183,6 +209,14 @@ class SwinTransformerBlock(nn.Module):
         n1w, n1b = _ln_params(self.norm1)
         n2w, n2b = _ln_params(self.norm2)
         at, mlp = self.attn, self.mlp
+        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.:
+            # stochastic depth (swin_transformer_sr.py:268, :272): the per-sample mask sits between each branch and its
+            # residual add, so the block runs as its op-level chain and the two adds are plain tensor ops
+            qkv = ops.ln_linear(x, n1w, n1b, at.qkv.weight, at.qkv.bias)
+            a = ops.window_attention(qkv, at.relative_position_bias_table, H, W, self.num_heads, self.window_size,
+                                     self.shift_size, at.scale)
+            x = x + self.drop_path(ops.ln_linear(a, None, None, at.proj.weight, at.proj.bias))
+            return x + self.drop_path(self.mlp(x, norm=self.norm2))
         if at.qkv.bias is None:  # qkv_bias=False: fall back to the op-level chain
             qkv = ops.ln_linear(x, n1w, n1b, at.qkv.weight, None)
             a = ops.window_attention(qkv, at.relative_position_bias_table, H, W, self.num_heads, self.window_size,
@@ -379,8 +413,8 @@ class UpsampleOneStep(nn.Sequential):
 
 
 class SwinIR(nn.Module):
-    """SwinIR (the paper's comparison baseline) on the HIP primitives.  Stochastic depth is accepted at
-    construction (drop_path_rate) and is the identity in eval(); training with drop_path_rate > 0 raises."""
+    """SwinIR (the paper's comparison baseline) on the HIP primitives.  Stochastic depth (drop_path_rate, linearly
+    increasing over the blocks as in swin_transformer_sr.py:695) is active in train() and the identity in eval()."""
 
     def __init__(self, img_size=64, patch_size=1, in_chans=3,
                  embed_dim=96, depths=[6, 6, 6, 6], num_heads=[6, 6, 6, 6],
@@ -420,12 +454,15 @@ class SwinIR(nn.Module):
             trunc_normal_(self.absolute_pos_embed, std=.02)
         _no_dropout(drop_rate, "drop_rate")
         self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]   # stochastic depth decay rule
         self.layers = nn.ModuleList()
         for i_layer in range(self.num_layers):
             self.layers.append(RSTB(dim=embed_dim, input_resolution=(patches_resolution[0], patches_resolution[1]),
                                     depth=depths[i_layer], num_heads=num_heads[i_layer], window_size=window_size,
                                     mlp_ratio=self.mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
-                                    attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer, downsample=None,
+                                    attn_drop=attn_drop_rate,
+                                    drop_path=dpr[sum(depths[:i_layer]):sum(depths[:i_layer + 1])],
+                                    norm_layer=norm_layer, downsample=None,
                                     use_checkpoint=use_checkpoint, img_size=img_size, patch_size=patch_size,
                                     resi_connection=resi_connection))
         self.norm = norm_layer(self.num_features)
@@ -484,9 +521,6 @@ class SwinIR(nn.Module):
         return _norm_only(t, self.norm).view(B, H, W, E)
 
     def forward(self, x):
-        if self.training and self.drop_path_rate and self.drop_path_rate > 0.:
-            raise NotImplementedError("rdst_amd SwinIR: stochastic depth (drop_path_rate > 0) in training mode is "
-                                      "not built; use eval() or drop_path_rate=0")
         self.mean = self.mean.type_as(x)
         xin = (x - self.mean) * self.img_range
         rows = ops.nchw_to_rows(xin, self.compute_dtype)

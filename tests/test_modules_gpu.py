@@ -276,3 +276,54 @@ def test_tester_shell_whole_slices():
     assert len(rep["psnr"]) == 9 and len(rep["ssim"]) == 9
     want = psnr(g["y"][0, :, 4:-4, 4:-4], rec[0].cpu().numpy()[:, 4:-4, 4:-4])
     assert rep["psnr"][0] == pytest.approx(want, rel=1e-9) and rep["ssim"][0] > 0.9999
+
+
+def test_swin_block_stochastic_depth_given_mask():
+    """DropPath > 0 in train(): the block's op-level chain with the per-sample mask between each branch and its residual
+    add (swin_transformer_sr.py:199, :271-272) against the same arithmetic in plain torch fp32 with the SAME masks (the draws
+    themselves are device-specific and timm is absent: unpinned); eval() is the fused block, unchanged."""
+    from rdst_amd.networks.swin_transformer_sr import SwinTransformerBlock, DropPath
+    C, heads, ws, H, W, B = 60, 6, 8, 16, 16, 4
+    torch.manual_seed(3)
+    blk = SwinTransformerBlock(dim=C, input_resolution=(H, W), num_heads=heads, window_size=ws, shift_size=4, mlp_ratio=2.0,
+                               drop_path=0.25)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    blk.to(DEV).train()
+    assert isinstance(blk.drop_path, DropPath)
+    masks = [torch.tensor([0., 4 / 3, 4 / 3, 0.]).view(B, 1, 1), torch.tensor([4 / 3, 0., 4 / 3, 4 / 3]).view(B, 1, 1)]
+    it = iter(masks)
+    blk.drop_path.mask = lambda x: next(it).to(x.device, x.dtype)
+    x = torch.randn(B, H * W, C)
+    gy = torch.randn(B, H * W, C)
+    xg = x.to(DEV).requires_grad_(True)
+    y = blk(xg, (H, W))
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "attn_mask" not in k and "index" not in k)
+          for k, v in blk.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    h1 = F.layer_norm(xr, (C,), sd["norm1.weight"], sd["norm1.bias"], 1e-5)
+    qkv = F.linear(h1, sd["attn.qkv.weight"], sd["attn.qkv.bias"])
+    a = O.window_attention_core(qkv.view(B, H, W, 3 * C), sd["attn.relative_position_bias_table"], heads, ws, 4,
+                                (C // heads) ** -0.5).view(B, H * W, C)
+    x1 = xr + masks[0] * F.linear(a, sd["attn.proj.weight"], sd["attn.proj.bias"])
+    h2 = F.layer_norm(x1, (C,), sd["norm2.weight"], sd["norm2.bias"], 1e-5)
+    m = F.linear(O.gelu(F.linear(h2, sd["mlp.fc1.weight"], sd["mlp.fc1.bias"])), sd["mlp.fc2.weight"], sd["mlp.fc2.bias"])
+    yr = x1 + masks[1] * m
+    yr.backward(gy)
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 1e-4
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() <= 1e-4
+    for k, p in blk.named_parameters():
+        ref = sd[k].grad
+        assert (p.grad.cpu() - ref).norm().item() <= 1e-3 * max(ref.norm().item(), 1e-9), k
+    # a dropped sample passes through untouched by the attention branch: rows of sample 0 / 3 got x + 0 * branch
+    # the default mask draws values in {0, 1 / keep} per sample; eval() is deterministic
+    del blk.drop_path.mask
+    m0 = blk.drop_path.mask(torch.empty(1000, 1, 1, device=DEV))
+    assert all(v == 0.0 or abs(v - 1.0 / 0.75) < 1e-6 for v in m0.unique().tolist()) and 0.6 < (m0 > 0).float().mean().item() < 0.9
+    blk.eval()
+    with torch.no_grad():
+        assert torch.equal(blk(xg, (H, W)), blk(xg, (H, W)))
