@@ -11,6 +11,11 @@ forward (RDSTSR, HIP kernels) + L1 loss + backward + flat-bucket gradient all-re
 :188-240), batch 32 per GPU of 1x64x64 patches -> 256x256, bf16 activations.  Rank 0 prints ONE JSON
 line.  Weak scaling: per-GPU batch fixed.
 
+`--config` selects the workload: e1 (default, the BASELINE.json metric), ws16 (BASELINE configs[3]), e1_unetf (the ini's
+'UNet-F' fine-tuning state: 0.1 L1 + 1 SegUNet_F({'encoder-L1': [1]})), e1_hrl (BASELINE configs[4], RDST-HRL: 0.1 L1 +
+1 SegUNet_F({'label-hr': []}): resnet34-UNet + multiclass Dice in the backward path).  `--backend gloo` runs the N > 1
+path without RCCL (tests; both ranks may share one GPU with RDST_BENCH_ONE_GPU=1).
+
 Extra objects on the line (N = 1, rank 0):
   roofline     — the window-attention forward kernel (K1): algorithmic bytes (4*C*elt per token per launch,
                  DESIGN.md) / its average duration, vs 8 TB/s HBM.  `frac` is the COLD figure: the step's 48 K1
@@ -173,7 +178,26 @@ def _pmc_traffic(kernel_key, files):
 # stress configuration, not the headline workload: its window attention runs on the shape-generic kernels)
 WS16 = dict(E1, img_size=128, in_chans=3, sr_scale=2, window_size=[16] * 8)
 CONFIGS = {"e1": (E1, 64, 1, 4, "RDST-E1 x4 (RDST_E1_OASIS_example_SRx4.ini), 1x64x64 LR patches -> 256x256"),
-           "ws16": (WS16, 128, 3, 2, "RDST x2 3-channel, window 16 (BASELINE configs[3]), 3x128x128 LR patches -> 256x256")}
+           "ws16": (WS16, 128, 3, 2, "RDST x2 3-channel, window 16 (BASELINE configs[3]), 3x128x128 LR patches -> 256x256"),
+           "e1_unetf": (E1, 64, 1, 4, "RDST-E1 x4, 'UNet-F' state of RDST_E1_OASIS_example_SRx4.ini:34,46 (0.1 L1 + 1 SegUNet_F "
+                                      "encoder-L1 [1]), 1x64x64 LR patches -> 256x256"),
+           "e1_hrl": (E1, 64, 1, 4, "RDST-HRL x4 (BASELINE configs[4]): 0.1 L1 + 1 SegUNet_F label-hr (resnet34-UNet + multiclass "
+                                    "Dice in the backward path), 1x64x64 LR patches -> 256x256")}
+LOSS_MODES = {"e1_unetf": {"encoder-L1": [1]}, "e1_hrl": {"label-hr": []}}
+
+
+def build_loss(config, device):
+    """None (plain L1) or the reference's weighted SRLoss for the UNet-F states (loss/sr_loss.py:35-51, ini :31-46).  The
+    UNet checkpoint (loss/unet_oasis.pt) is not in the repository: seeded random initialisation, said so in `data`."""
+    if config not in LOSS_MODES:
+        return None
+    import types
+    from rdst_amd.loss.sr_loss import SRLoss
+    torch.manual_seed(1)
+    paras = types.SimpleNamespace(gpu_id=device.index, precision=False, training_losses=["L1", "UNet-F"],
+                                  loss_scalars={"UNet-F": {"L1": 0.1, "UNet-F": 1}}, training_states=["UNet-F"],
+                                  unet_loss_layers=LOSS_MODES[config], unet_loss_mode="OASIS", unet_allow_random=True)
+    return SRLoss(paras)
 
 
 def build_net(device, dtype, cfg=None):
@@ -184,18 +208,19 @@ def build_net(device, dtype, cfg=None):
     return net
 
 
-def _cpu_baseline_worker(threads, sample_batch, timed):
+def _cpu_baseline_worker(threads, sample_batch, timed, which="e1"):
     """Runs in a child process: the oracle (a CPU port of the reference algorithm), fwd + L1 + bwd."""
     torch.set_num_threads(threads)
     from oracle import rdst_oracle as O
-    cfg = O.CFG_E1
+    cfg, cin, lr, sr = {"e1": (O.CFG_E1, 1, 64, 4), "tiny": (O.CFG_TINY, 1, 64, 4),
+                        "ws16": (O.make_cfg(**{**O.CFG_WS16, "img_size": 128}), 3, 128, 2)}[which]
     sd = O.make_weights(cfg, 0)
     lay = O.state_dict_layout(cfg)
     sd = {k: (v.clone().requires_grad_(True) if lay[k][2] not in ("index", "mask", "shift_w", "shift_b") else v)
           for k, v in sd.items()}
     g = torch.Generator().manual_seed(1234)
-    x = torch.rand(sample_batch, 1, 64, 64, generator=g)
-    tgt = torch.rand(sample_batch, 1, 256, 256, generator=g)
+    x = torch.rand(sample_batch, cin, lr, lr, generator=g)
+    tgt = torch.rand(sample_batch, cin, lr * sr, lr * sr, generator=g)
     best = None
     for it in range(1 + timed):
         t0 = time.perf_counter()
@@ -207,27 +232,57 @@ def _cpu_baseline_worker(threads, sample_batch, timed):
     print(json.dumps({"best_s": best}), flush=True)
 
 
-def cpu_baseline(threads=16, sample_batch=4, timed=3, timeout_s=150):
+def _host_cpu():
+    """(model name, physical cores, logical CPUs) of the host from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None and core is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
+
+
+def cpu_baseline(which="e1", threads=16, sample_batch=4, timed=3, timeout_s=150):
     """Bounded CPU baseline next to the GPU number.  16 threads: on the 256-CPU GPU-box host the
     oracle is FASTEST there (measured 1.7 s/step at 16 threads, 2.9 s at 32, 5.7 s at 64: the ops are
     small and OpenMP fork/join dominates beyond that), so this is the best CPU figure, not a handicap."""
     import subprocess
     threads = max(1, min(threads, os.cpu_count() or 1))
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(sample_batch), str(timed)]
+    model, phys, logical = _host_cpu()
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(sample_batch), str(timed), which]
+    names = {"e1": "RDST-E1 x4, 1x64x64", "tiny": "RDST-E tiny x4 (BASELINE configs[0]), 1x64x64", "ws16": "RDST x2 window 16, 3x128x128"}
+    host = {"cores": threads, "host_cpu": model, "host_physical_cores": phys, "host_logical_cpus": logical}
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         best = json.loads(r.stdout.strip().splitlines()[-1])["best_s"]
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "patches/s", "cores": threads, "kind": "port",
+        return {"value": None, "unit": "patches/s", **host, "kind": "port",
                 "sample": f"failed or exceeded {timeout_s}s: {type(e).__name__}"}
-    return {"value": round(sample_batch / best, 3), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/rdst_oracle.py fwd+L1+bwd, RDST-E1 x4, batch {sample_batch} of 1x64x64 fp32, "
-                      f"best of {timed} after 1 warm-up, torch CPU, {threads} threads"}
+    return {"value": round(sample_batch / best, 3), "unit": "patches/s", **host, "kind": "port",
+            "sample": f"oracle/rdst_oracle.py fwd+L1+bwd, {names[which]}, batch {sample_batch} fp32, "
+                      f"best of {timed} after 1 warm-up, torch CPU, {threads} threads (the oracle's fastest thread count on this host)"}
 
 
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
-        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+        _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "e1")
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +291,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU (default 32; 8 for --config ws16)")
     ap.add_argument("--config", default="e1", choices=sorted(CONFIGS), help="e1 = the BASELINE.json metric (default)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3, help="replay passes over the recorded launches")
@@ -250,76 +306,51 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node "
               f"{args.gpus} (or run plain `python bench.py` for one GPU)", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("RDST_BENCH_ONE_GPU") == "1":      # tests: every rank on cuda:0 (gloo only)
+        if args.backend != "gloo":
+            print("bench.py: RDST_BENCH_ONE_GPU=1 needs --backend gloo", file=sys.stderr)
+            sys.exit(2)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
-    from rdst_amd import dp, ops, optim
+    from rdst_amd import _lib, dp, optim  # noqa: F401
+    from rdst_amd.trainer import DPTrainStep
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg, lr_size, in_ch, sr, cfg_name = CONFIGS[args.config]
     if args.batch is None:
-        args.batch = 32 if args.config == "e1" else 8
-    if args.config != "e1":
-        args.no_roofline = True               # the per-op table and K1 roofline are defined for the headline workload
+        args.batch = 8 if args.config == "ws16" else 32
     net = build_net(device, dtype, cfg)
-    dp.broadcast_parameters(net)
-    bucket = dp.FlatGradBucket(net.parameters())
-    # utils/optim.py:30-53 with the ini's hyper-parameters; one fused HIP launch over the flat buffers
-    opt = optim.FlatAdam(bucket.params, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, bucket=bucket)
+    loss_obj = build_loss(args.config, device)
+    if loss_obj is not None:
+        loss_obj.loss_functions["UNet-F"].set_compute_dtype(dtype)
+    # the trainer-step shell a user calls (rdst_amd/trainer.py): flat bucket, one all-reduce, fused Adam with
+    # utils/optim.py:30-53's hyper-parameters from the ini; forward + loss + backward replayed from ONE HIP graph
+    tr = DPTrainStep(net, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, loss_fn=loss_obj, graph=False)
+    bucket = tr.bucket
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
     x = torch.rand(B, in_ch, lr_size, lr_size, generator=g).to(device)
     tgt = torch.rand(B, in_ch, lr_size * sr, lr_size * sr, generator=g).to(device)
-    loss_buf = torch.zeros((), device=device)
 
-    def fwd_bwd():
-        bucket.detach_grads()       # autograd assigns fresh grads (no per-parameter accumulate kernels) ...
-        y = net(x)
-        loss = F.l1_loss(y, tgt)
-        loss_buf.copy_(loss.detach())
-        loss.backward()
-        bucket.gather()             # ... which are flattened into the one all-reduce / Adam bucket
-
-    def step_eager():
-        fwd_bwd()
-        bucket.all_reduce_mean()
-        opt.step()
-
-    graph = None
-    recorded = []
+    lib = _lib.load()
+    rec = Recorder(lib)
     if args.graph:
-        # HIP graph of forward+backward (static shapes, no host sync inside); the collective and the
-        # optimizer stay outside so RCCL is free to use its own streams
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step_eager()
-        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(2):          # eager steps: every lazy initialisation (weight-image plans, workspaces) happens here
+            tr.step(x, tgt)
         torch.cuda.synchronize()
-        try:
-            from rdst_amd import _lib
-            graph = torch.cuda.CUDAGraph()
-            with Recorder(_lib.load()) as rec:   # the step graph's pool keeps every recorded operand alive
-                with torch.cuda.graph(graph):
-                    fwd_bwd()
-            recorded = rec.calls
-        except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                print(f"bench.py: graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-        if graph is not None and not bucket.check_views():
-            graph = None
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            bucket.all_reduce_mean()
-            opt.step()
-        else:
-            step_eager()
+        tr.use_graph = True
+        tr.capture_hook = lambda: rec   # the step graph's pool keeps every recorded operand alive
+        if not tr.capture(x, tgt) and rank == 0:
+            print("bench.py: graph capture failed; running eagerly", file=sys.stderr)
+        tr.capture_hook = None
+    recorded = rec.calls if tr.graph is not None else []
+    x, tgt = (tr._static if tr.graph is not None else (x, tgt))   # no per-step input copy: the step reads the static buffers
 
     def sync():
         if world > 1:
@@ -327,141 +358,204 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        tr.step(x, tgt)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        tr.step(x, tgt)
     sync()
     elapsed = time.perf_counter() - t0
+    loss_t = tr._loss_buf.detach().clone().double()
+    param_sync = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    loss_val = float(loss_buf.item())
+        dist.all_reduce(loss_t, op=dist.ReduceOp.SUM)
+        loss_t /= world
+        # replicas must hold identical parameters after the timed steps (same all-reduced gradients, same Adam)
+        cs = tr.optimizer.flat_param.double().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        param_sync = bool(lo.item() == hi.item())
+    loss_val = float(loss_t.item())
 
+    metric = {"e1": "SR patches/sec fwd+bwd, RDST-E1 x4 64->256",
+              "ws16": "SR patches/sec fwd+bwd, RDST x2 window-16 128->256 (BASELINE configs[3])",
+              "e1_unetf": "SR patches/sec fwd+bwd, RDST-E1 x4 64->256, UNet-F state (seg-UNet stem loss in the backward path)",
+              "e1_hrl": "SR patches/sec fwd+bwd, RDST-HRL x4 64->256 (BASELINE configs[4]: seg-UNet label-hr Dice loss)"}[args.config]
+    step_desc = "L1" if loss_obj is None else "0.1 L1 + 1 UNet-F"
     out = {
-        "metric": "SR patches/sec fwd+bwd, RDST-E1 x4 64->256" if args.config == "e1" else
-                  "SR patches/sec fwd+bwd, RDST x2 window-16 128->256 (BASELINE configs[3])",
+        "metric": metric,
         "value": round(world * B * args.steps / elapsed, 3),
         "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": cfg_name + ", step = fwd + L1 + bwd + flat-bucket grad all-reduce + Adam",
+        "dtype": args.dtype,
+        "data": "synthetic" + ("" if loss_obj is None else " (seg-UNet: seeded random init, the reference's loss/unet_oasis.pt is not in the repository)"),
+        "config": {"workload": cfg_name + f", step = fwd + {step_desc} + bwd + flat-bucket grad all-reduce + Adam",
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                   "hip_graph": graph is not None, "grad_bucket_bytes": bucket.nbytes},
+                   "hip_graph": tr.graph is not None, "grad_bucket_bytes": bucket.nbytes,
+                   "backend": (args.backend if world > 1 else None)},
         "loss": round(loss_val, 6),
     }
+    if param_sync is not None:
+        out["param_sync"] = param_sync
 
-    if rank == 0 and world == 1 and not args.no_roofline and graph is not None and recorded:
-        from rdst_amd import _lib
-        lib = _lib.load()
+    if rank == 0 and world == 1 and not args.no_roofline and tr.graph is not None and recorded:
         elt = 2 if args.dtype == "bf16" else 4
         reps = max(1, args.roofline_steps)
-        mfma_peak = MFMA_PEAK_TFLOPS[args.dtype] * 1e12
-        # ---- per-op table: every recorded launch of an entry point replayed back to back (cold operands) -------------
-        groups = {}
-        for n, a in recorded:
-            groups.setdefault(n, []).append((n, a))
-        table = []
-        for n, calls in groups.items():
-            ms = _replay_calls(lib, calls, reps)
-            by = [_alg(n, a, elt) for _, a in calls]
-            nbytes, flops = sum(b for b, _ in by) / len(calls), sum(f for _, f in by) / len(calls)
-            hbm, mf = nbytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), flops / (ms * 1e-3) / mfma_peak
-            table.append({"op": n, "launches_per_step": len(calls), "avg_us": round(1e3 * ms, 2),
-                          "ms_per_step": round(ms * len(calls), 3), "alg_bytes": int(nbytes), "alg_flops": int(flops),
-                          "bound": "hbm" if hbm >= mf else "mfma", "frac_of_peak": round(max(hbm, mf), 4)})
-        table.sort(key=lambda r: -r["ms_per_step"])
-        out["kernels"] = {"how": "all launches of a C-ABI entry point recorded while the step graph was captured, replayed back to "
-                                 "back from one HIP graph on the step's own operands (cold: a step's activations are GBs), HIP "
-                                 "events around the replays; frac_of_peak = max(alg bytes / 8 TB/s, alg FLOPs / dense MFMA peak) / time",
-                          "top": table[:6]}
-        # ---- roofline of the window-attention forward kernel (K1) -------------------------------------------------
-        k1 = groups["rdst_wattn_fwd"]
-        k1_ms = next(r["avg_us"] for r in table if r["op"] == "rdst_wattn_fwd") * 1e-3
-        k1_bytes = sum(_alg(n, a, elt)[0] for n, a in k1) / len(k1)
-        per_c = {}
-        for C in sorted({a[10] for _, a in k1}):
-            sub = [(n, a) for n, a in k1 if a[10] == C]
-            ms = _replay_calls(lib, sub, reps)
-            bts = _alg(sub[0][0], sub[0][1], elt)[0]
-            per_c[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
-        # inside the step: the forward pass as a HIP graph with its 48 K1 launches and with those launches left out
-        # (Recorder.skip: the library call is not made, its output buffer keeps the previous replay's values)
-        in_step = None
-        try:
-            def fwd_graph(skip):
-                with torch.no_grad():
-                    net(x)
-                    torch.cuda.synchronize()
-                    gph = torch.cuda.CUDAGraph()
-                    with Recorder(lib) as r2:
-                        r2.skip = skip
-                        with torch.cuda.graph(gph):
-                            net(x)
-                return gph
-            g_full, g_skip = fwd_graph(None), fwd_graph("rdst_wattn_fwd")
-            diffs = sorted(_timed_replay(g_full, 15) - _timed_replay(g_skip, 15) for _ in range(4))   # interleaved
-            in_step = 0.5 * (diffs[1] + diffs[2]) / len(k1)
-            del g_full, g_skip
-        except Exception as e:  # noqa: BLE001 - measurement aid only
-            print(f"bench.py: in-step K1 timing unavailable ({type(e).__name__}: {e})", file=sys.stderr)
-        traffic, tsrc = _pmc_traffic("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"])
-        ach = k1_bytes / (k1_ms * 1e-3) / 1e9
-        out["roofline"] = {"kernel": "rdst_wattn_fwd (K1, window attention forward)", "bound": "hbm",
-                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                           "launches": len(k1), "avg_launch_us": round(1e3 * k1_ms, 2),
-                           "how": "COLD: the step's 48 K1 launches (C = 60/90/120, shifted and not) replayed back to back on "
-                                  "the step's own buffers, HIP events on the launch stream; in_step = (forward graph with K1) - "
-                                  "(forward graph without) / 48, where qkv was just written by the preceding Linear",
-                           "per_shape": per_c, "algorithmic_bytes_per_launch_avg": int(k1_bytes)}
-        if in_step and in_step > 0:
-            a2 = k1_bytes / (in_step * 1e-3) / 1e9
-            out["roofline"]["in_step"] = {"avg_launch_us": round(1e3 * in_step, 2), "achieved": round(a2, 1),
-                                          "frac": round(a2 / HBM_PEAK_GBS, 4)}
-        k2r = next(r for r in table if r["op"] == "rdst_wattn_bwd")
-        t2, t2src = _pmc_traffic("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"])
-        out["roofline_bwd"] = {"kernel": "rdst_wattn_bwd (K2)", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "achieved": round(k2r["alg_bytes"] / (k2r["avg_us"] * 1e-6) / 1e9, 1),
-                               "frac": round(k2r["alg_bytes"] / (k2r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                               "avg_launch_us": k2r["avg_us"], "traffic": t2, "traffic_source": t2src}
+        out.update(op_tables(lib, recorded, elt, reps, args.dtype, net, x, ws16=(args.config == "ws16")))
     if rank == 0 and world == 1 and not args.no_roofline:
-        if args.dtype == "bf16" and not args.no_fp32_line:
+        if args.dtype == "bf16" and not args.no_fp32_line and args.config == "e1":
             # the parity mode (fp32 activations, exact-fp32 MFMA): the only mode with the 4-decimal PSNR claim
-            del graph
+            del tr
             try:
-                net32 = build_net(device, torch.float32)
-                b32 = dp.FlatGradBucket(net32.parameters())
-                o32 = optim.FlatAdam(b32.params, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, bucket=b32)
-
-                def step32():
-                    b32.detach_grads()
-                    F.l1_loss(net32(x), tgt).backward()
-                    b32.gather()
-                    o32.step()
-                for _ in range(2):
-                    step32()
-                torch.cuda.synchronize()
-                t32 = time.perf_counter()
-                for _ in range(3):
-                    step32()
-                torch.cuda.synchronize()
-                d32 = (time.perf_counter() - t32) / 3
-                out["fp32_mode"] = {"value": round(B / d32, 3), "unit": "patches/s", "ms_per_step": round(1e3 * d32, 3),
-                                    "steps": 3, "note": "fp32 activations + exact-fp32 MFMA (parity mode), eager launches"}
-                del net32, b32, o32
+                out["fp32_mode"] = fp32_line(device, x, tgt, B, lib)
             except Exception as e:  # noqa: BLE001
                 out["fp32_mode"] = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            if args.config == "ws16":
+                out["cpu_baseline"] = cpu_baseline("ws16", sample_batch=1, timed=1, timeout_s=200)
+            else:
+                out["cpu_baseline"] = cpu_baseline("e1")
+                if args.config == "e1":
+                    c1 = cpu_baseline("tiny", timeout_s=60)
+                    out["cpu_baseline"]["cfg1"] = {"value": c1["value"], "unit": "patches/s", "sample": c1["sample"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def fp32_line(device, x, tgt, B, lib):
+    """The same step in the fp32 parity mode, graph-captured like the bf16 one, with its own per-op table."""
+    from rdst_amd.trainer import DPTrainStep
+    net32 = build_net(device, torch.float32)
+    t32 = DPTrainStep(net32, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, graph=False)
+    for _ in range(2):
+        t32.step(x, tgt)
+    torch.cuda.synchronize()
+    rec = Recorder(lib)
+    t32.use_graph = True
+    t32.capture_hook = lambda: rec
+    t32.capture(x, tgt)
+    t32.capture_hook = None
+    xs, ts = t32._static if t32.graph is not None else (x, tgt)
+    t32.step(xs, ts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        t32.step(xs, ts)
+    torch.cuda.synchronize()
+    d32 = (time.perf_counter() - t0) / n
+    line = {"value": round(B / d32, 3), "unit": "patches/s", "ms_per_step": round(1e3 * d32, 3), "steps": n,
+            "hip_graph": t32.graph is not None,
+            "note": "fp32 activations + exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode, same step and graph capture as the bf16 line"}
+    if t32.graph is not None and rec.calls:
+        tab = _op_table(lib, rec.calls, 4, 2, MFMA_PEAK_TFLOPS["fp32"] * 1e12)
+        line["kernels"] = tab[:6]
+    return line
+
+
+def _op_table(lib, recorded, elt, reps, mfma_peak):
+    groups = {}
+    for n, a in recorded:
+        groups.setdefault(n, []).append((n, a))
+    table = []
+    for n, calls in groups.items():
+        ms = _replay_calls(lib, calls, reps)
+        by = [_alg(n, a, elt) for _, a in calls]
+        nbytes, flops = sum(b for b, _ in by) / len(calls), sum(f for _, f in by) / len(calls)
+        hbm, mf = nbytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), flops / (ms * 1e-3) / mfma_peak
+        table.append({"op": n, "launches_per_step": len(calls), "avg_us": round(1e3 * ms, 2),
+                      "ms_per_step": round(ms * len(calls), 3), "alg_bytes": int(nbytes), "alg_flops": int(flops),
+                      "bound": "hbm" if hbm >= mf else "mfma", "frac_of_peak": round(max(hbm, mf), 4)})
+    table.sort(key=lambda r: -r["ms_per_step"])
+    return table
+
+
+def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
+    """`kernels`, `roofline` (K1) and `roofline_bwd` (K2) of the line, all from the launches recorded during capture."""
+    out = {}
+    mfma_peak = MFMA_PEAK_TFLOPS[dtype_name] * 1e12
+    groups = {}
+    for n, a in recorded:
+        groups.setdefault(n, []).append((n, a))
+    table = _op_table(lib, recorded, elt, reps, mfma_peak)
+    out["kernels"] = {"how": "all launches of a C-ABI entry point recorded while the step graph was captured, replayed back to "
+                             "back from one HIP graph on the step's own operands (cold: a step's activations are GBs), HIP "
+                             "events around the replays; frac_of_peak = max(alg bytes / 8 TB/s, alg FLOPs / dense MFMA peak) / time",
+                      "top": table[:8]}
+    # ---- roofline of the window-attention forward kernel (K1) -------------------------------------------------
+    k1 = groups["rdst_wattn_fwd"]
+    k1_ms = next(r["avg_us"] for r in table if r["op"] == "rdst_wattn_fwd") * 1e-3
+    k1_bytes = sum(_alg(n, a, elt)[0] for n, a in k1) / len(k1)
+    per_c = {}
+    for C in sorted({a[10] for _, a in k1}):
+        sub = [(n, a) for n, a in k1 if a[10] == C]
+        ms = _replay_calls(lib, sub, reps)
+        bts = _alg(sub[0][0], sub[0][1], elt)[0]
+        per_c[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+    # inside the step: the forward pass as a HIP graph with its 48 K1 launches and with those launches left out
+    # (Recorder.skip: the library call is not made, its output buffer keeps the previous replay's values)
+    in_step = None
+    try:
+        def fwd_graph(skip):
+            with torch.no_grad():
+                net(x)
+                torch.cuda.synchronize()
+                gph = torch.cuda.CUDAGraph()
+                with Recorder(lib) as r2:
+                    r2.skip = skip
+                    with torch.cuda.graph(gph):
+                        net(x)
+            return gph
+        g_full, g_skip = fwd_graph(None), fwd_graph("rdst_wattn_fwd")
+        diffs = sorted(_timed_replay(g_full, 15) - _timed_replay(g_skip, 15) for _ in range(4))   # interleaved
+        in_step = 0.5 * (diffs[1] + diffs[2]) / len(k1)
+        del g_full, g_skip
+    except Exception as e:  # noqa: BLE001 - measurement aid only
+        print(f"bench.py: in-step K1 timing unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+    if ws16:
+        traffic, tsrc = _pmc_traffic("wattn16_fwd_kernel", ["wattn16_mfma.hip"])
+        t2, t2src = _pmc_traffic("wattn16_bwd_kernel", ["wattn16_mfma.hip"])
+        kname, bound_note = "rdst_wattn_fwd (K1, window 16: wattn16_fwd_kernel)", "vector ALU (256 x 256 x 6 exponentials per window); priced against HBM as north_star asks"
+    else:
+        traffic, tsrc = _pmc_traffic("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"])
+        t2, t2src = _pmc_traffic("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"])
+        kname, bound_note = "rdst_wattn_fwd (K1, window attention forward)", None
+    ach = k1_bytes / (k1_ms * 1e-3) / 1e9
+    out["roofline"] = {"kernel": kname, "bound": "hbm",
+                       "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                       "launches": len(k1), "avg_launch_us": round(1e3 * k1_ms, 2),
+                       "how": "COLD: the step's K1 launches (every width, shifted and not) replayed back to back on "
+                              "the step's own buffers, HIP events on the launch stream; in_step = (forward graph with K1) - "
+                              "(forward graph without) / launches, where qkv was just written by the preceding Linear",
+                       "per_shape": per_c, "algorithmic_bytes_per_launch_avg": int(k1_bytes)}
+    if bound_note:
+        out["roofline"]["note"] = bound_note
+    if in_step and in_step > 0:
+        a2 = k1_bytes / (in_step * 1e-3) / 1e9
+        out["roofline"]["in_step"] = {"avg_launch_us": round(1e3 * in_step, 2), "achieved": round(a2, 1),
+                                      "frac": round(a2 / HBM_PEAK_GBS, 4)}
+    k2r = next(r for r in table if r["op"] == "rdst_wattn_bwd")
+    k2 = groups["rdst_wattn_bwd"]
+    per_c2 = {}
+    for C in sorted({a[15] for _, a in k2}):
+        sub = [(n, a) for n, a in k2 if a[15] == C]
+        ms = _replay_calls(lib, sub, reps)
+        bts = _alg(sub[0][0], sub[0][1], elt)[0]
+        per_c2[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+    out["roofline_bwd"] = {"kernel": "rdst_wattn_bwd (K2)", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "achieved": round(k2r["alg_bytes"] / (k2r["avg_us"] * 1e-6) / 1e9, 1),
+                           "frac": round(k2r["alg_bytes"] / (k2r["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                           "avg_launch_us": k2r["avg_us"], "per_shape": per_c2, "traffic": t2, "traffic_source": t2src}
+    return out
 
 
 if __name__ == "__main__":

@@ -241,6 +241,81 @@ int rdst_stem_loss_fwd(const float* sr, const float* hr, const float* conv_w, co
 int rdst_stem_loss_bwd(const float* conv_w, const float* bn_w, const float* upstream, float* dsr, void* workspace,
                        size_t workspace_bytes, int B, int Cin, int H, int W, void* stream);
 
+/* ---- N2 (full): the seg-UNet of the reference's perceptual loss (loss/seg_unet.py:46-127) -----------------------------
+ * smp.Unet(in_channels, classes=4) = resnet34 encoder + UNet decoder + 3x3 head, BatchNorm in TRAINING mode, frozen
+ * weights: forward on the SR and the HR batch, backward to the SR image ONLY (no weight gradients: the optimizer of the
+ * reference holds model_g alone, models/trans_sr_trainer.py:72).  The host (rdst_amd/loss/seg_unet.py) composes the
+ * network from the entry points below; activations are NHWC rows (pixel-major, `ld` in elements) of `dtype`
+ * (RDST_F32 parity mode / RDST_BF16 throughput mode, fp32 accumulation and statistics).  `scratch` = at least
+ * rdst_u_scratch_bytes() bytes of device memory that calls on one stream may share (partial sums, fixed-order reductions).
+ */
+size_t rdst_u_scratch_bytes(void);
+
+/* Implicit-GEMM convolution on the matrix cores, k x k (1, 3), stride 1 / 2, zero padding k/2.
+ *   input  = channel concat of source 1 (C1 channels; nearest-upsampled x2 on the fly when up1 = 1: it then holds
+ *            (B, Hin/2, Win/2, C1)) and source 2 (C2 channels, may be NULL / 0) — the UNet decoder's
+ *            F.interpolate(x, 2, 'nearest') + torch.cat([x, skip], 1) never materialises;
+ *   Wp     = weights in `dtype`, [k*k][Npad][C1 + C2] (reduction index contiguous, Npad = Cout rounded up to 32, zero rows);
+ *   Y[b, oy, ox, :Cout] = sum_taps in[b, oy*stride + ky - k/2, ox*stride + kx - k/2, :] . Wp[tap] + bias + add
+ *   transposed = 1: the data gradient of such a convolution (input = dY in the FORWARD's output geometry (Hin, Win),
+ *            output = dX in the forward's input geometry (Hout, Wout)): in[b, (oy + k/2 - ky) / stride, ...] where divisible,
+ *            with Wp = the forward's weights as [k*k][Cin_fwd padded][Cout_fwd].
+ * (C1 + C2) * elementsize must be a multiple of 32 bytes and C1 * elementsize a multiple of the reduction chunk. */
+int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const void* X2, int64_t ld2, int C2, const void* Wp,
+                const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win, int Hout,
+                int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream);
+
+/* encoder.conv1: 7x7 stride 2 pad 3, Cin <= 4 -> 64, from the fp32 NCHW image; and its data gradient back to the image
+ * (times the device scalar `upstream`, NULL = 1).  W = fp32 (64, Cin, 7, 7) as nn.Conv2d stores it. */
+int rdst_u_stem_fwd(const float* img, const float* W, void* Y, int64_t ld_y, int B, int Cin, int H, int Wd, int dtype,
+                    void* stream);
+int rdst_u_stem_dgrad(const void* dR, int64_t ld, const float* W, const float* upstream, float* dimg, int B, int Cin, int H,
+                      int Wd, int dtype, void* stream);
+
+/* BatchNorm2d in training mode on rows X (P, C): batch statistics (biased variance, fixed-order sums) ->
+ * coef[0..C) = a = gamma * rstd, coef[C..2C) = b = beta - mean * a, coef[2C..3C) = mean, coef[3C..4C) = rstd;
+ * running_mean / running_var (may be NULL) updated as nn.BatchNorm2d does (momentum, unbiased variance). */
+int rdst_u_bn_stats(const void* X, int64_t ld, int64_t P, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* coef, void* scratch, int dtype,
+                    void* stream);
+/* Y = act(a X + b [+ a2 X2 + b2] [+ R]), act = ReLU when relu != 0: BatchNorm apply, the BasicBlock's identity /
+ * downsample branch and the activation in one pass. */
+int rdst_u_bn_apply(const void* X, int64_t ldx, const float* coef, const void* X2, int64_t ldx2, const float* coef2,
+                    const void* R, int64_t ldr, int relu, void* Y, int64_t ldy, int64_t P, int C, int dtype, void* stream);
+/* Backward of Y = act(BatchNorm_train(Xraw) + ...) to Xraw: g = dY * [Ymask > 0] (Ymask NULL: g = dY),
+ * dX = a (g - mean(g) - xhat mean(g xhat)); Gout (may be NULL) receives g (+ Gadd), the gradient of the "+ ..." operand. */
+int rdst_u_bn_bwd(const void* dY, int64_t lddy, const void* Ymask, int64_t ldm, const void* Xraw, int64_t ldx,
+                  const float* coef, void* dX, int64_t lddx, void* Gout, int64_t ldg, const void* Gadd, int64_t ldga,
+                  int64_t P, int C, void* scratch, int dtype, void* stream);
+
+/* MaxPool2d(3, 2, 1) (the first maximum of a window in row-major scan order wins, as ATen), its backward (+ add), and the
+ * backward of the nearest x2 upsampling (2x2 sums of dY (B, 2H, 2W, C) (+ add)). */
+int rdst_u_maxpool_fwd(const void* X, int64_t ldx, void* Y, int64_t ldy, uint8_t* idx, int B, int H, int W, int C, int dtype,
+                       void* stream);
+int rdst_u_maxpool_bwd(const void* dY, int64_t lddy, const uint8_t* idx, const void* add, int64_t ld_add, void* dX,
+                       int64_t lddx, int B, int H, int W, int C, int dtype, void* stream);
+int rdst_u_sumpool2(const void* dY, int64_t lddy, const void* add, int64_t ld_add, void* dX, int64_t lddx, int B, int H,
+                    int W, int C, int dtype, void* stream);
+
+/* loss[0] = (accumulate ? loss[0] : 0) + weight * mean((A - B)^2) (mse = 1) or weight * mean(|A - B|) over (P, C) rows;
+ * backward: dA = (add +) weight * upstream[0] * d(mean)/dA. */
+int rdst_u_pair_loss_fwd(const void* A, int64_t lda, const void* Bv, int64_t ldb, int64_t P, int C, int mse, float weight,
+                         int accumulate, float* loss, void* scratch, int dtype, void* stream);
+int rdst_u_pair_loss_bwd(const void* A, int64_t lda, const void* Bv, int64_t ldb, int64_t P, int C, int mse, float weight,
+                         const float* upstream, const void* add, int64_t ld_add, void* dA, int64_t ldda, int dtype,
+                         void* stream);
+
+/* smp.losses.DiceLoss('multiclass', classes) on logits (P, ncls <= 8): targets = argmax of `target_logits` (first
+ * maximum; the 'label-hr' mode, loss/seg_unet.py:112-116) or `labels` (int64, 'label-gt'); class_mask bit c = class c is
+ * averaged.  coef (2 * ncls floats) carries d(loss)/d(probability) to the backward, which writes dlogits (P, ncls_pad):
+ * channels >= ncls are zeroed (the head's data-gradient conv wants a 32-byte reduction). */
+int rdst_u_dice_fwd(const void* logits, int64_t ld, const void* target_logits, int64_t ldt, const int64_t* labels, int64_t P,
+                    int ncls, int class_mask, float eps, float weight, int accumulate, float* loss, float* coef,
+                    void* scratch, int dtype, void* stream);
+int rdst_u_dice_bwd(const void* logits, int64_t ld, const void* target_logits, int64_t ldt, const int64_t* labels, int64_t P,
+                    int ncls, const float* coef, const float* upstream, void* dlogits, int64_t ldd, int ncls_pad, int dtype,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,8 +53,24 @@ SIGNATURES = {
     "rdst_stem_loss_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
     "rdst_stem_loss_bwd": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "rdst_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _p]),
+    # the seg-UNet of the perceptual loss (ABI v5)
+    "rdst_u_scratch_bytes": (_z, []),
+    "rdst_u_conv": (_i, [_p, _l, _i, _i, _p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rdst_u_stem_fwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "rdst_u_stem_dgrad": (_i, [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "rdst_u_bn_stats": (_i, [_p, _l, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),
+    "rdst_u_bn_apply": (_i, [_p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _l, _l, _i, _i, _p]),
+    "rdst_u_bn_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _l, _p, _l, _l, _i, _p, _i, _p]),
+    "rdst_u_maxpool_fwd": (_i, [_p, _l, _p, _l, _p, _i, _i, _i, _i, _i, _p]),
+    "rdst_u_maxpool_bwd": (_i, [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "rdst_u_sumpool2": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "rdst_u_pair_loss_fwd": (_i, [_p, _l, _p, _l, _l, _i, _i, _f, _i, _p, _p, _i, _p]),
+    "rdst_u_pair_loss_bwd": (_i, [_p, _l, _p, _l, _l, _i, _i, _f, _p, _p, _l, _p, _l, _i, _p]),
+    "rdst_u_dice_fwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _i, _f, _f, _i, _p, _p, _p, _i, _p]),
+    "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
+ABI_VERSION = 5             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 
@@ -82,6 +98,10 @@ def load() -> C.CDLL:
             continue
         fn.restype = res
         fn.argtypes = args
+    got = lib.rdst_abi_version()
+    if got != ABI_VERSION:   # a stale library would be called with shifted arguments (sizes read as pointers)
+        raise RuntimeError(f"rdst_amd: {LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: "
+                           "rebuild it with `python -m rdst_amd.build --force` (and `--debug` for the _dbg library)")
     _lib = lib
     return lib
 

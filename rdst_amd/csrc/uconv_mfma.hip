@@ -1,0 +1,244 @@
+// rdst_u_conv: implicit-GEMM convolution on the matrix cores for the frozen seg-UNet of the reference's perceptual loss
+// (loss/seg_unet.py:46,83-92: smp.Unet resnet34 encoder + decoder + head).  No im2col and no padded copies:
+//   D[pixel][cout] = sum over (tap, cin chunk) of X[pixel + tap offset][cin] . W[tap][cout][cin]
+// A workgroup (4 waves) owns a BM x BN tile of D; per step it stages a BM x KB-byte slab of input pixels (one tap, one
+// channel chunk: each pixel's chunk is KB contiguous bytes of its NHWC row, read as 16-byte pieces; out-of-image taps read
+// zeros) and the matching BN x KB slab of the prepacked weights ([tap][cout][cin], cin contiguous) into a double-buffered
+// LDS tile (rows KB + 16 bytes: an odd number of 16-byte slots, conflict-free ds_read_b128), global loads of step i + 1 in
+// flight under the MFMAs of step i, ONE barrier per step.  The same kernel covers
+//   * stride 1 / 2 forward convolutions (3x3, 1x1 downsample),
+//   * the decoder's nearest-x2 upsampling + channel concat, folded into the address of the slab loads (source 1 read at
+//     (y/2, x/2), source 2 behind it in the channel index): neither F.interpolate nor torch.cat materialises,
+//   * `transposed` = the data gradient of all of those (gather form: out-of-phase taps of a stride-2 layer read zeros),
+//   * bias and an addend (residual fan-in of gradients) in the epilogue, which bounces each 32x32 accumulator through a
+//     wave-private LDS tile and leaves as 8/16-byte row segments (mfma.h: tile_store_rows).
+// T = bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32: the exact parity mode), same code (mfma.h: Mma<T>).
+// Roofline: MFMA for the 3x3 layers (K = 9 Cin >= 576: >= 250 FLOP/B), HBM for the 16/32-channel decoder tail.
+#include "mfma.h"
+
+namespace {
+
+struct UConvP {
+  const char* X1; int64_t ld1; int C1; int up1;
+  const char* X2; int64_t ld2; int C2;
+  const char* Wp;
+  const float* bias;
+  const void* add; int64_t ld_add;
+  void* Y; int64_t ld_y;
+  int B, Hin, Win, Hout, Wout, Cin, Cout, Npad, k, stride, transposed;
+  int64_t P;   // output pixels
+};
+
+template <typename T, int BM, int BN, int KB, int WM, int WN>
+__global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int RS = KB + 16;               // LDS row stride (bytes)
+  constexpr int PIECES = KB / 16;           // 16-byte pieces per row
+  constexpr int RPP = 256 / PIECES;         // rows staged per pass of the workgroup
+  constexpr int AP = (BM + RPP - 1) / RPP;
+  constexpr int BP = (BN + RPP - 1) / RPP;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int EPC = KB / ES;              // elements per chunk
+  constexpr int STAGE = (BM + BN) * RS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int piece = tid % PIECES, r0 = tid / PIECES;
+  const int pad = p.k >> 1;
+  const int s2 = p.stride == 2 ? 1 : 0;
+  const int H1 = p.Hin >> p.up1, W1 = p.Win >> p.up1;
+
+  // the output pixels whose input rows this thread stages
+  int oy[AP], ox[AP];
+  int64_t b1[AP], b2[AP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int row = r0 + j * RPP;
+    const int64_t m = m0 + row;
+    if (row < BM && m < p.P) {
+      ox[j] = (int)(m % p.Wout);
+      const int64_t t = m / p.Wout;
+      oy[j] = (int)(t % p.Hout);
+      const int64_t b = t / p.Hout;
+      b1[j] = b * H1 * W1;
+      b2[j] = b * p.Hin * p.Win;
+    } else {
+      ox[j] = oy[j] = -(1 << 20);
+      b1[j] = b2[j] = 0;
+    }
+  }
+
+  const int CH = p.Cin / EPC;                 // chunks per tap
+  const int NIT = p.k * p.k * CH;
+  u32x4_a4 ra[AP], rb[BP];
+
+  auto fetch = [&](int tap, int ch) {
+    const int ky = tap / p.k, kx = tap - ky * p.k;
+    const int c0 = ch * EPC;
+    const bool first = c0 < p.C1;
+    const char* base = first ? p.X1 : p.X2;
+    const int64_t ld = first ? p.ld1 : p.ld2;
+    const int cc = (first ? c0 : c0 - p.C1) + piece * (16 / ES);
+    const int up = first ? p.up1 : 0;
+    const int Ws = first ? W1 : p.Win;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      int iy, ix;
+      bool ok;
+      if (p.transposed) {
+        const int ty = oy[j] + pad - ky, tx = ox[j] + pad - kx;
+        ok = ty >= 0 && tx >= 0 && ((ty | tx) & s2) == 0;
+        iy = ty >> s2; ix = tx >> s2;
+        ok = ok && iy < p.Hin && ix < p.Win;
+      } else {
+        iy = oy[j] * p.stride + ky - pad; ix = ox[j] * p.stride + kx - pad;
+        ok = iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
+      }
+      const u32x4_a4 z = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const int64_t pix = (first ? b1[j] : b2[j]) + (int64_t)(iy >> up) * Ws + (ix >> up);
+        ra[j] = *reinterpret_cast<const u32x4_a4*>(base + (pix * ld + cc) * ES);
+      } else {
+        ra[j] = z;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const int row = r0 + j * RPP;
+      const u32x4_a4 z = {0u, 0u, 0u, 0u};
+      if (row < BN)   // Npad is a multiple of BN: every staged weight row exists (zero rows beyond Cout)
+        rb[j] = *reinterpret_cast<const u32x4_a4*>(p.Wp + (((int64_t)tap * p.Npad + n0 + row) * p.Cin + c0) * ES + piece * 16);
+      else
+        rb[j] = z;
+    }
+  };
+  auto stash = [&](int buf) {
+    char* A = smem + buf * STAGE;
+    char* Bt = A + BM * RS;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+      const int row = r0 + j * RPP;
+      if (row < BM) *reinterpret_cast<u32x4_a4*>(A + row * RS + piece * 16) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const int row = r0 + j * RPP;
+      if (row < BN) *reinterpret_cast<u32x4_a4*>(Bt + row * RS + piece * 16) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  int tap = 0, ch = 0;
+  fetch(0, 0);
+  stash(0);
+  __syncthreads();
+  for (int it = 0; it < NIT; ++it) {
+    int ntap = tap, nch = ch + 1;
+    if (nch == CH) { nch = 0; ++ntap; }
+    const bool more = it + 1 < NIT;
+    if (more) fetch(ntap, nch);
+    const char* A = smem + (it & 1) * STAGE + (wm * TM * 32 + r) * RS + h * 16;
+    const char* Bt = smem + (it & 1) * STAGE + BM * RS + (wn * TN * 32 + r) * RS + h * 16;
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      Pack16 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::mma(acc[i][j], a[i], b[j]);
+    }
+    if (more) stash((it + 1) & 1);
+    __syncthreads();
+    tap = ntap; ch = nch;
+  }
+
+  // epilogue: rows of D leave as 8/16-byte segments through a wave-private 4 KB bounce tile
+  float* eps = reinterpret_cast<float*>(smem + wave * 4096);
+  TileEpilogue e;
+  e.R = p.add; e.ldr = p.ld_add;
+  e.Xa = nullptr; e.ldxa = 0; e.act = 0;
+  e.Y = p.Y; e.ldy = p.ld_y;
+  e.Acc = nullptr; e.ldacc = 0;
+  e.Yf32 = nullptr; e.ldf = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col0 = n0 + (wn * TN + j) * 32;
+      if (col0 >= p.Cout) continue;
+      float vals[16];
+      const float bv = (p.bias && col0 + r < p.Cout) ? p.bias[col0 + r] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) vals[v] = acc[i][j][v] + bv;
+      tile_store_rows<T>(eps, vals, lane, m0 + (wm * TM + i) * 32, p.P, col0, p.Cout, e);
+    }
+}
+
+template <typename T, int BM, int BN, int KB, int WM, int WN>
+int launch(const UConvP& p, hipStream_t st) {
+  constexpr int RS = KB + 16;
+  size_t lds = (size_t)2 * (BM + BN) * RS;
+  if (lds < 16384) lds = 16384;
+  const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)(p.Npad / BN));
+  hipLaunchKernelGGL((uconv_kernel<T, BM, BN, KB, WM, WN>), grid, dim3(256), lds, st, p);
+  return rdst_launch_status("rdst_u_conv");
+}
+
+template <typename T, int KB>
+int pick_bn(const UConvP& p, hipStream_t st) {
+  if (p.Npad % 128 == 0) return launch<T, 128, 128, KB, 2, 2>(p, st);
+  if (p.Npad % 64 == 0) return launch<T, 128, 64, KB, 2, 2>(p, st);
+  return launch<T, 128, 32, KB, 4, 1>(p, st);
+}
+
+template <typename T>
+int pick_kb(const UConvP& p, hipStream_t st) {
+  const int es = (int)sizeof(T);
+  auto fits = [&](int kb) { return (p.Cin * es) % kb == 0 && (p.C1 * es) % kb == 0; };
+  if (fits(128)) return pick_bn<T, 128>(p, st);
+  if (fits(64)) return pick_bn<T, 64>(p, st);
+  if (fits(32)) return pick_bn<T, 32>(p, st);
+  return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: (C1 + C2) * elementsize = %d must be a multiple of 32 bytes (C1 = %d)", p.Cin * es, p.C1);
+}
+
+}  // namespace
+
+extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const void* X2, int64_t ld2, int C2, const void* Wp,
+                           const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win,
+                           int Hout, int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream) {
+  if (!X1 || !Wp || !Y) return rdst_fail(RDST_EINVAL, "rdst_u_conv: null pointer");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad dtype %d", dtype);
+  if (B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0)
+    return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad shape");
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: k = %d stride = %d", ksize, stride);
+  if (Npad < Cout || Npad % 32) return rdst_fail(RDST_EINVAL, "rdst_u_conv: Npad = %d (Cout = %d rounded up to 32)", Npad, Cout);
+  if (C2 > 0 && !X2) return rdst_fail(RDST_EINVAL, "rdst_u_conv: C2 > 0 without a second source");
+  if (up1 && ((Hin | Win) & 1)) return rdst_fail(RDST_EINVAL, "rdst_u_conv: upsampled source needs even Hin, Win");
+  if (ld1 < C1 || (C2 > 0 && ld2 < C2) || ld_y < Cout || (add && ld_add < Cout)) return rdst_fail(RDST_EINVAL, "rdst_u_conv: leading dimension too small");
+  const int es = dtype == RDST_F32 ? 4 : 2;
+  if (((uintptr_t)X1 | (uintptr_t)X2 | (uintptr_t)Wp) & 3 || (ld1 * es) % 4 || (ld2 * es) % 4)
+    return rdst_fail(RDST_EINVAL, "rdst_u_conv: sources must be dword aligned");
+  UConvP p;
+  p.X1 = (const char*)X1; p.ld1 = ld1; p.C1 = C1; p.up1 = up1 ? 1 : 0;
+  p.X2 = (const char*)X2; p.ld2 = ld2; p.C2 = C2;
+  p.Wp = (const char*)Wp; p.bias = bias; p.add = add; p.ld_add = ld_add; p.Y = Y; p.ld_y = ld_y;
+  p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.Cin = C1 + C2; p.Cout = Cout; p.Npad = Npad;
+  p.k = ksize; p.stride = stride; p.transposed = transposed ? 1 : 0;
+  p.P = (int64_t)B * Hout * Wout;
+  return dtype == RDST_F32 ? pick_kb<float>(p, (hipStream_t)stream) : pick_kb<bf16>(p, (hipStream_t)stream);
+}

@@ -44,8 +44,10 @@ class DropPath(nn.Module):
         self.scale_by_keep = scale_by_keep
 
     def mask(self, x):
+        """Per-sample keep mask, drawn AND scaled in fp32 whatever the activation dtype: in bf16 1 / keep would be
+        rounded (1 / 0.9 -> 1.109375, -0.16 %) and every kept branch would carry that bias (E[mask] != 1)."""
         keep = 1.0 - self.drop_prob
-        m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        m = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=torch.float32, device=x.device).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             m.div_(keep)
         return m
@@ -53,7 +55,7 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0. or not self.training:
             return x
-        return x * self.mask(x)
+        return (x.float() * self.mask(x)).to(x.dtype)    # fp32 product, one rounding back to the activation dtype
 
     def extra_repr(self):
         return f"drop_prob={round(self.drop_prob, 3):0.3f}"

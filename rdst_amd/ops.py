@@ -11,6 +11,7 @@ Parameters are always fp32; activations are fp32 (parity mode) or bf16 (throughp
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import Optional
 
@@ -101,13 +102,17 @@ class PackPlan:
     """The bf16 fragment images of all the weights a network's forward reads (rdst_pack_batch, include/rdst_hip.h).
     Discovered on one forward (every op reports the pack it just did for itself), then refreshed as a whole at the start
     of each later forward; an op that finds its weights in the plan passes the image with workspace_bytes = PREPACKED.
-    A plan is only used while every recorded tensor still lives at its recorded address."""
+    A plan is only used while every parameter of the owning module still has the dtype and lives at the address it had
+    when the plan was recorded (``valid(owner)``): re-pointing ``p.data`` (FlatAdam's flat buffer), ``.to()`` or ``.half()``
+    drops the plan and the next forward rediscovers it.  Plans live in a module-level WeakKeyDictionary keyed by the
+    owner, never in the module's ``__dict__``: ``copy.deepcopy(net)`` / ``torch.save(net)`` neither see nor share them."""
 
     def __init__(self):
         self.keys, self.specs, self.tensors = {}, [], []
         self.arena = None
         self.jobs = None
         self.misses = 0
+        self.owner_sig = None
 
     @staticmethod
     def _key(kind, w, lw, lb, b, N, K, s):
@@ -135,9 +140,14 @@ class PackPlan:
             return None
         return self.arena.data_ptr() + self.offsets[i]
 
-    def finalize(self, device):
+    @staticmethod
+    def signature(owner):
+        return (getattr(owner, "compute_dtype", None),) + tuple((p.data_ptr(), p.dtype) for p in owner.parameters())
+
+    def finalize(self, device, owner=None):
         if not self.specs:
             return False
+        self.owner_sig = self.signature(owner) if owner is not None else None
         total = sum(sp[4] for sp in self.specs)
         self.arena = torch.empty(total, dtype=torch.uint8, device=device)
         self.jobs = (_lib.PackJob * len(self.specs))()
@@ -151,7 +161,10 @@ class PackPlan:
         self.ptrs = [tuple(_ptr(t) or 0 for t in ts) for ts in self.tensors]
         return True
 
-    def valid(self):
+    def valid(self, owner=None):
+        """The LIVE parameters of the owner are where (and what) they were when the plan was recorded."""
+        if owner is not None and self.owner_sig is not None and self.signature(owner) != self.owner_sig:
+            return False
         return all(tuple(_ptr(t) or 0 for t in ts) == p for ts, p in zip(self.tensors, self.ptrs))
 
     def run(self):
@@ -169,6 +182,11 @@ class PackPlan:
 
 _plan_active: Optional[PackPlan] = None
 _plan_recording: Optional[PackPlan] = None
+_PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # owner module -> PackPlan
+
+
+def pack_plan_of(owner) -> Optional[PackPlan]:
+    return _PLANS.get(owner)
 PACK_LINEAR, PACK_CONV3_FWD = 0, 1
 
 
@@ -183,8 +201,11 @@ class pack_scope:
         self.outer = (_plan_active, _plan_recording)
         if self.outer != (None, None):     # nested network forwards share the outer scope
             return self
-        plan = getattr(self.owner, "_rdst_pack_plan", None)
-        if plan is not None and plan.valid():
+        plan = _PLANS.get(self.owner)
+        if plan is not None and not plan.valid(self.owner):
+            _PLANS.pop(self.owner, None)     # parameters moved or changed dtype: frees the stale arena and weight copies
+            plan = None
+        if plan is not None:
             plan.misses = 0
             plan.run()
             _plan_active = plan
@@ -200,9 +221,12 @@ class pack_scope:
         _plan_active = _plan_recording = None
         if rec is not None and exc[0] is None:
             dev = next(self.owner.parameters()).device
-            self.owner._rdst_pack_plan = rec if rec.finalize(dev) else None
+            if rec.finalize(dev, self.owner):
+                _PLANS[self.owner] = rec
+            else:
+                _PLANS.pop(self.owner, None)
         if act is not None and act.misses:
-            self.owner._rdst_pack_plan = None    # the forward took another path than the recorded one: rediscover
+            _PLANS.pop(self.owner, None)         # the forward took another path than the recorded one: rediscover
         return False
 
 

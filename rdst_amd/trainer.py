@@ -30,9 +30,17 @@ GUARD_OFF = 1e8   # config_files/RDST_E1_OASIS_example_SRx4.ini:136
 
 
 class DPTrainStep:
+    """``loss_fn``: a callable ``(pred, target) -> loss`` (default L1) or an ``SRLoss``-shaped object returning
+    ``(loss, report)`` (rdst_amd.loss.SRLoss: the weighted 'L1' / 'UNet-F' states of the reference trainer).
+    ``graph=True``: after ``graph_warmup`` eager steps on one input shape, forward + loss + backward are captured into ONE
+    HIP graph and every later step of that shape replays it (the collective and the optimizer stay outside, so RCCL
+    keeps its own streams); other shapes, and steps under an active loss-threshold guard, run eagerly.  This is the
+    step ``bench.py`` times."""
+
     def __init__(self, net: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.99), eps: float = 1e-8,
                  weight_decay: float = 0.0, milestones: Optional[Sequence[int]] = None, gamma: float = 0.5,
-                 loss_threshold: float = GUARD_OFF, loss_fn: Optional[Callable] = None, group=None):
+                 loss_threshold: float = GUARD_OFF, loss_fn: Optional[Callable] = None, group=None,
+                 graph: bool = False, graph_warmup: int = 2):
         self.net = net
         self.group = group
         dp.broadcast_parameters(net, group=group)
@@ -42,10 +50,20 @@ class DPTrainStep:
         self.scheduler = (torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=gamma)
                           if milestones else None)
         self.loss_fn = loss_fn if loss_fn is not None else F.l1_loss      # SRLoss 'L1' (loss/sr_loss.py)
-        self.loss_module = loss_fn if isinstance(loss_fn, torch.nn.Module) else torch.nn.Module()
+        # what the reference saves under 'loss' (basic_trainer.py:195): the loss object's own state_dict()
+        self.loss_module = loss_fn if hasattr(loss_fn, "state_dict") else torch.nn.Module()
         self.loss_threshold = float(loss_threshold)
+        self.last_report = None        # the (lazy) per-component report of the last step, SRLoss-shaped losses only
+        # graph capture
+        self.use_graph = bool(graph)
+        self.graph_warmup = int(graph_warmup)
+        self.graph = None
+        self._static = None            # (inputs, targets) the graph reads
+        self._eager_seen = 0
+        self._loss_buf = None
+        self.capture_hook = None       # optional context-manager factory wrapped around the capture (bench.py's Recorder)
         # training state carried by the reference's checkpoints
-        self.training_loss_names = ["L1"] if loss_fn is None else ["loss"]
+        self.training_loss_names = ["L1"] if loss_fn is None else list(getattr(loss_fn, "loss_components", ["loss"]))
         self.training_loss_records: Dict[str, list] = {n: [] for n in self.training_loss_names}
         self.quick_validation_reports: list = []
         self.current_training_state_id = 0
@@ -61,22 +79,93 @@ class DPTrainStep:
             dist.all_reduce(skip, op=dist.ReduceOp.MAX, group=self.group)
         return float(skip.item()) == 0.0
 
+    def _loss(self, out, targets):
+        r = self.loss_fn(out, targets)
+        if isinstance(r, tuple):
+            self.last_report = r[1]
+            return r[0]
+        return r
+
+    def fwd_bwd(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """forward + loss + backward with the gradients written straight into the flat bucket (no host sync inside:
+        capturable).  Returns the loss as a device scalar that is overwritten by the next call."""
+        self.bucket.detach_grads()       # autograd assigns fresh gradients; the HIP ops take the bucket views as destinations
+        out = self.net(inputs)
+        loss = self._loss(out, targets)
+        if self._loss_buf is None:
+            self._loss_buf = torch.zeros((), dtype=torch.float32, device=inputs.device)
+        self._loss_buf.copy_(loss.detach())
+        loss.backward()
+        self.bucket.gather()             # whatever was not written in place is flattened into the bucket
+        return self._loss_buf
+
+    def capture(self, inputs: torch.Tensor, targets: torch.Tensor) -> bool:
+        """Capture fwd_bwd on (copies of) these tensors into a HIP graph.  False (and eager from then on) if the capture
+        fails; the parameters and BatchNorm statistics are not touched by a failed capture."""
+        import contextlib
+        self._static = (inputs.detach().clone(), targets.detach().clone())
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with (self.capture_hook() if self.capture_hook is not None else contextlib.nullcontext()):
+                with torch.cuda.graph(g):
+                    self.fwd_bwd(*self._static)
+        except Exception as e:  # noqa: BLE001 - fall back to eager, loudly
+            import warnings
+            warnings.warn(f"rdst_amd.trainer: HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly")
+            torch.cuda.synchronize()
+            self.use_graph, self.graph, self._static = False, None, None
+            return False
+        if not self.bucket.check_views():
+            self.use_graph, self.graph, self._static = False, None, None
+            return False
+        self.graph = g
+        return True
+
+    def _graph_fits(self, inputs, targets) -> bool:
+        return (self._static is not None and inputs.shape == self._static[0].shape and targets.shape == self._static[1].shape
+                and inputs.dtype == self._static[0].dtype and targets.dtype == self._static[1].dtype)
+
     def step(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         """One iteration of trans_sr_trainer.py:131-178; returns the (device) loss."""
         t0 = time.time()                               # :132
         self.current_epoch += 1                        # :134 — advanced whether or not the update is skipped
         self.net.train()
-        out = self.net(inputs)
-        loss = self.loss_fn(out, targets)
-        if self.loss_threshold >= GUARD_OFF or self._keep_step(loss):   # :162
-            self.optimizer.zero_grad()                 # one memset of the flat bucket
-            loss.backward()
-            self.bucket.all_reduce_mean(self.group)    # no-op on one rank
-            self.optimizer.step()
-            if self.scheduler is not None:
-                self.scheduler.step()
-        self.training_epoch_costs.append(time.time() - t0)   # :176-178 (host-side enqueue time unless the guard synced)
-        return loss.detach()
+        guarded = self.loss_threshold < GUARD_OFF
+        if guarded:
+            # the reference's order: forward, loss, decide, then backward (trans_sr_trainer.py:149-174); one host sync
+            self.bucket.detach_grads()
+            out = self.net(inputs)
+            loss = self._loss(out, targets)
+            if self._keep_step(loss):                  # :162
+                loss.backward()
+                self.bucket.gather()
+                self._finish_step()
+            else:
+                self.bucket.gather()                   # restore p.grad = bucket views (zeros for this step)
+            self.training_epoch_costs.append(time.time() - t0)
+            return loss.detach()
+        if self.use_graph and self.graph is None and self._eager_seen >= self.graph_warmup:
+            self.capture(inputs, targets)
+        if self.graph is not None and self._graph_fits(inputs, targets):
+            if inputs.data_ptr() != self._static[0].data_ptr():
+                self._static[0].copy_(inputs)
+            if targets.data_ptr() != self._static[1].data_ptr():
+                self._static[1].copy_(targets)
+            self.graph.replay()
+            loss = self._loss_buf
+        else:
+            loss = self.fwd_bwd(inputs, targets)
+            self._eager_seen += 1
+        self._finish_step()
+        self.training_epoch_costs.append(time.time() - t0)   # :176-178 (host-side enqueue time: nothing synced)
+        return loss
+
+    def _finish_step(self) -> None:
+        self.bucket.all_reduce_mean(self.group)        # no-op on one rank
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
 
     # ---- models/basic_trainer.py:164-208 -----------------------------------------------------------
     def checkpoint(self) -> dict:
@@ -105,7 +194,7 @@ class DPTrainStep:
         self.optimizer.load_state_dict(ck["optimizer_g"])
         if self.scheduler is not None and "scheduler_g" in ck:
             self.scheduler.load_state_dict(ck["scheduler_g"])
-        if "loss" in ck and len(ck["loss"]) and isinstance(self.loss_module, torch.nn.Module):
+        if "loss" in ck and len(ck["loss"]) and hasattr(self.loss_module, "load_state_dict"):
             self.loss_module.load_state_dict(ck["loss"])
         self.training_loss_names = ck.get("training_loss_names", self.training_loss_names)
         self.training_loss_records = ck.get("training_loss_records", self.training_loss_records)

@@ -9,8 +9,9 @@ pinned to the reference, swin_transformer_sr.py:110-141) or with plain fp32 torc
 (Linear / Mlp / conv: nn.Linear, nn.LayerNorm, nn.GELU, nn.Conv2d + PixelShuffle exactly as the reference composes
 them, rdst_variations.py:335-341,420-445, common.py:125-136).
 
-Tolerance (bf16 storage = 8 significant bits, fp32 accumulation): relative L2 <= 2e-2 on every output and gradient
-(measured values are printed with -s; they sit at 2e-3..6e-3), identical bf16-representable inputs on both sides."""
+Tolerance (bf16 storage = 8 significant bits, fp32 accumulation): relative L2 <= 8e-3 on every output and gradient
+(measured values are printed with -s; they sit at 1.4e-3..4e-3: a 2x regression fails), identical bf16-representable
+inputs on both sides."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -20,7 +21,7 @@ from util import rand
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = 2e-2
+TOL = 8e-3
 B_FULL, HW = 32, 64
 M_FULL = B_FULL * HW * HW          # 131072 tokens = 4096 tiles of 32 = 2048 windows of 8x8
 
@@ -251,13 +252,9 @@ def test_conv_bf16_full_size(B, H, W, Cin, Cout, res, scale, r):
 # ------------------------------------------------------------------------------------------------------------------
 # The network: RDST-E1 x4 (BASELINE.json configs[1] architecture), bf16, forward + L1 + backward vs the oracle
 # ------------------------------------------------------------------------------------------------------------------
-def test_e1_bf16_train_step_all_gradients_vs_oracle():
-    """Every one of the 750 trainable tensors' gradients against the fp32 oracle (rdst_variations.py:1342-1360), batch 8
-    of 64x64 (512 windows: every persistent workgroup loops).  bf16 activations through 48 Swin blocks: stated tolerance
-    rel L2 <= 5e-2 per tensor (most sit near 1e-2), total gradient rel L2 <= 2e-2, |dPSNR| < 0.05 dB (printed)."""
+def _e1_all_gradients(B):
     from util import build_net
     cfg = O.CFG_E1
-    B = 8
     sd = O.make_weights(cfg, 11)
     net = build_net(cfg)
     net.load_state_dict(sd, strict=True)
@@ -293,7 +290,7 @@ def test_e1_bf16_train_step_all_gradients_vs_oracle():
         rel = d / max(rn, 1e-12)
         if rel > worst[0]:
             worst = (rel, k)
-        if rel > 5e-2:
+        if rel > 3e-2:
             bad.append((k, rel))
     total = (tot_d / tot_r) ** 0.5
     print(f"\nE1 bf16 B={B}: |dPSNR| {dpsnr:.2e} dB  out max|d| {(yc - oy.detach()).abs().max().item():.2e}  "
@@ -301,15 +298,27 @@ def test_e1_bf16_train_step_all_gradients_vs_oracle():
           f"({worst[1]})")
     assert n == 750
     assert dpsnr < 0.05 and abs(loss.item() - oloss.item()) <= 2e-3
-    assert total <= 2e-2
+    assert total <= 1.2e-2
     assert not bad, bad[:10]
+
+
+def test_e1_bf16_train_step_all_gradients_vs_oracle():
+    """Every one of the 750 trainable tensors' gradients against the fp32 oracle (rdst_variations.py:1342-1360), batch 8
+    of 64x64 (512 windows: every persistent workgroup loops).  bf16 activations through 48 Swin blocks: stated tolerance
+    rel L2 <= 3e-2 per tensor (most sit near 1e-2), total gradient rel L2 <= 1.2e-2, |dPSNR| < 0.05 dB (printed)."""
+    _e1_all_gradients(8)
+
+
+def test_e1_bf16_train_step_all_gradients_vs_oracle_bench_batch():
+    """The same at THE batch bench.py runs (BASELINE configs[1]: B = 32, 2048 windows per Swin block)."""
+    _e1_all_gradients(32)
 
 
 def test_ws16_bf16_train_step_all_gradients_vs_oracle():
     """BASELINE configs[3] (3-channel x2, 128x128 -> 256x256, window 16, the E1 widths) in the bf16 mode: every trainable
     tensor's gradient against the fp32 oracle, batch 2 (128 windows per layer: wattn16_mfma.hip forward and backward in all
     48 Swin blocks, shifted and not, with the region masks of the last window row / column).  Same stated tolerances as the
-    E1 test: rel L2 <= 5e-2 per tensor, total <= 2e-2, |dPSNR| < 0.05 dB."""
+    E1 test: rel L2 <= 3e-2 per tensor, total <= 1.2e-2, |dPSNR| < 0.05 dB."""
     from util import build_net
     cfg = O.CFG_WS16
     B = 2
@@ -347,7 +356,7 @@ def test_ws16_bf16_train_step_all_gradients_vs_oracle():
         rel = d / max(rn, 1e-12)
         if rel > worst[0]:
             worst = (rel, k)
-        if rel > 5e-2:
+        if rel > 3e-2:
             bad.append((k, rel))
     total = (tot_d / tot_r) ** 0.5
     print(f"\nws16 bf16 B={B}: |dPSNR| {dpsnr:.2e} dB  out max|d| {(yc - oy.detach()).abs().max().item():.2e}  "
@@ -355,5 +364,5 @@ def test_ws16_bf16_train_step_all_gradients_vs_oracle():
           f"({worst[1]})")
     assert n == sum(1 for v in osd.values() if v.requires_grad) == 748   # one PixelShuffle stage (x2): two tensors fewer than E1
     assert dpsnr < 0.05 and abs(loss.item() - oloss.item()) <= 2e-3
-    assert total <= 2e-2
+    assert total <= 1.2e-2
     assert not bad, bad[:10]

@@ -52,7 +52,7 @@ def test_lnlin3_bwd_vs_torch(K, N, ln, M, with_add):
                                       dlw.data_ptr() if ln else None, dlb.data_ptr() if ln else None, wsp.data_ptr(), nws,
                                       M, K, N, 1.0, _lib.BF16, st), "rdst_ln_linear_bwd")
     torch.cuda.synchronize()
-    tol = 2e-2   # bf16 operands, fp32 accumulation, bf16 dX / slabs: the bound of the other bf16 kernel tests
+    tol = 8e-3   # bf16 operands, fp32 accumulation, bf16 dX / slabs: the bound of the other bf16 kernel tests
     assert torch.isfinite(dx).all()
     assert _rel(dx, want_dx) <= tol
     assert _rel(dW, wr.grad) <= tol and _rel(db, br.grad) <= tol

@@ -65,7 +65,7 @@ def test_mlp_bwd_fused(M, C, hid):
                                 G[1].data_ptr(), G[2].data_ptr(), G[3].data_ptr(), G[4].data_ptr(), G[5].data_ptr(),
                                 wsp.data_ptr(), nb, M, C, hid, _lib.BF16, st), "rdst_mlp_bwd")
     torch.cuda.synchronize()
-    tol = 2e-2   # bf16 operands, fp32 accumulation; the same bound test_ops_gpu.py uses for the unfused bf16 kernels
+    tol = 8e-3   # bf16 operands, fp32 accumulation; the same bound test_ops_gpu.py uses for the unfused bf16 kernels
     assert _rel(dx, gref[0]) <= tol
     for got, want, name in zip(G, (gref[3], gref[4], gref[5], gref[6], gref[1], gref[2]),
                                ("dW1", "db1", "dW2", "db2", "dln_w", "dln_b")):

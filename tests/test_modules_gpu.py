@@ -195,11 +195,14 @@ def test_full_size_batch_independence_properties():
         assert (yp - y[perm]).abs().max().item() <= tol
 
 
-def test_full_size_gradient_linearity_over_batch():
-    """fwd+bwd at the BASELINE shape in fp32: with a sum-reduced loss the parameter gradient of the full batch
-    equals the sum of the gradients of its two halves (linearity of backprop over independent patches)."""
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-3)])
+def test_full_size_gradient_linearity_over_batch(dtype, tol):
+    """fwd+bwd at the BASELINE shape (B = 32) in both arithmetic modes: with a sum-reduced loss the parameter gradient of the
+    full batch equals the sum of the gradients of its two halves (linearity of backprop over independent patches).  bf16:
+    the per-patch arithmetic is identical in both runs (patches never interact), only the fp32 accumulation order of the
+    weight-gradient slabs differs — plus the bf16 rounding of the partial slabs."""
     import bench
-    net = bench.build_net(torch.device(DEV), torch.float32)
+    net = bench.build_net(torch.device(DEV), dtype)
     g = torch.Generator().manual_seed(6)
     x = torch.rand(32, 1, 64, 64, generator=g).to(DEV)
     w = torch.randn(32, 1, 256, 256, generator=g).to(DEV)
@@ -217,7 +220,7 @@ def test_full_size_gradient_linearity_over_batch():
     for k in keys:
         ref = full[k]
         err = (a[k] + b[k] - ref).norm().item() / max(ref.norm().item(), 1e-12)
-        assert err <= 2e-4, (k, err)
+        assert err <= tol, (k, err)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -24,7 +24,7 @@ for it in range(3):
     with torch.no_grad():
         net(x)
     torch.cuda.synchronize()
-    plan = getattr(net, "_rdst_pack_plan", None)
+    plan = ops.pack_plan_of(net)
     print(f"forward {it}: plan specs {None if plan is None else len(plan.specs)} misses {None if plan is None else plan.misses}")
     for k, v in sorted(log.items()):
         print("   ", k, v)
