@@ -292,6 +292,9 @@ def main():
     ap.add_argument("--config", default="e1", choices=sorted(CONFIGS), help="e1 = the BASELINE.json metric (default)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--unet-dtype", default=None, choices=["fp32", "fp32x3", "bf16"],
+                    help="arithmetic of the seg-UNet loss network (e1_unetf / e1_hrl); default fp32x3: fp32 activations, 3-term bf16 "
+                         "split on the matrix cores (the features of SR and HR are DIFFERENCED: bf16 activations are too noisy)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3, help="replay passes over the recorded launches")
@@ -327,8 +330,10 @@ def main():
         args.batch = 8 if args.config == "ws16" else 32
     net = build_net(device, dtype, cfg)
     loss_obj = build_loss(args.config, device)
+    unet_dtype = None
     if loss_obj is not None:
-        loss_obj.loss_functions["UNet-F"].set_compute_dtype(dtype)
+        unet_dtype = args.unet_dtype or "fp32x3"
+        loss_obj.loss_functions["UNet-F"].set_compute_dtype(unet_dtype)
     # the trainer-step shell a user calls (rdst_amd/trainer.py): flat bucket, one all-reduce, fused Adam with
     # utils/optim.py:30-53's hyper-parameters from the ini; forward + loss + backward replayed from ONE HIP graph
     tr = DPTrainStep(net, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, loss_fn=loss_obj, graph=False)
@@ -398,7 +403,7 @@ def main():
         "config": {"workload": cfg_name + f", step = fwd + {step_desc} + bwd + flat-bucket grad all-reduce + Adam",
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "hip_graph": tr.graph is not None, "grad_bucket_bytes": bucket.nbytes,
-                   "backend": (args.backend if world > 1 else None)},
+                   "backend": (args.backend if world > 1 else None), "unet_dtype": unet_dtype},
         "loss": round(loss_val, 6),
     }
     if param_sync is not None:

@@ -31,6 +31,8 @@ extern "C" {
 
 #define RDST_F32 0
 #define RDST_BF16 1
+#define RDST_F32X3 2   /* rdst_u_* only: fp32 rows; convolutions as a 3-term bf16 split (hi.hi + hi.lo + lo.hi) on the matrix
+                          cores, ~1e-5 relative; every other rdst_u_* entry point treats it as RDST_F32 */
 
 #define RDST_EINVAL (-10001)
 #define RDST_ENOTSUP (-10002)

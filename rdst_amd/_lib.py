@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # is the in-tree release library, and a missing file raises either way
 LIB_PATH = os.environ.get("RDST_HIP_LIB") or os.path.join(_HERE, "librdst_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 EINVAL, ENOTSUP = -10001, -10002
 ACT_NONE, ACT_GELU, ACT_LEAKY02, ACT_LEAKY001 = 0, 1, 2, 3
 

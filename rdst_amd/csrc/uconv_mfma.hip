@@ -13,6 +13,11 @@
 //   * bias and an addend (residual fan-in of gradients) in the epilogue, which bounces each 32x32 accumulator through a
 //     wave-private LDS tile and leaves as 8/16-byte row segments (mfma.h: tile_store_rows).
 // T = bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32: the exact parity mode), same code (mfma.h: Mma<T>).
+// SPLIT (RDST_F32X3, the default of the loss network): fp32 rows in HBM, but every staged 16-byte piece is split into
+// bf16 (hi, lo = x - hi) halves on its way into LDS and a k-step is THREE bf16 MFMAs (hi.lo + lo.hi + hi.hi; the dropped lo.lo
+// term is 2^-16 relative): products good to ~1e-5 at 3/16 of the fp32-MFMA cost.  Why not plain bf16: the loss DIFFERENCES
+// the features of SR and HR, and bf16 activations through 50 train-mode BatchNorm layers carry 1e-2..1e-1 relative error —
+// as large as that difference late in training (measured: gradient cosine 0.58 against fp32, tools/segunet_bf16_trace.py).
 // Roofline: MFMA for the 3x3 layers (K = 9 Cin >= 576: >= 250 FLOP/B), HBM for the 16/32-channel decoder tail.
 #include "mfma.h"
 
@@ -29,8 +34,9 @@ struct UConvP {
   int64_t P;   // output pixels
 };
 
-template <typename T, int BM, int BN, int KB, int WM, int WN>
+template <typename T, int BM, int BN, int KB, int WM, int WN, bool SPLIT>
 __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
+  static_assert(!SPLIT || (sizeof(T) == 4 && KB >= 64), "the split mode stages fp32 rows, 16 elements per k-step");
   constexpr int ES = (int)sizeof(T);
   constexpr int RS = KB + 16;               // LDS row stride (bytes)
   constexpr int PIECES = KB / 16;           // 16-byte pieces per row
@@ -116,18 +122,32 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
         rb[j] = z;
     }
   };
+  // SPLIT: a row of the LDS tile is [hi: KB/2 bytes of bf16][lo: KB/2 bytes of bf16]; a piece (4 floats) lands as 8 + 8 bytes
+  auto put = [&](char* rowp, const u32x4_a4& v) {
+    if (SPLIT) {
+      const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+      u32x2_a4 hi, lo;
+      hi.x = pack_bf16x2(f0, f1); hi.y = pack_bf16x2(f2, f3);
+      lo.x = pack_bf16x2(f0 - bf16lo(hi.x), f1 - bf16hi(hi.x));
+      lo.y = pack_bf16x2(f2 - bf16lo(hi.y), f3 - bf16hi(hi.y));
+      *reinterpret_cast<u32x2_a4*>(rowp + piece * 8) = hi;
+      *reinterpret_cast<u32x2_a4*>(rowp + KB / 2 + piece * 8) = lo;
+    } else {
+      *reinterpret_cast<u32x4_a4*>(rowp + piece * 16) = v;
+    }
+  };
   auto stash = [&](int buf) {
     char* A = smem + buf * STAGE;
     char* Bt = A + BM * RS;
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       const int row = r0 + j * RPP;
-      if (row < BM) *reinterpret_cast<u32x4_a4*>(A + row * RS + piece * 16) = ra[j];
+      if (row < BM) put(A + row * RS, ra[j]);
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int row = r0 + j * RPP;
-      if (row < BN) *reinterpret_cast<u32x4_a4*>(Bt + row * RS + piece * 16) = rb[j];
+      if (row < BN) put(Bt + row * RS, rb[j]);
     }
   };
 
@@ -150,17 +170,42 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
     if (more) fetch(ntap, nch);
     const char* A = smem + (it & 1) * STAGE + (wm * TM * 32 + r) * RS + h * 16;
     const char* Bt = smem + (it & 1) * STAGE + BM * RS + (wn * TN * 32 + r) * RS + h * 16;
+    if (SPLIT) {
 #pragma unroll
-    for (int kk = 0; kk < KB / 32; ++kk) {
-      Pack16 a[TM], b[TN];
+      for (int kk = 0; kk < KB / 64; ++kk) {   // 16 elements per k-step: 32 bytes of the hi half, 32 of the lo half
+        Pack16 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 32);
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 32);
+          al[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + KB / 2 + kk * 32);
+        }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 32);
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 32);
+          bl[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + KB / 2 + kk * 32);
+        }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::mma(acc[i][j], a[i], b[j]);
+          for (int j = 0; j < TN; ++j) {
+            Mma<bf16>::mma(acc[i][j], ah[i], bl[j]);
+            Mma<bf16>::mma(acc[i][j], al[i], bh[j]);
+            Mma<bf16>::mma(acc[i][j], ah[i], bh[j]);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KB / 32; ++kk) {
+        Pack16 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 32);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::mma(acc[i][j], a[i], b[j]);
+      }
     }
     if (more) stash((it + 1) & 1);
     __syncthreads();
@@ -189,31 +234,33 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
     }
 }
 
-template <typename T, int BM, int BN, int KB, int WM, int WN>
+template <typename T, int BM, int BN, int KB, int WM, int WN, bool SPLIT>
 int launch(const UConvP& p, hipStream_t st) {
   constexpr int RS = KB + 16;
   size_t lds = (size_t)2 * (BM + BN) * RS;
   if (lds < 16384) lds = 16384;
   const dim3 grid((unsigned)((p.P + BM - 1) / BM), (unsigned)(p.Npad / BN));
-  hipLaunchKernelGGL((uconv_kernel<T, BM, BN, KB, WM, WN>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((uconv_kernel<T, BM, BN, KB, WM, WN, SPLIT>), grid, dim3(256), lds, st, p);
   return rdst_launch_status("rdst_u_conv");
 }
 
-template <typename T, int KB>
+template <typename T, int KB, bool SPLIT>
 int pick_bn(const UConvP& p, hipStream_t st) {
-  if (p.Npad % 128 == 0) return launch<T, 128, 128, KB, 2, 2>(p, st);
-  if (p.Npad % 64 == 0) return launch<T, 128, 64, KB, 2, 2>(p, st);
-  return launch<T, 128, 32, KB, 4, 1>(p, st);
+  if (p.Npad % 128 == 0) return launch<T, 128, 128, KB, 2, 2, SPLIT>(p, st);
+  if (p.Npad % 64 == 0) return launch<T, 128, 64, KB, 2, 2, SPLIT>(p, st);
+  return launch<T, 128, 32, KB, 4, 1, SPLIT>(p, st);
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 int pick_kb(const UConvP& p, hipStream_t st) {
   const int es = (int)sizeof(T);
   auto fits = [&](int kb) { return (p.Cin * es) % kb == 0 && (p.C1 * es) % kb == 0; };
-  if (fits(128)) return pick_bn<T, 128>(p, st);
-  if (fits(64)) return pick_bn<T, 64>(p, st);
-  if (fits(32)) return pick_bn<T, 32>(p, st);
-  return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: (C1 + C2) * elementsize = %d must be a multiple of 32 bytes (C1 = %d)", p.Cin * es, p.C1);
+  if (fits(128)) return pick_bn<T, 128, SPLIT>(p, st);
+  if (fits(64)) return pick_bn<T, 64, SPLIT>(p, st);
+  if constexpr (!SPLIT)
+    if (fits(32)) return pick_bn<T, 32, false>(p, st);
+  return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: (C1 + C2) * elementsize = %d must be a multiple of %d bytes (C1 = %d)", p.Cin * es,
+                   SPLIT ? 64 : 32, p.C1);
 }
 
 }  // namespace
@@ -222,7 +269,7 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
                            const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win,
                            int Hout, int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream) {
   if (!X1 || !Wp || !Y) return rdst_fail(RDST_EINVAL, "rdst_u_conv: null pointer");
-  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad dtype %d", dtype);
+  if (dtype != RDST_F32 && dtype != RDST_BF16 && dtype != RDST_F32X3) return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad dtype %d", dtype);
   if (B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0)
     return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad shape");
   if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: k = %d stride = %d", ksize, stride);
@@ -230,7 +277,7 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
   if (C2 > 0 && !X2) return rdst_fail(RDST_EINVAL, "rdst_u_conv: C2 > 0 without a second source");
   if (up1 && ((Hin | Win) & 1)) return rdst_fail(RDST_EINVAL, "rdst_u_conv: upsampled source needs even Hin, Win");
   if (ld1 < C1 || (C2 > 0 && ld2 < C2) || ld_y < Cout || (add && ld_add < Cout)) return rdst_fail(RDST_EINVAL, "rdst_u_conv: leading dimension too small");
-  const int es = dtype == RDST_F32 ? 4 : 2;
+  const int es = dtype == RDST_BF16 ? 2 : 4;
   if (((uintptr_t)X1 | (uintptr_t)X2 | (uintptr_t)Wp) & 3 || (ld1 * es) % 4 || (ld2 * es) % 4)
     return rdst_fail(RDST_EINVAL, "rdst_u_conv: sources must be dword aligned");
   UConvP p;
@@ -240,5 +287,6 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
   p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.Cin = C1 + C2; p.Cout = Cout; p.Npad = Npad;
   p.k = ksize; p.stride = stride; p.transposed = transposed ? 1 : 0;
   p.P = (int64_t)B * Hout * Wout;
-  return dtype == RDST_F32 ? pick_kb<float>(p, (hipStream_t)stream) : pick_kb<bf16>(p, (hipStream_t)stream);
+  if (dtype == RDST_F32X3) return pick_kb<float, true>(p, (hipStream_t)stream);
+  return dtype == RDST_F32 ? pick_kb<float, false>(p, (hipStream_t)stream) : pick_kb<bf16, false>(p, (hipStream_t)stream);
 }

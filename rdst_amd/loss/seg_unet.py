@@ -33,7 +33,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from .._lib import BF16, F32
+from .._lib import BF16, F32, F32X3
 
 RESNET34_BLOCKS = (3, 4, 6, 3)
 RESNET34_PLANES = (64, 128, 256, 512)
@@ -153,7 +153,7 @@ class _Runner:
         self.m = mod
         self.lib = _lib.load()
         self.dt = mod.compute_dtype
-        self.code = BF16 if self.dt == torch.bfloat16 else F32
+        self.code = mod.compute_code
         self.dev = mod.encoder.conv1.weight.device
         self.scratch = mod._scratch()
         self.packs = mod._packs()
@@ -392,8 +392,9 @@ class _UNetLoss(torch.autograd.Function):
         else:
             fs = r.encoder(sr, 5, save)
             dec_s = r.decoder(fs, save)
-            fh = r.encoder(hr, 5, None)
-            dec_h = r.decoder(fh, None)
+            if mode != "label-gt":                   # 'label-gt' never looks at HR (loss/seg_unet.py:117-123)
+                fh = r.encoder(hr, 5, None)
+                dec_h = r.decoder(fh, None)
             if "decoder" in mode:
                 C = dec_s.shape[-1]
                 _lib.check(lib.rdst_u_pair_loss_fwd(dec_s.data_ptr(), C, dec_h.data_ptr(), C, dec_s.numel() // C, C, int(mod.use_mse), 1.0,
@@ -419,8 +420,10 @@ class _UNetLoss(torch.autograd.Function):
                 _lib.check(lib.rdst_u_dice_fwd(lg_s.data_ptr(), ncls, _ptr(lg_h), ncls, _ptr(labels), P, ncls, cmask, 1e-7, 1.0, 0,
                                                loss.data_ptr(), coef.data_ptr(), r.scratch.data_ptr(), code, st), "rdst_u_dice_fwd")
                 save["dice"] = (lg_s, lg_h, labels, coef, dec_s.shape)
+                if mod.keep_debug:
+                    mod.debug_last = {"sr_logits": lg_s, "hr_logits": lg_h}
                 ctx.kind = "label"
-        mod._count_batches(2)
+        mod._count_batches(1 if mode == "label-gt" else 2)
         return loss
 
     @staticmethod
@@ -505,16 +508,22 @@ class SegUNet_F(nn.Module):
             p.requires_grad_(False)
         self.loss_names = ["SegUNet({})".format(self.loss_mode)]
         self.use_mse = "L1" in self.loss_mode         # loss/seg_unet.py:73-78: 'L1' -> MSELoss, everything else L1Loss
-        self.compute_dtype = torch.float32
+        self.compute_dtype, self.compute_code = torch.float32, F32X3
         self.force_generic = False                    # tests: run layers {0, 1} through the generic UNet path too
+        self.keep_debug = False                       # tests: keep the logits of the last 'label' call in self.debug_last
         self._pack_cache = {}
         self._scratch_buf = None
 
     # ---- plumbing ----------------------------------------------------------------------------------------------------
     def set_compute_dtype(self, dtype):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
-        self.compute_dtype = dtype
+        """'fp32x3' (default): fp32 activations, convolutions as a 3-term bf16 split on the matrix cores (~1e-5 relative);
+        'fp32' / torch.float32: exact fp32 MFMA (the parity mode, 5x slower GEMMs); 'bf16' / torch.bfloat16: bf16 activations
+        (fastest, but the loss DIFFERENCES SR and HR features that then carry 1e-2..1e-1 relative error: noisy gradients)."""
+        table = {"fp32x3": (torch.float32, F32X3), "fp32": (torch.float32, F32), torch.float32: (torch.float32, F32),
+                 "bf16": (torch.bfloat16, BF16), torch.bfloat16: (torch.bfloat16, BF16)}
+        if dtype not in table:
+            raise ValueError("compute dtype must be 'fp32x3', 'fp32' / torch.float32 or 'bf16' / torch.bfloat16")
+        self.compute_dtype, self.compute_code = table[dtype]
         return self
 
     def _scratch(self):
