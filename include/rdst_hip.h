@@ -258,6 +258,8 @@ size_t rdst_u_scratch_bytes(void);
  *            (B, Hin/2, Win/2, C1)) and source 2 (C2 channels, may be NULL / 0) — the UNet decoder's
  *            F.interpolate(x, 2, 'nearest') + torch.cat([x, skip], 1) never materialises;
  *   Wp     = weights in `dtype`, [k*k][Npad][C1 + C2] (reduction index contiguous, Npad = Cout rounded up to 32, zero rows);
+ *            RDST_F32X3: the same bytes per row, as 64-byte groups of [16 bf16 hi][16 bf16 lo] per 16 reduction elements
+ *            (hi = bf16(w), lo = bf16(w - hi)): the frozen weights are split once, on the host;
  *   Y[b, oy, ox, :Cout] = sum_taps in[b, oy*stride + ky - k/2, ox*stride + kx - k/2, :] . Wp[tap] + bias + add
  *   transposed = 1: the data gradient of such a convolution (input = dY in the FORWARD's output geometry (Hin, Win),
  *            output = dX in the forward's input geometry (Hout, Wout)): in[b, (oy + k/2 - ky) / stride, ...] where divisible,

@@ -15,11 +15,14 @@
 // T = bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32: the exact parity mode), same code (mfma.h: Mma<T>).
 // SPLIT (RDST_F32X3, the default of the loss network): fp32 rows in HBM, but every staged 16-byte piece is split into
 // bf16 (hi, lo = x - hi) halves on its way into LDS and a k-step is THREE bf16 MFMAs (hi.lo + lo.hi + hi.hi; the dropped lo.lo
-// term is 2^-16 relative): products good to ~1e-5 at 3/16 of the fp32-MFMA cost.  Why not plain bf16: the loss DIFFERENCES
+// term is 2^-16 relative): products good to ~1e-5 at 3/16 of the fp32-MFMA cost.  The (frozen) weights are split once on
+// the host: Wp rows are 64-byte groups [16 bf16 hi][16 bf16 lo] per 16 reduction elements (same bytes as fp32).  Why not plain bf16: the loss DIFFERENCES
 // the features of SR and HR, and bf16 activations through 50 train-mode BatchNorm layers carry 1e-2..1e-1 relative error —
 // as large as that difference late in training (measured: gradient cosine 0.58 against fp32, tools/segunet_bf16_trace.py).
 // Roofline: MFMA for the 3x3 layers (K = 9 Cin >= 576: >= 250 FLOP/B), HBM for the 16/32-channel decoder tail.
 #include "mfma.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +35,7 @@ struct UConvP {
   void* Y; int64_t ld_y;
   int B, Hin, Win, Hout, Wout, Cin, Cout, Npad, k, stride, transposed;
   int64_t P;   // output pixels
+  int dbg;     // ablation switches (RDST_DEBUG builds only)
 };
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, bool SPLIT>
@@ -58,96 +62,124 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
   const int s2 = p.stride == 2 ? 1 : 0;
   const int H1 = p.Hin >> p.up1, W1 = p.Win >> p.up1;
 
-  // the output pixels whose input rows this thread stages
-  int oy[AP], ox[AP];
-  int64_t b1[AP], b2[AP];
+  // The output pixels whose input rows this thread stages.  cy / cx: the tap-0 input coordinate before the tap offset
+  // (forward: oy * stride - pad, taps ADD ky; transposed: oy + pad, taps SUBTRACT ky, then the stride divides).
+  // Everything a tap needs per row is prepared ONCE: a k*k-bit validity mask and, for the "regular" sources (no
+  // upsampling, no stride-2 data gradient), the pixel index of tap (0, 0) — a tap is then a UNIFORM pixel offset, and a
+  // row costs four vector instructions per step (add, bit test, select, 64-bit mad).  (Recomputing coordinates, bounds
+  // and 64-bit addresses per tap cost ~1000 cycles of vector issue per step: more than the step's MFMAs.)
+  const int sgn = p.transposed ? -1 : 1;
+  const int sh = p.transposed ? s2 : 0;        // only the data gradient of a stride-2 layer divides (and skips odd phases)
+  const bool reg1 = !p.up1 && sh == 0, reg2 = sh == 0;
+  int cy[AP], cx[AP], pb1[AP], pb2[AP], pc1[AP], pc2[AP];
+  uint32_t vmask[AP];
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
     const int row = r0 + j * RPP;
     const int64_t m = m0 + row;
+    vmask[j] = 0;
     if (row < BM && m < p.P) {
-      ox[j] = (int)(m % p.Wout);
+      const int ox = (int)(m % p.Wout);
       const int64_t t = m / p.Wout;
-      oy[j] = (int)(t % p.Hout);
-      const int64_t b = t / p.Hout;
-      b1[j] = b * H1 * W1;
-      b2[j] = b * p.Hin * p.Win;
+      const int oy = (int)(t % p.Hout);
+      const int b = (int)(t / p.Hout);
+      cy[j] = p.transposed ? oy + pad : oy * p.stride - pad;
+      cx[j] = p.transposed ? ox + pad : ox * p.stride - pad;
+      pb1[j] = b * H1 * W1;
+      pb2[j] = b * p.Hin * p.Win;
+      for (int tp = 0; tp < p.k * p.k; ++tp) {
+        const int ky = tp / p.k, kx = tp - ky * p.k;
+        const int ty = cy[j] + sgn * ky, tx = cx[j] + sgn * kx;
+        const int iy = ty >> sh, ix = tx >> sh;
+        const bool ok = (((ty | tx) & sh) == 0) & ((unsigned)iy < (unsigned)p.Hin) & ((unsigned)ix < (unsigned)p.Win);
+        vmask[j] |= ok ? (1u << tp) : 0u;
+      }
     } else {
-      ox[j] = oy[j] = -(1 << 20);
-      b1[j] = b2[j] = 0;
+      cy[j] = cx[j] = 0;
+      pb1[j] = pb2[j] = 0;
     }
+    pc1[j] = pb1[j] + cy[j] * W1 + cx[j];          // regular sources: pixel of tap (0, 0) (may lie outside: masked)
+    pc2[j] = pb2[j] + cy[j] * p.Win + cx[j];
+  }
+  // weight rows: byte offset of the thread's piece inside a (tap, chunk) slab, without the uniform part
+  uint32_t wof[BP];
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int row = r0 + j * RPP;
+    wof[j] = (uint32_t)(((n0 + (row < BN ? row : 0)) * p.Cin) * ES + piece * 16);
   }
 
   const int CH = p.Cin / EPC;                 // chunks per tap
   const int NIT = p.k * p.k * CH;
   u32x4_a4 ra[AP], rb[BP];
+  uint32_t okm = 0;   // bit j: row j of the tile in flight is inside the image (the zero is selected when it is STASHED, so
+                      // that nothing touches the loaded registers — and waits for them — before the MFMAs of this step)
 
-  auto fetch = [&](int tap, int ch) {
-    const int ky = tap / p.k, kx = tap - ky * p.k;
+  // Branch-free: every lane loads (pixel 0 when its tap falls outside the image) and the zero is selected afterwards.
+  auto fetch = [&](int tap, int ky, int kx, int ch) {
     const int c0 = ch * EPC;
     const bool first = c0 < p.C1;
-    const char* base = first ? p.X1 : p.X2;
-    const int64_t ld = first ? p.ld1 : p.ld2;
-    const int cc = (first ? c0 : c0 - p.C1) + piece * (16 / ES);
-    const int up = first ? p.up1 : 0;
-    const int Ws = first ? W1 : p.Win;
+    const char* base = (first ? p.X1 : p.X2) + (size_t)((first ? c0 : c0 - p.C1) * ES) + piece * 16;
+    const uint32_t ldb = (uint32_t)((first ? p.ld1 : p.ld2) * ES);
+    okm = 0;
+    if (first ? reg1 : reg2) {
+      const int delta = sgn * (ky * (first ? W1 : p.Win) + kx);
 #pragma unroll
-    for (int j = 0; j < AP; ++j) {
-      int iy, ix;
-      bool ok;
-      if (p.transposed) {
-        const int ty = oy[j] + pad - ky, tx = ox[j] + pad - kx;
-        ok = ty >= 0 && tx >= 0 && ((ty | tx) & s2) == 0;
-        iy = ty >> s2; ix = tx >> s2;
-        ok = ok && iy < p.Hin && ix < p.Win;
-      } else {
-        iy = oy[j] * p.stride + ky - pad; ix = ox[j] * p.stride + kx - pad;
-        ok = iy >= 0 && ix >= 0 && iy < p.Hin && ix < p.Win;
+      for (int j = 0; j < AP; ++j) {
+        const bool ok = (vmask[j] >> tap) & 1u;
+        const int pix = ok ? (first ? pc1[j] : pc2[j]) + delta : 0;
+        okm |= ok ? (1u << j) : 0u;
+        if (!(RDST_DBGV(p.dbg) & 1)) ra[j] = *reinterpret_cast<const u32x4_a4*>(base + (uint64_t)(uint32_t)pix * ldb);
       }
-      const u32x4_a4 z = {0u, 0u, 0u, 0u};
-      if (ok) {
-        const int64_t pix = (first ? b1[j] : b2[j]) + (int64_t)(iy >> up) * Ws + (ix >> up);
-        ra[j] = *reinterpret_cast<const u32x4_a4*>(base + (pix * ld + cc) * ES);
-      } else {
-        ra[j] = z;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < BP; ++j) {
-      const int row = r0 + j * RPP;
-      const u32x4_a4 z = {0u, 0u, 0u, 0u};
-      if (row < BN)   // Npad is a multiple of BN: every staged weight row exists (zero rows beyond Cout)
-        rb[j] = *reinterpret_cast<const u32x4_a4*>(p.Wp + (((int64_t)tap * p.Npad + n0 + row) * p.Cin + c0) * ES + piece * 16);
-      else
-        rb[j] = z;
-    }
-  };
-  // SPLIT: a row of the LDS tile is [hi: KB/2 bytes of bf16][lo: KB/2 bytes of bf16]; a piece (4 floats) lands as 8 + 8 bytes
-  auto put = [&](char* rowp, const u32x4_a4& v) {
-    if (SPLIT) {
-      const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
-      u32x2_a4 hi, lo;
-      hi.x = pack_bf16x2(f0, f1); hi.y = pack_bf16x2(f2, f3);
-      lo.x = pack_bf16x2(f0 - bf16lo(hi.x), f1 - bf16hi(hi.x));
-      lo.y = pack_bf16x2(f2 - bf16lo(hi.y), f3 - bf16hi(hi.y));
-      *reinterpret_cast<u32x2_a4*>(rowp + piece * 8) = hi;
-      *reinterpret_cast<u32x2_a4*>(rowp + KB / 2 + piece * 8) = lo;
     } else {
-      *reinterpret_cast<u32x4_a4*>(rowp + piece * 16) = v;
+      const int up = first ? p.up1 : 0;
+      const int Ws = first ? W1 : p.Win;
+      const int dy = sgn * ky, dx = sgn * kx;
+#pragma unroll
+      for (int j = 0; j < AP; ++j) {
+        const bool ok = (vmask[j] >> tap) & 1u;
+        const int iy = (cy[j] + dy) >> sh, ix = (cx[j] + dx) >> sh;
+        const int pix = ok ? (first ? pb1[j] : pb2[j]) + (iy >> up) * Ws + (ix >> up) : 0;
+        okm |= ok ? (1u << j) : 0u;
+        if (!(RDST_DBGV(p.dbg) & 1)) ra[j] = *reinterpret_cast<const u32x4_a4*>(base + (uint64_t)(uint32_t)pix * ldb);
+      }
     }
+    const char* wb = p.Wp + ((size_t)tap * p.Npad * p.Cin + c0) * ES;
+#pragma unroll
+    for (int j = 0; j < BP; ++j)
+      if (!(RDST_DBGV(p.dbg) & 2)) rb[j] = *reinterpret_cast<const u32x4_a4*>(wb + wof[j]);
   };
+  // SPLIT: LDS rows are 64-byte groups [16 bf16 hi][16 bf16 lo]; an activation piece (4 floats) lands as 8 + 8 bytes, the
+  // weights arrive ALREADY split in that layout (host-side pack) and are copied as they are.
   auto stash = [&](int buf) {
+    if (RDST_DBGV(p.dbg) & 4) return;
     char* A = smem + buf * STAGE;
     char* Bt = A + BM * RS;
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
       const int row = r0 + j * RPP;
-      if (row < BM) put(A + row * RS, ra[j]);
+      if (BM % RPP == 0 || row < BM) {      // compile-time true for every instantiated tile: no exec-mask branch
+        const bool ok = (okm >> j) & 1u;
+        u32x4_a4 v;
+        v.x = ok ? ra[j].x : 0u; v.y = ok ? ra[j].y : 0u; v.z = ok ? ra[j].z : 0u; v.w = ok ? ra[j].w : 0u;
+        if (SPLIT) {
+          const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+          u32x2_a4 hi, lo;
+          hi.x = pack_bf16x2(f0, f1); hi.y = pack_bf16x2(f2, f3);
+          lo.x = pack_bf16x2(f0 - bf16lo(hi.x), f1 - bf16hi(hi.x));
+          lo.y = pack_bf16x2(f2 - bf16lo(hi.y), f3 - bf16hi(hi.y));
+          char* g = A + row * RS + (piece >> 2) * 64 + (piece & 3) * 8;
+          *reinterpret_cast<u32x2_a4*>(g) = hi;
+          *reinterpret_cast<u32x2_a4*>(g + 32) = lo;
+        } else {
+          *reinterpret_cast<u32x4_a4*>(A + row * RS + piece * 16) = v;
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
       const int row = r0 + j * RPP;
-      if (row < BN) put(Bt + row * RS, rb[j]);
+      if (BN % RPP == 0 || row < BN) *reinterpret_cast<u32x4_a4*>(Bt + row * RS + piece * 16) = rb[j];
     }
   };
 
@@ -159,35 +191,44 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  int tap = 0, ch = 0;
-  fetch(0, 0);
+  int tap = 0, ky = 0, kx = 0, ch = 0;         // (tap, chunk) of the tile being FETCHED
+  auto advance = [&]() {
+    if (++ch == CH) {
+      ch = 0; ++tap;
+      if (++kx == p.k) { kx = 0; ++ky; }
+    }
+  };
+  fetch(0, 0, 0, 0);
+  advance();
   stash(0);
   __syncthreads();
   for (int it = 0; it < NIT; ++it) {
-    int ntap = tap, nch = ch + 1;
-    if (nch == CH) { nch = 0; ++ntap; }
     const bool more = it + 1 < NIT;
-    if (more) fetch(ntap, nch);
+    if (more) {
+      fetch(tap, ky, kx, ch);
+      advance();
+    }
     const char* A = smem + (it & 1) * STAGE + (wm * TM * 32 + r) * RS + h * 16;
     const char* Bt = smem + (it & 1) * STAGE + BM * RS + (wn * TN * 32 + r) * RS + h * 16;
     if (SPLIT) {
 #pragma unroll
-      for (int kk = 0; kk < KB / 64; ++kk) {   // 16 elements per k-step: 32 bytes of the hi half, 32 of the lo half
+      for (int kk = 0; kk < KB / 64; ++kk) {   // 16 elements per k-step: a 64-byte group, hi half then lo half
         Pack16 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          ah[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 32);
-          al[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + KB / 2 + kk * 32);
+          ah[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 64);
+          al[i] = *reinterpret_cast<const Pack16*>(A + i * 32 * RS + kk * 64 + 32);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          bh[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 32);
-          bl[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + KB / 2 + kk * 32);
+          bh[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 64);
+          bl[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 64 + 32);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            if (RDST_DBGV(p.dbg) & 8) continue;
             Mma<bf16>::mma(acc[i][j], ah[i], bl[j]);
             Mma<bf16>::mma(acc[i][j], al[i], bh[j]);
             Mma<bf16>::mma(acc[i][j], ah[i], bh[j]);
@@ -209,7 +250,6 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
     }
     if (more) stash((it + 1) & 1);
     __syncthreads();
-    tap = ntap; ch = nch;
   }
 
   // epilogue: rows of D leave as 8/16-byte segments through a wave-private 4 KB bounce tile
@@ -246,8 +286,18 @@ int launch(const UConvP& p, hipStream_t st) {
 
 template <typename T, int KB, bool SPLIT>
 int pick_bn(const UConvP& p, hipStream_t st) {
-  if (p.Npad % 128 == 0) return launch<T, 128, 128, KB, 2, 2, SPLIT>(p, st);
-  if (p.Npad % 64 == 0) return launch<T, 128, 64, KB, 2, 2, SPLIT>(p, st);
+  // the widest tile that still gives every CU a workgroup: the deep layers of the UNet have few pixels (2048 at 8x8 x 32)
+  // and long reductions (K = 4608): at 128 x 128 they are 64 workgroups of 144 steps on 256 CUs
+  const int64_t mb128 = (p.P + 127) / 128;
+  if (p.Npad % 128 == 0) {
+    if (mb128 * (p.Npad / 128) >= 256) return launch<T, 128, 128, KB, 2, 2, SPLIT>(p, st);
+    if (2 * mb128 * (p.Npad / 128) >= 256) return launch<T, 64, 128, KB, 2, 2, SPLIT>(p, st);
+    return launch<T, 64, 64, KB, 2, 2, SPLIT>(p, st);
+  }
+  if (p.Npad % 64 == 0) {
+    if (mb128 * (p.Npad / 64) >= 256) return launch<T, 128, 64, KB, 2, 2, SPLIT>(p, st);
+    return launch<T, 64, 64, KB, 2, 2, SPLIT>(p, st);
+  }
   return launch<T, 128, 32, KB, 4, 1, SPLIT>(p, st);
 }
 
@@ -280,6 +330,8 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
   const int es = dtype == RDST_BF16 ? 2 : 4;
   if (((uintptr_t)X1 | (uintptr_t)X2 | (uintptr_t)Wp) & 3 || (ld1 * es) % 4 || (ld2 * es) % 4)
     return rdst_fail(RDST_EINVAL, "rdst_u_conv: sources must be dword aligned");
+  if ((int64_t)B * Hin * Win >= (1ll << 31) || (int64_t)B * Hin * Win * (ld1 > ld2 ? ld1 : ld2) * es >= (1ll << 40))
+    return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: tensor too large for 32-bit pixel indices");
   UConvP p;
   p.X1 = (const char*)X1; p.ld1 = ld1; p.C1 = C1; p.up1 = up1 ? 1 : 0;
   p.X2 = (const char*)X2; p.ld2 = ld2; p.C2 = C2;
@@ -287,6 +339,10 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
   p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.Cin = C1 + C2; p.Cout = Cout; p.Npad = Npad;
   p.k = ksize; p.stride = stride; p.transposed = transposed ? 1 : 0;
   p.P = (int64_t)B * Hout * Wout;
+  {
+    const char* e = rdst_dbg_getenv("RDST_UCONV_DBG");
+    p.dbg = e ? atoi(e) : 0;
+  }
   if (dtype == RDST_F32X3) return pick_kb<float, true>(p, (hipStream_t)stream);
   return dtype == RDST_F32 ? pick_kb<float, false>(p, (hipStream_t)stream) : pick_kb<bf16, false>(p, (hipStream_t)stream);
 }

@@ -347,6 +347,21 @@ class _Runner:
         return dimg
 
 
+def _pack_weights(t, code):
+    """(taps, Npad, K) fp32 -> the image rdst_u_conv reads (include/rdst_hip.h): bf16 / fp32 as they are; RDST_F32X3 as
+    64-byte groups [16 bf16 hi][16 bf16 lo] per 16 reduction elements (K % 16 == 0)."""
+    if code == BF16:
+        return t.to(torch.bfloat16).contiguous()
+    if code == F32:
+        return t.float().contiguous()
+    taps, n, K = t.shape
+    if K % 16:
+        raise ValueError("rdst_amd.loss: the fp32x3 mode needs a reduction length that is a multiple of 16")
+    hi = t.float().to(torch.bfloat16)
+    lo = (t.float() - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi.reshape(taps, n, K // 16, 16), lo.reshape(taps, n, K // 16, 16)], dim=-1).reshape(taps, n, 2 * K).contiguous()
+
+
 def _add_rows(a, b):
     """a + b for two row views (rare: a feature that receives both a feature-loss gradient and a skip gradient)."""
     return (a.float() + b.float()).to(a.dtype)
@@ -541,7 +556,7 @@ class SegUNet_F(nn.Module):
         """name, transposed -> (weights as [k*k][Npad][K] in the compute dtype, Npad, k): frozen weights, packed once per
         (weights version, dtype, device)."""
         ws = list(self._conv_weights())
-        sig = (self.compute_dtype, tuple((w.data_ptr(), w._version) for _, w in ws))
+        sig = (self.compute_code, tuple((w.data_ptr(), w._version) for _, w in ws))
         if self._pack_cache.get("sig") != sig:
             packs = {}
             with torch.no_grad():
@@ -552,8 +567,8 @@ class SegUNet_F(nn.Module):
                         N, K = t.shape[2], t.shape[3]
                         npad = (N + 31) // 32 * 32
                         kpad = max(K, NCLS_PAD) if tr and n == "tail.0" else K           # the head's dgrad reduces over 16 padded classes
-                        t = F.pad(t, (0, kpad - K, 0, npad - N))
-                        packs[(n, tr)] = (t.reshape(k * k, npad, kpad).to(self.compute_dtype).contiguous(), npad, k)
+                        t = F.pad(t, (0, kpad - K, 0, npad - N)).reshape(k * k, npad, kpad)
+                        packs[(n, tr)] = (_pack_weights(t, self.compute_code), npad, k)
             self._pack_cache = {"sig": sig, "packs": packs}
         return self._pack_cache["packs"]
 
