@@ -230,19 +230,6 @@ int rdst_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
                    void* stream);
 
-/* ---- N2: stem of the seg-UNet perceptual loss (loss/seg_unet.py:80-107, 'encoder' mode, loss layer 1) -----------
- * loss = mean((f(sr) - f(hr))^2)  (use_mse = 1, the reference's '...L1' modes) or mean(|f(sr) - f(hr)|), where
- * f = ReLU(BatchNorm2d_train(conv7x7/2(x))) is the first stage of the smp.Unet resnet34 encoder.  fp32 NCHW images.
- * BatchNorm runs in training mode on the SR batch, then on the HR batch (running_mean/var updated twice, may be NULL).
- * The forward keeps the conv outputs in `workspace`; the backward (d loss / d sr, times the device scalar `upstream`,
- * NULL = 1) must get the same workspace untouched. */
-size_t rdst_stem_loss_workspace(int B, int H, int W);
-int rdst_stem_loss_fwd(const float* sr, const float* hr, const float* conv_w, const float* bn_w, const float* bn_b,
-                       float* running_mean, float* running_var, float momentum, float eps, int use_mse, float* loss,
-                       void* workspace, size_t workspace_bytes, int B, int Cin, int H, int W, void* stream);
-int rdst_stem_loss_bwd(const float* conv_w, const float* bn_w, const float* upstream, float* dsr, void* workspace,
-                       size_t workspace_bytes, int B, int Cin, int H, int W, void* stream);
-
 /* ---- N2 (full): the seg-UNet of the reference's perceptual loss (loss/seg_unet.py:46-127) -----------------------------
  * smp.Unet(in_channels, classes=4) = resnet34 encoder + UNet decoder + 3x3 head, BatchNorm in TRAINING mode, frozen
  * weights: forward on the SR and the HR batch, backward to the SR image ONLY (no weight gradients: the optimizer of the

@@ -49,9 +49,6 @@ SIGNATURES = {
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "rdst_upsample2_fwd": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_upsample2_bwd": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
-    "rdst_stem_loss_workspace": (_z, [_i, _i, _i]),
-    "rdst_stem_loss_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _z, _i, _i, _i, _i, _p]),
-    "rdst_stem_loss_bwd": (_i, [_p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "rdst_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _p]),
     # the seg-UNet of the perceptual loss (ABI v5)
     "rdst_u_scratch_bytes": (_z, []),

@@ -7,6 +7,7 @@
 // every reduction is a per-workgroup partial + a fixed-order finish (bit-identical run to run, no atomics).
 // The convolutions themselves are uconv_mfma.hip.
 #include "mfma.h"
+#include "stem_conv.h"
 
 namespace {
 
@@ -319,80 +320,9 @@ __global__ void __launch_bounds__(256) sumpool2_kernel(const T* __restrict__ dY,
   }
 }
 
-// ---- the 7x7 / 2 stem (Cin <= 4 input channels: a 49-tap stencil, no GEMM) -----------------------------------------------
-constexpr int SC = 64;
-struct Geo { int B, H, W, Ho, Wo, Cin; };
-
-template <typename T>
-__global__ void __launch_bounds__(256) stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
-                                                       int64_t ldy, Geo g) {
-  extern __shared__ float wl[];   // [Cin*49][64] transposed: the lanes of a pixel read consecutive channels
-  for (int i = threadIdx.x; i < SC * g.Cin * 49; i += 256) {
-    const int c = i / (g.Cin * 49), t = i - c * (g.Cin * 49);
-    wl[t * SC + c] = w[i];
-  }
-  __syncthreads();
-  const int c = threadIdx.x & 63;
-  const int64_t P = (int64_t)g.B * g.Ho * g.Wo;
-  for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += (int64_t)gridDim.x * 4) {
-    const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho), b = (int)(p / ((int64_t)g.Wo * g.Ho));
-    float a = 0.f;
-    for (int ci = 0; ci < g.Cin; ++ci) {
-      const float* xp = x + ((int64_t)b * g.Cin + ci) * g.H * g.W;
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        const int yy = 2 * ho + ky - 3;
-        if (yy < 0 || yy >= g.H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-          const int xx = 2 * wo + kx - 3;
-          if (xx < 0 || xx >= g.W) continue;
-          a = fmaf(xp[(int64_t)yy * g.W + xx], wl[((ci * 7 + ky) * 7 + kx) * SC + c], a);
-        }
-      }
-    }
-    y[p * ldy + c] = from_f32<T>(a);
-  }
-}
-
-// dimg[b][ci][y][x] = up * sum_{c,ky,kx: (y+3-ky), (x+3-kx) even} dR[b][(y+3-ky)/2][(x+3-kx)/2][c] w[c][ci][ky][kx]
-template <typename T>
-__global__ void __launch_bounds__(256) stem_dgrad_kernel(const T* __restrict__ dc, int64_t ld, const float* __restrict__ w,
-                                                         const float* __restrict__ upstream, float* __restrict__ dx, Geo g) {
-  extern __shared__ float wl[];   // [Cin*49][64]
-  for (int i = threadIdx.x; i < SC * g.Cin * 49; i += 256) {
-    const int c = i / (g.Cin * 49), t = i - c * (g.Cin * 49);
-    wl[t * SC + c] = w[i];
-  }
-  __syncthreads();
-  const float up = upstream ? upstream[0] : 1.f;
-  const int64_t n = (int64_t)g.B * g.Cin * g.H * g.W;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H);
-    const int ci = (int)((i / ((int64_t)g.W * g.H)) % g.Cin), b = (int)(i / ((int64_t)g.W * g.H * g.Cin));
-    float a = 0.f;
-    for (int ky = (y + 3) & 1; ky < 7; ky += 2) {
-      const int ho = (y + 3 - ky) >> 1;
-      if (ho < 0 || ho >= g.Ho) continue;
-      for (int kx = (x + 3) & 1; kx < 7; kx += 2) {
-        const int wo = (x + 3 - kx) >> 1;
-        if (wo < 0 || wo >= g.Wo) continue;
-        const T* dp = dc + (((int64_t)b * g.Ho + ho) * g.Wo + wo) * ld;
-        const float* wp = wl + ((ci * 7 + ky) * 7 + kx) * SC;
-        float t = 0.f;
-#pragma unroll
-        for (int c8 = 0; c8 < SC; c8 += V<T>::N) {
-          float f[V<T>::N];
-          ldv<T>(dp + c8, f);
-#pragma unroll
-          for (int e = 0; e < V<T>::N; ++e) t = fmaf(f[e], wp[c8 + e], t);
-        }
-        a += t;
-      }
-    }
-    dx[i] = a * up;
-  }
-}
+// ---- the 7x7 / 2 stem: stem_conv.h ---------------------------------------------------------------------------------------
+using stemconv::Geo;
+constexpr int SC = stemconv::SC;
 
 // ---- feature L1 / MSE loss between the SR and the HR features ('encoder' / 'decoder' modes, loss/seg_unet.py:99-111) ------
 template <typename T>
@@ -693,11 +623,9 @@ extern "C" int rdst_u_stem_fwd(const float* img, const float* W, void* Y, int64_
   if (!img || !W || !Y || B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cin > 4 || ld_y < SC) return rdst_fail(RDST_EINVAL, "rdst_u_stem_fwd: bad argument");
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_u_stem_fwd: bad dtype");
   Geo g{B, H, Wd, (H + 1) / 2, (Wd + 1) / 2, Cin};
-  const int64_t P = (int64_t)B * g.Ho * g.Wo;
-  const unsigned grid = (unsigned)((P + 3) / 4 < 4096 ? (P + 3) / 4 : 4096);
-  const size_t lds = (size_t)SC * Cin * 49 * 4;
-  if (dtype == RDST_F32) hipLaunchKernelGGL((stem_fwd_kernel<float>), dim3(grid), dim3(256), lds, (hipStream_t)stream, img, W, (float*)Y, ld_y, g);
-  else hipLaunchKernelGGL((stem_fwd_kernel<bf16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, img, W, (bf16*)Y, ld_y, g);
+  const unsigned grid = stemconv::fwd_grid(g);
+  if (dtype == RDST_F32) hipLaunchKernelGGL((stemconv::fwd_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, img, W, (float*)Y, ld_y, g);
+  else hipLaunchKernelGGL((stemconv::fwd_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, img, W, (bf16*)Y, ld_y, g);
   return rdst_launch_status("rdst_u_stem_fwd");
 }
 
@@ -707,11 +635,9 @@ extern "C" int rdst_u_stem_dgrad(const void* dR, int64_t ld, const float* W, con
   if (!dR || !W || !dimg || B <= 0 || H <= 0 || Wd <= 0 || Cin <= 0 || Cin > 4 || ld < SC) return rdst_fail(RDST_EINVAL, "rdst_u_stem_dgrad: bad argument");
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_u_stem_dgrad: bad dtype");
   Geo g{B, H, Wd, (H + 1) / 2, (Wd + 1) / 2, Cin};
-  const int64_t n = (int64_t)B * Cin * H * Wd;
-  const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-  const size_t lds = (size_t)SC * Cin * 49 * 4;
-  if (dtype == RDST_F32) hipLaunchKernelGGL((stem_dgrad_kernel<float>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float*)dR, ld, W, upstream, dimg, g);
-  else hipLaunchKernelGGL((stem_dgrad_kernel<bf16>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dR, ld, W, upstream, dimg, g);
+  const unsigned grid = stemconv::dgrad_grid(g);
+  if (dtype == RDST_F32) hipLaunchKernelGGL((stemconv::dgrad_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dR, ld, W, upstream, dimg, g);
+  else hipLaunchKernelGGL((stemconv::dgrad_kernel<bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dR, ld, W, upstream, dimg, g);
   return rdst_launch_status("rdst_u_stem_dgrad");
 }
 

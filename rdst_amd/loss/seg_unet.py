@@ -94,41 +94,6 @@ class _Decoder(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-# the stem-only fast path (loss layers within {0, 1}): one fused fp32 kernel pair, csrc/stem_loss.hip
-# ------------------------------------------------------------------------------------------------------------------------
-class _StemLoss(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, sr, hr, conv_w, bn_w, bn_b, rmean, rvar, momentum, eps, use_mse):
-        if not sr.is_cuda:
-            raise RuntimeError("rdst_amd.loss.SegUNet_F: the stem loss is a HIP kernel; there is no CPU fallback")
-        lib = _lib.load()
-        B, Cin, H, W = sr.shape
-        srs, hrs = sr.detach().float().contiguous(), hr.detach().float().contiguous()
-        nb = lib.rdst_stem_loss_workspace(B, H, W)
-        wsp = torch.empty(nb, dtype=torch.uint8, device=sr.device)
-        loss = torch.empty((), dtype=torch.float32, device=sr.device)
-        st = torch.cuda.current_stream().cuda_stream
-        _lib.check(lib.rdst_stem_loss_fwd(srs.data_ptr(), hrs.data_ptr(), conv_w.data_ptr(), bn_w.data_ptr(), bn_b.data_ptr(),
-                                          rmean.data_ptr() if rmean is not None else None,
-                                          rvar.data_ptr() if rvar is not None else None, float(momentum), float(eps),
-                                          int(use_mse), loss.data_ptr(), wsp.data_ptr(), nb, B, Cin, H, W, st), "rdst_stem_loss_fwd")
-        ctx.save_for_backward(conv_w, bn_w, wsp)
-        ctx.geom = (B, Cin, H, W, nb)
-        return loss
-
-    @staticmethod
-    def backward(ctx, gout):
-        conv_w, bn_w, wsp = ctx.saved_tensors
-        B, Cin, H, W, nb = ctx.geom
-        lib = _lib.load()
-        up = gout.detach().float().contiguous()
-        dsr = torch.empty((B, Cin, H, W), dtype=torch.float32, device=wsp.device)
-        _lib.check(lib.rdst_stem_loss_bwd(conv_w.data_ptr(), bn_w.data_ptr(), up.data_ptr(), dsr.data_ptr(), wsp.data_ptr(), nb,
-                                          B, Cin, H, W, torch.cuda.current_stream().cuda_stream), "rdst_stem_loss_bwd")
-        return dsr, None, None, None, None, None, None, None, None, None
-
-
-# ------------------------------------------------------------------------------------------------------------------------
 # the UNet on the rdst_u_* entry points
 # ------------------------------------------------------------------------------------------------------------------------
 def _ptr(t):
@@ -524,7 +489,6 @@ class SegUNet_F(nn.Module):
         self.loss_names = ["SegUNet({})".format(self.loss_mode)]
         self.use_mse = "L1" in self.loss_mode         # loss/seg_unet.py:73-78: 'L1' -> MSELoss, everything else L1Loss
         self.compute_dtype, self.compute_code = torch.float32, F32X3
-        self.force_generic = False                    # tests: run layers {0, 1} through the generic UNet path too
         self.keep_debug = False                       # tests: keep the logits of the last 'label' call in self.debug_last
         self._pack_cache = {}
         self._scratch_buf = None
@@ -584,25 +548,9 @@ class SegUNet_F(nn.Module):
             object.__setattr__(self, "_nbt_flat", flat)
         flat += n
 
-    def _pixel_loss(self, a, b):
-        return F.mse_loss(a, b) if self.use_mse else F.l1_loss(a, b)
-
     # ---- loss/seg_unet.py:94-127 ----------------------------------------------------------------------------------------
     def forward(self, sr, hr, gt_label=None):
         assert sr.shape == hr.shape, "Seg UNet Loss invalid SR({}) and HR({}) shape!".format(sr.shape, hr.shape)
         from .sr_loss import LazyScalars
-        if "encoder" in self.loss_mode and all(l in (0, 1) for l in self.loss_layers) and not self.force_generic:
-            bn = self.encoder.bn1                     # the shipped ini's case ({'encoder-L1': [1]}): one fused fp32 kernel pair
-            loss = 0
-            for l in self.loss_layers:
-                if l == 0:
-                    term = self._pixel_loss(sr, hr.detach())
-                else:
-                    term = _StemLoss.apply(sr, hr, self.encoder.conv1.weight.detach(), bn.weight.detach(), bn.bias.detach(),
-                                           bn.running_mean, bn.running_var, bn.momentum, bn.eps, self.use_mse)
-                    bn.num_batches_tracked += 2       # one BatchNorm forward on SR, one on HR
-                loss = loss + term
-                loss = loss / len(self.loss_layers)   # :105-107: inside the loop, as the reference has it
-        else:
-            loss = _UNetLoss.apply(sr, hr, gt_label, self)
+        loss = _UNetLoss.apply(sr, hr, gt_label, self)
         return loss, LazyScalars({self.loss_names[0]: loss.detach()})

@@ -1,4 +1,4 @@
-"""N2: the stem of the seg-UNet perceptual loss (rdst_amd.loss.SegUNet_F, csrc/stem_loss.hip) against the same function
+"""N2: the stem of the seg-UNet perceptual loss (rdst_amd.loss.SegUNet_F on stem_conv.h + segunet.hip) against the same function
 in plain torch on the CPU: conv 7x7/2 -> BatchNorm2d (training mode) -> ReLU -> MSE / L1 between SR and HR features
 (loss/seg_unet.py:80-107).  Parity with the reference's own UNet is unpinned (no smp, no weights in the image)."""
 import pytest

@@ -18,7 +18,6 @@ for dt in (torch.float32, torch.bfloat16):
     mod = U.SegUNet_F({mode: layers}, "OASIS", allow_random_init=True)
     mod.load_state_dict(sd, strict=True)
     mod.to("cuda:0").set_compute_dtype(dt)
-    mod.force_generic = True
     seq = []
     ob, oc, oa = U._Runner.bn_bwd, U._Runner.conv, U._Runner.bn_apply
     def bnb(self, dy, mask, raw, coef, want_g=False, gadd=None, _o=ob):

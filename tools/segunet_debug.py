@@ -14,7 +14,6 @@ sd = S.make_unet_weights(1, 4, 0)
 mod = U.SegUNet_F({mode: []}, "OASIS", allow_random_init=True)
 mod.load_state_dict(sd, strict=True)
 mod.to("cuda:0")
-mod.force_generic = True
 
 # oracle with retained intermediate grads
 srr = sr.clone().requires_grad_(True)
