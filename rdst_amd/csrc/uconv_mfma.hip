@@ -274,6 +274,300 @@ __global__ void __launch_bounds__(256) uconv_kernel(const UConvP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 (forward and data gradient: 90 % of the UNet's FLOPs): the HALO form.  A workgroup owns a TH x TW patch of
+// ONE image and, per channel chunk, stages the (TH + 2) x (TW + 2) halo of input pixels ONCE; the nine taps are row
+// offsets of the fragment reads into that tile (compile-time: the tap loop is unrolled), so per tap only the BN x KB weight
+// slab is staged (already in its LDS layout: a copy).  Against uconv_kernel — one BM x KB input slab per (tap, chunk),
+// ~400 instructions per 24 MFMAs: instruction-issue bound at a third of the MFMA rate — the input staging drops 6.4x
+// (180 instead of 9 x 128 rows per chunk) and a tap costs ~100 instructions.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int TH, int TW, int BN, int KB, int WM, int WN, bool SPLIT>
+__global__ void __launch_bounds__(256) uconv_halo_kernel(const UConvP p) {
+  static_assert(!SPLIT || (sizeof(T) == 4 && KB >= 64), "the split mode stages fp32 rows, 16 elements per k-step");
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BM = TH * TW;
+  constexpr int HH = TH + 2, HW = TW + 2, NH = HH * HW;      // halo pixels
+  constexpr int RS = KB + 16;
+  constexpr int PIECES = KB / 16;
+  constexpr int APN = (NH * PIECES + 255) / 256;             // halo pieces per thread
+  constexpr int RPP = 256 / PIECES;
+  constexpr int BP = (BN + RPP - 1) / RPP;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int EPC = KB / ES;
+  constexpr int ASZ = ((NH * RS + 255) / 256) * 256, BSZ = BN * RS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Ah = smem;                      // halo tile (single buffer: rewritten once per channel chunk)
+  char* const Bw = smem + ASZ;                // weight slabs, two buffers
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int n0 = blockIdx.y * BN;
+  const int ntx = (p.Wout + TW - 1) / TW, nty = (p.Hout + TH - 1) / TH;
+  const int txi = blockIdx.x % ntx, tyi = (blockIdx.x / ntx) % nty, b = blockIdx.x / (ntx * nty);
+  const int y0 = tyi * TH, x0 = txi * TW;
+  const int H1 = p.Hin >> p.up1, W1 = p.Win >> p.up1;
+
+  // halo pieces of this thread: source pixel indices (both sources) and validity, prepared once
+  int hp1[APN], hp2[APN];
+  uint32_t hoff[APN];                          // LDS byte offset of the piece (row * RS + position inside the row)
+  uint32_t hok = 0, hin = 0;                   // bit a: inside the image / a real piece of the tile
+#pragma unroll
+  for (int a = 0; a < APN; ++a) {
+    const int idx = tid + a * 256;
+    const int hr = idx / PIECES, pc = idx - hr * PIECES;
+    const int hy = hr / HW, hx = hr - hy * HW;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    const bool in = idx < NH * PIECES;
+    const bool ok = in && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    hin |= in ? (1u << a) : 0u;
+    hok |= ok ? (1u << a) : 0u;
+    hp1[a] = ok ? (b * H1 + (iy >> p.up1)) * W1 + (ix >> p.up1) : 0;
+    hp2[a] = ok ? (b * p.Hin + iy) * p.Win + ix : 0;
+    hoff[a] = (uint32_t)(hr * RS) | ((uint32_t)pc << 24);     // piece index in the top byte
+  }
+  uint32_t wof[BP];
+#pragma unroll
+  for (int j = 0; j < BP; ++j) {
+    const int row = tid / PIECES + j * RPP;
+    wof[j] = (uint32_t)(((n0 + (row < BN ? row : 0)) * p.Cin) * ES + (tid % PIECES) * 16);
+  }
+  // fragment rows: lane r of M-subtile i is tile pixel m = (wm * TM + i) * 32 + r -> halo row (ty * HW + tx) of tap (0, 0)
+  uint32_t arow[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = (wm * TM + i) * 32 + r;
+    arow[i] = (uint32_t)(((m / TW) * HW + (m % TW)) * RS + h * 16);
+  }
+
+  const int CH = p.Cin / EPC;
+  u32x4_a4 ra[APN], rb[2][BP];   // weight slabs: two register sets, fetched TWO taps ahead of their use
+  auto fetchA = [&](int ch) {
+    const int c0 = ch * EPC;
+    const bool first = c0 < p.C1;
+    const char* base = (first ? p.X1 : p.X2) + (size_t)((first ? c0 : c0 - p.C1) * ES);
+    const uint32_t ldb = (uint32_t)((first ? p.ld1 : p.ld2) * ES);
+#pragma unroll
+    for (int a = 0; a < APN; ++a)
+      ra[a] = *reinterpret_cast<const u32x4_a4*>(base + (uint64_t)(uint32_t)(first ? hp1[a] : hp2[a]) * ldb + (hoff[a] >> 24) * 16);
+  };
+  auto stashA = [&]() {
+#pragma unroll
+    for (int a = 0; a < APN; ++a) {
+      if (!((hin >> a) & 1u)) continue;
+      const bool ok = (hok >> a) & 1u;
+      u32x4_a4 v;
+      v.x = ok ? ra[a].x : 0u; v.y = ok ? ra[a].y : 0u; v.z = ok ? ra[a].z : 0u; v.w = ok ? ra[a].w : 0u;
+      const uint32_t pc = hoff[a] >> 24;
+      char* rowp = Ah + (hoff[a] & 0xffffffu);
+      if (SPLIT) {
+        const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+        u32x2_a4 hi, lo;
+        hi.x = pack_bf16x2(f0, f1); hi.y = pack_bf16x2(f2, f3);
+        lo.x = pack_bf16x2(f0 - bf16lo(hi.x), f1 - bf16hi(hi.x));
+        lo.y = pack_bf16x2(f2 - bf16lo(hi.y), f3 - bf16hi(hi.y));
+        char* g = rowp + (pc >> 2) * 64 + (pc & 3) * 8;
+        *reinterpret_cast<u32x2_a4*>(g) = hi;
+        *reinterpret_cast<u32x2_a4*>(g + 32) = lo;
+      } else {
+        *reinterpret_cast<u32x4_a4*>(rowp + pc * 16) = v;
+      }
+    }
+  };
+  auto fetchB = [&](auto slotc, int tap, int ch) {
+    constexpr int SL = decltype(slotc)::value;
+    const char* wb = p.Wp + ((size_t)tap * p.Npad * p.Cin + (size_t)ch * EPC) * ES;
+#pragma unroll
+    for (int j = 0; j < BP; ++j) rb[SL][j] = *reinterpret_cast<const u32x4_a4*>(wb + wof[j]);
+  };
+  auto stashB = [&](auto slotc, int buf) {
+    constexpr int SL = decltype(slotc)::value;
+    char* Bt = Bw + buf * BSZ;
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+      const int row = tid / PIECES + j * RPP;
+      if (BN % RPP == 0 || row < BN) *reinterpret_cast<u32x4_a4*>(Bt + row * RS + (tid % PIECES) * 16) = rb[SL][j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // slab s (= tap-step index ch * 9 + tap) waits in register set s & 1 and is multiplied from LDS buffer s & 1; the loop is
+  // unrolled over 18 steps (two chunks) so that both parities are compile-time constants
+  auto slab_tap = [&](int sidx, int& t, int& c) { c = sidx / 9; t = sidx - 9 * c; };
+  const int NS = 9 * CH;
+  fetchA(0);
+  fetchB(S0{}, 0, 0);
+  stashA();
+  stashB(S0{}, 0);
+  if (NS > 1) {
+    int t, c;
+    slab_tap(1, t, c);
+    fetchB(S1{}, t, c);
+  }
+  __syncthreads();
+  auto step = [&](int sidx, int ch, auto tapc, auto parc) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int PAR = decltype(parc)::value;         // sidx & 1
+    const bool lastc = ch + 1 == CH;
+    if (sidx + 2 < NS) {                                // slab sidx + 2 -> the register set slab sidx has left
+      int t, c;
+      slab_tap(sidx + 2, t, c);
+      fetchB(parc, t, c);
+    }
+    if (tap == 6 && !lastc) fetchA(ch + 1);             // lands under the last three taps
+    const int bsel = PAR;
+      // the input pixel of tap (ky, kx): forward out + (ky, kx) - 1, data gradient out + 1 - (ky, kx)
+      const int ky = tap / 3, kx = tap % 3;
+      const int toff = p.transposed ? ((2 - ky) * HW + (2 - kx)) * RS : (ky * HW + kx) * RS;
+      const char* Bt = Bw + bsel * BSZ + (wn * TN * 32 + r) * RS + h * 16;
+      if (SPLIT) {
+#pragma unroll
+        for (int kk = 0; kk < KB / 64; ++kk) {
+          Pack16 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const Pack16*>(Ah + arow[i] + toff + kk * 64);
+            al[i] = *reinterpret_cast<const Pack16*>(Ah + arow[i] + toff + kk * 64 + 32);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 64);
+            bl[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 64 + 32);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              Mma<bf16>::mma(acc[i][j], ah[i], bl[j]);
+              Mma<bf16>::mma(acc[i][j], al[i], bh[j]);
+              Mma<bf16>::mma(acc[i][j], ah[i], bh[j]);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KB / 32; ++kk) {
+          Pack16 a[TM], bq[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Pack16*>(Ah + arow[i] + toff + kk * 32);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bq[j] = *reinterpret_cast<const Pack16*>(Bt + j * 32 * RS + kk * 32);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Mma<T>::mma(acc[i][j], a[i], bq[j]);
+        }
+      }
+    if (sidx + 1 < NS) stashB(std::integral_constant<int, PAR ^ 1>{}, PAR ^ 1);
+    if (tap == 8 && !lastc) {
+      __syncthreads();                                  // every wave is done with this chunk's halo
+      stashA();
+    }
+    __syncthreads();
+  };
+  for (int ch = 0; ch < CH; ch += 2) {
+#define RDST_UC_STEP(TAP, PAR) step(ch * 9 + TAP, ch, std::integral_constant<int, TAP>{}, std::integral_constant<int, PAR>{});
+    RDST_UC_STEP(0, 0) RDST_UC_STEP(1, 1) RDST_UC_STEP(2, 0) RDST_UC_STEP(3, 1) RDST_UC_STEP(4, 0) RDST_UC_STEP(5, 1) RDST_UC_STEP(6, 0)
+    RDST_UC_STEP(7, 1) RDST_UC_STEP(8, 0)
+#undef RDST_UC_STEP
+    if (ch + 1 < CH) {
+#define RDST_UC_STEP(TAP, PAR) step((ch + 1) * 9 + TAP, ch + 1, std::integral_constant<int, TAP>{}, std::integral_constant<int, PAR>{});
+      RDST_UC_STEP(0, 1) RDST_UC_STEP(1, 0) RDST_UC_STEP(2, 1) RDST_UC_STEP(3, 0) RDST_UC_STEP(4, 1) RDST_UC_STEP(5, 0) RDST_UC_STEP(6, 1)
+      RDST_UC_STEP(7, 0) RDST_UC_STEP(8, 1)
+#undef RDST_UC_STEP
+    }
+  }
+
+  // epilogue: each 32 x 32 accumulator through a wave-private bounce tile, rows leave as 8/16-byte segments; a tile row is
+  // a pixel of the patch (not a consecutive pixel index): rows outside the image are dropped
+  float* eps = reinterpret_cast<float*>(smem + wave * 4096);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col0 = n0 + (wn * TN + j) * 32;
+      if (col0 >= p.Cout) continue;
+      const float bv = (p.bias && col0 + r < p.Cout) ? p.bias[col0 + r] : 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) eps[acc_row(v, h) * 32 + r] = acc[i][j][v] + bv;
+      __builtin_amdgcn_wave_barrier();
+      const int chunk = lane & 7, col = col0 + chunk * 4;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int row = (lane >> 3) + 8 * pass;
+        const int m = (wm * TM + i) * 32 + row;
+        const int oy = y0 + m / TW, ox = x0 + m % TW;
+        const float4 f4 = *reinterpret_cast<const float4*>(eps + row * 32 + chunk * 4);
+        if (oy < p.Hout && ox < p.Wout && col < p.Cout) {
+          const int64_t rr = ((int64_t)b * p.Hout + oy) * p.Wout + ox;
+          float f[4] = {f4.x, f4.y, f4.z, f4.w};
+          T* dst = reinterpret_cast<T*>(p.Y) + rr * p.ld_y + col;
+          const bool full = col + 4 <= p.Cout;
+          if (p.add) {
+            const T* ap = reinterpret_cast<const T*>(p.add) + rr * p.ld_add + col;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (col + q < p.Cout) f[q] += to_f32<T>(ap[q]);
+          }
+          if (full && (reinterpret_cast<uintptr_t>(dst) & (sizeof(T) == 2 ? 7 : 15)) == 0) {
+            if (sizeof(T) == 2) {
+              u32x2_a4 u;
+              u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+              *reinterpret_cast<u32x2_a4*>(dst) = u;
+            } else {
+              u32x4_a4 u;
+              u.x = __float_as_uint(f[0]); u.y = __float_as_uint(f[1]); u.z = __float_as_uint(f[2]); u.w = __float_as_uint(f[3]);
+              *reinterpret_cast<u32x4_a4*>(dst) = u;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (col + q < p.Cout) dst[q] = from_f32<T>(f[q]);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T, int TH, int TW, int BN, int KB, int WM, int WN, bool SPLIT>
+int launch_halo(const UConvP& p, hipStream_t st) {
+  constexpr int RS = KB + 16, NH = (TH + 2) * (TW + 2);
+  constexpr size_t ASZ = ((NH * RS + 255) / 256) * 256;
+  size_t lds = ASZ + (size_t)2 * BN * RS;
+  if (lds < 16384) lds = 16384;
+  auto kern = uconv_halo_kernel<T, TH, TW, BN, KB, WM, WN, SPLIT>;
+  const int ntx = (p.Wout + TW - 1) / TW, nty = (p.Hout + TH - 1) / TH;
+  const dim3 grid((unsigned)((int64_t)p.B * ntx * nty), (unsigned)(p.Npad / BN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  return rdst_launch_status("rdst_u_conv");
+}
+
+template <typename T, int KB, bool SPLIT>
+int pick_halo(const UConvP& p, hipStream_t st) {
+  const int64_t big = (int64_t)p.B * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);     // 8 x 16 patches
+  if (p.Npad % 128 == 0) {
+    if (p.Wout >= 16 && big * (p.Npad / 128) >= 256) return launch_halo<T, 8, 16, 128, KB, 2, 2, SPLIT>(p, st);
+    const int64_t small = (int64_t)p.B * ((p.Hout + 7) / 8) * ((p.Wout + 7) / 8);
+    if (small * (p.Npad / 128) >= 256) return launch_halo<T, 8, 8, 128, KB, 2, 2, SPLIT>(p, st);
+    return launch_halo<T, 8, 8, 64, KB, 2, 2, SPLIT>(p, st);
+  }
+  if (p.Npad % 64 == 0) {
+    if (p.Wout >= 16 && big * (p.Npad / 64) >= 256) return launch_halo<T, 8, 16, 64, KB, 2, 2, SPLIT>(p, st);
+    return launch_halo<T, 8, 8, 64, KB, 2, 2, SPLIT>(p, st);
+  }
+  return launch_halo<T, 8, 16, 32, KB, 4, 1, SPLIT>(p, st);
+}
+
 template <typename T, int BM, int BN, int KB, int WM, int WN, bool SPLIT>
 int launch(const UConvP& p, hipStream_t st) {
   constexpr int RS = KB + 16;
@@ -305,6 +599,11 @@ template <typename T, bool SPLIT>
 int pick_kb(const UConvP& p, hipStream_t st) {
   const int es = (int)sizeof(T);
   auto fits = [&](int kb) { return (p.Cin * es) % kb == 0 && (p.C1 * es) % kb == 0; };
+  const bool halo = p.k == 3 && p.stride == 1 && !(RDST_DBGV(p.dbg) & 16);
+  if (halo) {
+    if (fits(128)) return pick_halo<T, 128, SPLIT>(p, st);
+    if (fits(64)) return pick_halo<T, 64, SPLIT>(p, st);
+  }
   if (fits(128)) return pick_bn<T, 128, SPLIT>(p, st);
   if (fits(64)) return pick_bn<T, 64, SPLIT>(p, st);
   if constexpr (!SPLIT)
