@@ -526,8 +526,8 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
     except Exception as e:  # noqa: BLE001 - measurement aid only
         print(f"bench.py: in-step K1 timing unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     if ws16:
-        traffic, tsrc = _pmc_traffic("wattn16_fwd_kernel", ["wattn16_mfma.hip"])
-        t2, t2src = _pmc_traffic("wattn16_bwd_kernel", ["wattn16_mfma.hip"])
+        traffic, tsrc = _pmc_traffic("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
+        t2, t2src = _pmc_traffic("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
         kname, bound_note = "rdst_wattn_fwd (K1, window 16: wattn16_fwd_kernel)", "vector ALU (256 x 256 x 6 exponentials per window); priced against HBM as north_star asks"
     else:
         traffic, tsrc = _pmc_traffic("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"])

@@ -20,9 +20,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "librdst_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
-# per-file extras.  -fno-slp-vectorize: keeps the GELU arithmetic of the fused Mlp kernels on scalar v_fma_f32 / v_mul_f32 —
-# hipcc otherwise pairs adjacent fp32 operations into v_pk_*_f32, which cost several times their scalar halves at issue
-EXTRA_FLAGS = {"mlp_mfma.hip": ["-fno-slp-vectorize"]}
+
 
 
 def _newer(src_list, target):
@@ -47,7 +45,7 @@ def build(force: bool = False, verbose: bool = True, debug: bool = False) -> str
         obj = os.path.join(OBJ, s[:-4] + ".o")
         objs.append(obj)
         if force or _newer([src] + hdrs, obj):
-            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(s, []), "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

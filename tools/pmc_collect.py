@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Collect hardware counters for the kernels of ONE training step of bench.py and write profiles/pmc_latest.json.
 
-Run on the GPU box (through gpurun), from the repo root:   python3 tools/pmc_collect.py [tag [config]]
+Run on the GPU box (through gpurun), from the repo root:   python3 tools/pmc_collect.py [tag [config [merge.json]]]
+(`merge.json`: an earlier collection whose OTHER kernels are carried over, e.g. e1 + ws16 + e1_hrl into one pmc_latest.json)
 
 Method (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): one rocprofv3 run PER counter set, `--kernel-trace --pmc`
 only (no other trace domain), the program itself behind `--`:
@@ -42,6 +43,8 @@ KERNELS = {
     "mlp3_fwd_kernel": ("mlp3_fwd_kernel", ["mlp3_mfma.hip"]),
     "wattn16_fwd_kernel": ("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "wattn16_bwd_kernel": ("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
+    "uconv_halo_kernel": ("uconv_halo_kernel", ["uconv_mfma.hip"]),
+    "uconv_kernel": ("uconv_kernel", ["uconv_mfma.hip"]),
 }
 CONFIG = sys.argv[2] if len(sys.argv) > 2 else "e1"   # bench.py --config (ws16: the window-16 kernels)
 
@@ -106,6 +109,11 @@ def main():
             ent["lds_bank_conflict_frac"] = (mean.get("SQ_LDS_BANK_CONFLICT", 0.0) / mean["SQ_LDS_IDX_ACTIVE"]
                                              if mean.get("SQ_LDS_IDX_ACTIVE") else None)
         out["kernels"][key] = ent
+    if len(sys.argv) > 3 and os.path.exists(sys.argv[3]):
+        with open(sys.argv[3]) as fh:
+            old = json.load(fh)
+        for key, ent in old.get("kernels", {}).items():
+            out["kernels"].setdefault(key, ent)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     dst = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc.json")
     with open(dst, "w") as fh:
