@@ -218,3 +218,59 @@ def test_metrics_psnr_ssim_definitions():
     assert isinstance(m["psnr"], float)
     with pytest.raises(ValueError):
         SRMetrics("fid")
+
+
+# ---- round 3: the loss side of the boundary (loss/sr_loss.py, loss/seg_unet.py), host logic only ---------------------------
+def _loss_paras(**kw):
+    base = dict(gpu_id=-1, precision=False, training_losses=["L1"], loss_scalars={"WarmUP": {"L1": 1}}, training_states=["WarmUP"])
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_srloss_weights_states_and_lazy_report():
+    """SRLoss mirrors loss/sr_loss.py:35-51 (weighted sum over the current state's scalars) and loss/basic_loss.py:94-95
+    (set_training_state); its report converts to floats only when read; components outside section 8 say so."""
+    from rdst_amd.loss import LazyScalars, SRLoss
+    sl = SRLoss(_loss_paras(training_losses=["L1", "MSE"], loss_scalars={"A": {"L1": 1}, "B": {"L1": 0.25, "MSE": 2.0}},
+                            training_states=["A", "B"]))
+    assert sl.loss_components == ["Rec_L1", "Rec_MSE"] and sl.current_training_state == "A"
+    g = torch.Generator().manual_seed(0)
+    p, t = torch.rand(2, 1, 8, 8, generator=g), torch.rand(2, 1, 8, 8, generator=g)
+    la, ra = sl(p, t)
+    assert torch.allclose(la, torch.nn.functional.l1_loss(p, t)) and list(ra.keys()) == ["Rec_L1"]
+    sl.set_training_state("B")
+    lb, rb = sl(p, t)
+    want = 0.25 * torch.nn.functional.l1_loss(p, t) + 2.0 * torch.nn.functional.mse_loss(p, t)
+    assert torch.allclose(lb, want)
+    assert isinstance(rb, LazyScalars) and isinstance(rb.raw("Rec_MSE"), torch.Tensor)       # still a device scalar ...
+    assert isinstance(rb["Rec_MSE"], float) and abs(rb["Rec_MSE"] - torch.nn.functional.mse_loss(p, t).item()) < 1e-7
+    assert dict(rb.items()).keys() == {"Rec_L1", "Rec_MSE"} and all(isinstance(v, float) for v in rb.values())
+    assert sl.state_dict() == {}                       # RecLoss carries no state (basic_loss.py:77-88)
+    with pytest.raises(NotImplementedError):
+        SRLoss(_loss_paras(training_losses=["VGG54"], loss_scalars={"WarmUP": {"VGG54": 1}}))
+
+
+def test_segunet_f_state_dict_is_smp_layout_and_loads_smp_checkpoint(tmp_path):
+    """SegUNet_F carries smp 0.3.x's resnet34-UNet keys (24.4 M parameters), loads a checkpoint written under smp's own names
+    (segmentation_head.* -> tail.*, loss/seg_unet.py:57) strictly, raises on a missing file like loss/seg_unet.py:47-48, and
+    freezes the UNet.  (Parity with smp itself is unpinned: smp is not in the image.)"""
+    from oracle import segunet_oracle as S
+    from rdst_amd.loss import SegUNet_F
+    lay = S.unet_layout(1, 4)
+    mod = SegUNet_F({"label-hr": []}, "OASIS", unet_path="/nonexistent", allow_random_init=True)
+    sd = mod.state_dict()
+    assert list(sd) == list(lay) and all(tuple(sd[k].shape) == lay[k] for k in lay)
+    assert sum(p.numel() for p in mod.parameters()) == 24430532 - 0 * 1      # smp.Unet('resnet34', in_channels=1, classes=4)
+    assert all(not p.requires_grad for p in mod.parameters())
+    w = S.make_unet_weights(1, 4, 5)
+    path = str(tmp_path / "unet_oasis.pt")
+    torch.save({("segmentation_head." + k[5:] if k.startswith("tail.") else k): v for k, v in w.items()}, path)
+    m2 = SegUNet_F({"encoder-L1": [1, 2]}, "OASIS", unet_path=path)
+    assert torch.equal(m2.tail[0].weight, w["tail.0.weight"]) and torch.equal(m2.encoder.layer3[5].bn2.running_var, w["encoder.layer3.5.bn2.running_var"])
+    assert m2.use_mse and m2.loss_names == ["SegUNet(encoder-L1)"]          # 'L1' in the name selects MSELoss (:73-74)
+    assert not SegUNet_F({"encoder-L2": [1]}, "OASIS", unet_path=path).use_mse
+    assert SegUNet_F({"label-gt": []}, "BraTS tumor_only", allow_random_init=True).dice_classes == [1, 2, 3]      # :40-44
+    with pytest.raises(ValueError, match="Pre-trained UNet not exist"):
+        SegUNet_F({"label-hr": []}, "OASIS", unet_path=str(tmp_path / "missing.pt"))
+    with pytest.raises(ValueError):
+        SegUNet_F({"label-hr": []}, "MARS", allow_random_init=True)

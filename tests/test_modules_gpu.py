@@ -330,3 +330,38 @@ def test_swin_block_stochastic_depth_given_mask():
     blk.eval()
     with torch.no_grad():
         assert torch.equal(blk(xg, (H, W)), blk(xg, (H, W)))
+
+
+def test_deepcopy_and_repointed_parameters_after_forward():
+    """A network that has run once can be deep-copied (EMA / best-model snapshots: the packed-weight plan holds ctypes job
+    tables and device pointers, so it lives OUTSIDE the module) and the copy computes on its own weights; re-pointing the
+    parameters afterwards (FlatAdam moves them into one flat buffer) drops the stale plan instead of packing dead storage."""
+    import copy
+    from rdst_amd import ops, optim
+    from util import build_net
+    cfg = O.make_cfg(img_size=16, in_chans=1, sr_scale=2, embed_dim=60, dense_layer_depths=[2], num_heads=[6], window_size=[8],
+                     rdb_depths=[2], mlp_ratio=2.0, growth_rate=30, pre_norm=True, feature_last_operation=True)
+    net = build_net(cfg)
+    net.load_state_dict(O.make_weights(cfg, 3), strict=True)
+    net.to(DEV).eval().set_compute_dtype(torch.bfloat16)
+    x = torch.rand(2, 1, 16, 16, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        y0 = net(x)
+        y1 = net(x)                                   # second forward: served from the plan
+    assert ops.pack_plan_of(net) is not None and "_rdst_pack_plan" not in net.__dict__
+    twin = copy.deepcopy(net)                         # raised "ctypes objects containing pointers cannot be pickled" before
+    assert ops.pack_plan_of(twin) is None
+    with torch.no_grad():
+        for p in twin.parameters():
+            if p.requires_grad:
+                p.mul_(1.5)
+        yt = twin(x)
+        y2 = net(x)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2) and not torch.equal(yt, y0)
+    old_plan = ops.pack_plan_of(net)
+    opt = optim.FlatAdam(net.parameters(), lr=0.0)    # parameters now live in the optimizer's flat buffer
+    assert not old_plan.valid(net)
+    with torch.no_grad():
+        y3 = net(x)
+    assert torch.equal(y3, y0) and ops.pack_plan_of(net) is not old_plan
+    del opt
