@@ -113,6 +113,55 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
   erf_as(x * 0.70710678118654752440f, e, g);                       // g = exp(-x^2/2)
   return fmaf(x * 0.39894228040143267794f, g, 0.5f * (1.0f + e));
 }
+// GELU through a table in LDS (bf16 throughput mode, the fused Mlp kernels): 512 entries of four fp16 over [-8, 8),
+//   entry i = (Phi(u_i), Phi(u_i+1) - Phi(u_i), g(u_i), g(u_i+1) - g(u_i)),  u_i = -8 + i/32,  g = GELU' = Phi + u phi,
+// read with ONE ds_read_b64 and interpolated linearly by v_fma_mix_f32 (fp32 weight x fp16 slope + fp16 value, fp32
+// result): interpolation error <= 3e-5 in Phi, 1e-4 in GELU', fp16 storage 2.4e-4 / 4.9e-4 — the results are then
+// rounded to bf16 (2e-3) anyway — for ~8 vector instructions per element where the erf / exp2 / rcp form takes ~27:
+// those kernels' GELU phases run at the vector-issue floor.  Outside [-8, 8) the clamped index
+// gives 0 / 1.
+#define RDST_GELU_TAB_BYTES 4096
+__device__ __forceinline__ void gelu_tab_fill(char* tab, int tid, int nt) {
+  for (int i = tid; i < 512; i += nt) {
+    const float u0 = -8.f + (float)i * 0.03125f, u1 = u0 + 0.03125f;
+    const float c0 = 0.5f * erfcf(-u0 * 0.70710678118654752440f), c1 = 0.5f * erfcf(-u1 * 0.70710678118654752440f);
+    const float g0 = fmaf(u0 * 0.39894228040143267794f, expf(-0.5f * u0 * u0), c0);
+    const float g1 = fmaf(u1 * 0.39894228040143267794f, expf(-0.5f * u1 * u1), c1);
+    const _Float16 h0 = (_Float16)c0, h2 = (_Float16)g0;
+    const _Float16 h1 = (_Float16)(c1 - (float)h0), h3 = (_Float16)(g1 - (float)h2);   // slopes from the ROUNDED values
+    uint2 w;
+    w.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+    w.y = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+    reinterpret_cast<uint2*>(tab)[i] = w;
+  }
+}
+// forward only: (Phi, slope) pairs alone, 4 bytes per entry (a b32 read of random entries spreads over all 64 banks)
+#define RDST_GELU_TAB4_BYTES 2048
+__device__ __forceinline__ void gelu_tab4_fill(char* tab, int tid, int nt) {
+  for (int i = tid; i < 512; i += nt) {
+    const float u0 = -8.f + (float)i * 0.03125f, u1 = u0 + 0.03125f;
+    const float c0 = 0.5f * erfcf(-u0 * 0.70710678118654752440f), c1 = 0.5f * erfcf(-u1 * 0.70710678118654752440f);
+    const _Float16 h0 = (_Float16)c0, h1 = (_Float16)(c1 - (float)h0);
+    reinterpret_cast<uint32_t*>(tab)[i] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+  }
+}
+// (interpolation weight, byte offset of the entry)
+__device__ __forceinline__ float gelu_tab_index(float u, uint32_t& off) {
+  const float t = __builtin_amdgcn_fmed3f(fmaf(u, 32.f, 256.f), 0.f, 511.99f);
+  off = (uint32_t)t << 3;
+  return __builtin_amdgcn_fractf(t);
+}
+__device__ __forceinline__ float gelu_tab4_index(float u, uint32_t& off) {
+  const float t = __builtin_amdgcn_fmed3f(fmaf(u, 32.f, 256.f), 0.f, 511.99f);
+  off = (uint32_t)t << 2;
+  return __builtin_amdgcn_fractf(t);
+}
+// value + weight * slope of one packed (value = low half, slope = high half) fp16 pair
+__device__ __forceinline__ float gelu_tab_lerp(float w, uint32_t pair) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(pair));
+  return r;
+}
 template <bool FAST = false>
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == RDST_ACT_GELU) return FAST ? gelu_fast(x) : gelu_erf(x);

@@ -56,7 +56,8 @@ struct M3Cfg {
   static constexpr int SB1_B = (2 * NT1 * 32 * 4 + 1023) / 1024 * 1024;
   static constexpr int SB2_OFF = SB1_OFF + SB1_B;                     // [2][NT2*32]
   static constexpr int SB2_B = (2 * NT2 * 32 * 4 + 1023) / 1024 * 1024;
-  static constexpr int SMEM = SB2_OFF + SB2_B;
+  static constexpr int TAB_OFF = SB2_OFF + SB2_B;                     // GELU table (common.h)
+  static constexpr int SMEM = TAB_OFF + RDST_GELU_TAB4_BYTES;
   static constexpr int WGCU = SMEM <= 80 * 1024 ? 2 : 1;
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(TP >= NW, "every wave owns at least one piece of a tile");
@@ -75,6 +76,8 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
   const float* sb1L = reinterpret_cast<const float*>(smem + CF::SB1_OFF);
   const float* sb2L = reinterpret_cast<const float*>(smem + CF::SB2_OFF);
   char* hL = smem + CF::H_OFF;
+  gelu_tab4_fill(smem + CF::TAB_OFF, tid, CF::NTHR);   // visible after the first tile's barrier
+  const char* gtab = smem + CF::TAB_OFF;
 
   typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
   auto make_rsrc = [&](const void* ptr, uint32_t bytes) {
@@ -236,19 +239,35 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
         const float2 mr = *reinterpret_cast<const float2*>(st + tok * 2);
         const float rstd = mr.y, nrm = -mr.y * mr.x;
         char* hrow = hL + tok * HS;
+        // GELU = u Phi(u), Phi from the LDS table (common.h; the erf / exp2 / rcp form kept this phase at the vector-issue
+        // rate): all sixteen table reads of the tile are in flight before the first is used
+        float u[16], fr[16];
+        uint32_t en[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int n0 = nt * 32 + 8 * g4 + 4 * h;
           const float4 S4 = *reinterpret_cast<const float4*>(sb1L + n0);
           const float4 B4 = *reinterpret_cast<const float4*>(sb1L + NT1 * 32 + n0);
-          // (packed fp32 arithmetic, v_pk_fma_f32, was tried here: same time — the phase runs at the vector-issue rate)
-          const float h0 = gelu_fast(fmaf(rstd, acc[4 * g4], fmaf(nrm, S4.x, B4.x)));
-          const float h1 = gelu_fast(fmaf(rstd, acc[4 * g4 + 1], fmaf(nrm, S4.y, B4.y)));
-          const float h2 = gelu_fast(fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4.z, B4.z)));
-          const float h3 = gelu_fast(fmaf(rstd, acc[4 * g4 + 3], fmaf(nrm, S4.w, B4.w)));
-          u32x2_a4 u;
-          u.x = pack_bf16x2(h0, h1); u.y = pack_bf16x2(h2, h3);
-          if (n0 * 2 + 8 <= HS) *reinterpret_cast<u32x2_a4*>(hrow + n0 * 2) = u;   // (padded hidden units past the row are dropped)
+          u[4 * g4] = fmaf(rstd, acc[4 * g4], fmaf(nrm, S4.x, B4.x));
+          u[4 * g4 + 1] = fmaf(rstd, acc[4 * g4 + 1], fmaf(nrm, S4.y, B4.y));
+          u[4 * g4 + 2] = fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4.z, B4.z));
+          u[4 * g4 + 3] = fmaf(rstd, acc[4 * g4 + 3], fmaf(nrm, S4.w, B4.w));
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          uint32_t off;
+          fr[v] = gelu_tab4_index(u[v], off);
+          en[v] = *reinterpret_cast<const uint32_t*>(gtab + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n0 = nt * 32 + 8 * g4 + 4 * h;
+          const float h0 = u[4 * g4] * gelu_tab_lerp(fr[4 * g4], en[4 * g4]), h1 = u[4 * g4 + 1] * gelu_tab_lerp(fr[4 * g4 + 1], en[4 * g4 + 1]);
+          const float h2 = u[4 * g4 + 2] * gelu_tab_lerp(fr[4 * g4 + 2], en[4 * g4 + 2]), h3 = u[4 * g4 + 3] * gelu_tab_lerp(fr[4 * g4 + 3], en[4 * g4 + 3]);
+          u32x2_a4 uu;
+          uu.x = pack_bf16x2(h0, h1); uu.y = pack_bf16x2(h2, h3);
+          if (n0 * 2 + 8 <= HS) *reinterpret_cast<u32x2_a4*>(hrow + n0 * 2) = uu;   // (padded hidden units past the row are dropped)
         }
       }
     STAMP_ADD(2);

@@ -37,6 +37,7 @@ struct MlpArgs {
   float* slab; int64_t slab_stride;   // per-workgroup partials: G1 [hid][C+1], then dW2^T [hid+1][C]
   int64_t M; int C; int hid; int64_t ntiles; int tiles_per_wg;
   unsigned long long* stamps;   // RDST_MLP_STAMPS=n (debug): [grid][16] s_memtime stamps of thread 0
+  int dbg;                      // RDST_MLP_DBG (debug build): ablation bits of mlp_bwd_kernel
 };
 
 template <int NCT> struct MlpCfg {
@@ -47,7 +48,11 @@ template <int NCT> struct MlpCfg {
   static constexpr int LDW = NCT == 4 ? 336 : CP * 2 + 16, LDX = LDW, LDH = 64;
   static constexpr int OFF_W1 = 0, OFF_XH = OFF_W1 + JP * LDW, OFF_DY = OFF_XH + 32 * LDX, OFF_DH = OFF_DY + 32 * LDX,
                        OFF_B1 = OFF_DH + JP * LDH, OFF_SM = OFF_B1 + JP * 4, OFF_RED = OFF_SM + 32 * 4,
-                       SMEM = OFF_RED + NCT * 32 * 8;
+                       OFF_TAB = OFF_RED + NCT * 32 * 8, OFF_W2L = OFF_TAB + RDST_GELU_TAB_BYTES;
+  // C = 120: the last W2L of the wave's KC W2^T packs live in LDS, not in registers (128 accumulators + 32 pack registers
+  // + the tiles' fragments do not fit 256: hipcc spilled three packs and RELOADED them in every tile behind a
+  // vmcnt(0), which also waits for the next tile's prefetch)
+  static constexpr int W2L = NCT == 4 ? 3 : 0, SMEM = OFF_W2L + W2L * NJ * 1024;
 };
 
 __device__ __forceinline__ void unpack8(const u32x4_a4& v, float (&f)[8]) {
@@ -55,9 +60,8 @@ __device__ __forceinline__ void unpack8(const u32x4_a4& v, float (&f)[8]) {
   f[4] = bf16lo(v.z); f[5] = bf16hi(v.z); f[6] = bf16lo(v.w); f[7] = bf16hi(v.w);
 }
 
-// GELU(erf) and its derivative for TWO elements at a time on the packed fp32 pipes (v_pk_fma_f32 / v_pk_mul_f32):
-// the kernel's phase 1 is bound by exactly this arithmetic (measured: ~100 cycles per element unpacked).
-// erf by Abramowitz & Stegun 7.1.26 as in common.h (|error| <= 1.5e-7); the coefficients carry the factor 1/2:
+// GELU(erf) for TWO elements at a time on the packed fp32 pipes (the fallback forward below): erf by Abramowitz & Stegun
+// 7.1.26 as in common.h (|error| <= 1.5e-7); the coefficients carry the factor 1/2:
 //   q = (1/2) erfc(|x|/sqrt2),  cdf = x >= 0 ? 1 - q : q,  pdf*sqrt(2 pi) = ex = exp(-x^2/2)
 __device__ __forceinline__ void gelu_pair(f32x2 x, f32x2& cdf, f32x2& ex) {
   const f32x2 z = x * 0.70710678118654752440f;
@@ -89,6 +93,8 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
   float* b1s = reinterpret_cast<float*>(smem + CF::OFF_B1);
   float* sm = reinterpret_cast<float*>(smem + CF::OFF_SM);
   float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
+  const lds_cp gtab = (lds_cp)(smem + CF::OFF_TAB);
+  gelu_tab_fill(smem + CF::OFF_TAB, tid, NT);   // visible after the prologue's barriers
   int nst = 0;
   auto stamp = [&]() {
     if (RDST_DBGV(p.stamps) && tid == 0 && nst < 14) p.stamps[(size_t)blockIdx.x * 16 + nst++] = __builtin_readcyclecounter();
@@ -97,7 +103,8 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
 
   // ---- prologue ------------------------------------------------------------------------------------
   // W2^T tile of the wave, in registers for the whole kernel: pack t, element e = W2[16t + 8hh + e][j]
-  Pack16 w2b[CF::KC];
+  Pack16 w2b[CF::KC - CF::W2L];
+  const lds_cp w2l = (lds_cp)(smem + CF::OFF_W2L + (wave * 64 + lane) * 16);   // + NJ * 1024 per pack
   {
     float f[CF::KC][8];
 #pragma unroll
@@ -111,7 +118,12 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     for (int t = 0; t < CF::KC; ++t) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[t][e] = (16 * t + 8 * hh + e < C && j < hid) ? f[t][e] : 0.f;
-      w2b[t] = MM::pack(f[t]);
+      if (t < CF::KC - CF::W2L) w2b[t < CF::KC - CF::W2L ? t : 0] = MM::pack(f[t]);
+      else {   // read back by this lane only
+        const Pack16 pk = MM::pack(f[t]);
+        u32x4_t v; v.x = pk.w[0]; v.y = pk.w[1]; v.z = pk.w[2]; v.w = pk.w[3];
+        *reinterpret_cast<LDS_AS u32x4_t*>(w2l + (t - (CF::KC - CF::W2L)) * NJ * 1024) = v;
+      }
     }
   }
   stamp();   // W2 tile loaded
@@ -316,25 +328,42 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       const float bj = b1s[j];
 #pragma unroll
       for (int v = 0; v < 16; ++v) { ah[v] = bj; ad[v] = 0.f; }
+      if (!(RDST_DBGV(p.dbg) & 2))
 #pragma unroll
       for (int t = 0; t < CF::KC; ++t) {
         const Pack16 xa = lds_pack(xrow + 32 * t), wb = lds_pack(wrow + 32 * t), ya = lds_pack(yrow + 32 * t);
         MM::mma(ah, xa, wb);        // rows (registers) = tokens, columns (lanes) = hidden units
-        MM::mma(ad, ya, w2b[t]);
+        if (t < CF::KC - CF::W2L) MM::mma(ad, ya, w2b[t < CF::KC - CF::W2L ? t : 0]);
+        else MM::mma(ad, ya, lds_pack(w2l + (t - (CF::KC - CF::W2L)) * NJ * 1024));
       }
       const bool ones = j == hid;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        // GELU and GELU' from the LDS table (common.h): LB reads in flight before the first is used (8, or 4 where the
+        // 128 weight-gradient accumulators of C = 120 leave no registers: a spill inside this loop costs a vmcnt(0),
+        // i.e. the whole prefetch of the next tile)
+        constexpr int LB = NCT == 4 ? 4 : 8;
 #pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          f32x2 x, g, cdf, ex;
-          x.x = ah[8 * s + 2 * e2]; x.y = ah[8 * s + 2 * e2 + 1];
-          g.x = ad[8 * s + 2 * e2]; g.y = ad[8 * s + 2 * e2 + 1];
-          gelu_pair(x, cdf, ex);
-          const f32x2 hv = x * cdf;
-          const f32x2 dv = g * __builtin_elementwise_fma(x * 0.39894228040143267794f, ex, cdf);
-          hA[s].w[e2] = ones ? 0x3f803f80u : pack_bf16x2(hv.x, hv.y);   // the ones row: d(bias) of fc2
-          dA[s].w[e2] = pack_bf16x2(dv.x, dv.y);
+        for (int b = 0; b < 8; b += LB) {
+          float fr[LB];
+          u32x2_t en[LB];
+#pragma unroll
+          for (int k = 0; k < LB; ++k) {
+            uint32_t off;
+            fr[k] = gelu_tab_index(ah[8 * s + b + k], off);
+            if (RDST_DBGV(p.dbg) & 1) { en[k].x = off; en[k].y = off + 1; }
+            else en[k] = *reinterpret_cast<const LDS_AS u32x2_t*>(gtab + off);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < LB; k += 2) {
+            const int v = 8 * s + b + k;
+            const float h0 = ah[v] * gelu_tab_lerp(fr[k], en[k].x), h1 = ah[v + 1] * gelu_tab_lerp(fr[k + 1], en[k + 1].x);
+            const float d0 = ad[v] * gelu_tab_lerp(fr[k], en[k].y), d1 = ad[v + 1] * gelu_tab_lerp(fr[k + 1], en[k + 1].y);
+            const uint32_t hp = pack_bf16x2(h0, h1);
+            hA[s].w[(b + k) / 2] = ones ? 0x3f803f80u : hp;   // the ones row: d(bias) of fc2
+            dA[s].w[(b + k) / 2] = pack_bf16x2(d0, d1);
+          }
         }
         // dHp -> [hidden][token] image: registers 8s..8s+3 are tokens 16s+4hh.., 8s+4..8s+7 tokens 16s+8+4hh..
         u32x2_t lo, hi;
@@ -346,6 +375,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     __syncthreads();   // B2: dHp image complete
     stamp();   // 3: phase 1 done
     // ---- phase 2: weight gradients (contraction over the tile's 32 tokens, 2 k-steps)
+    if (!(RDST_DBGV(p.dbg) & 4))
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -362,6 +392,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       f32x16 dx2;   // two independent accumulation chains: only one wave per SIMD is in this phase
 #pragma unroll
       for (int v = 0; v < 16; ++v) { dx[v] = 0.f; dx2[v] = 0.f; }
+      if (!(RDST_DBGV(p.dbg) & 8))
 #pragma unroll
       for (int kk = 0; kk < CF::KJ; kk += 2) {
         const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
@@ -1234,6 +1265,7 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
   }
   static int split = -1;
   if (split < 0) { const char* e = rdst_dbg_getenv("RDST_MLP_SPLIT"); split = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = rdst_dbg_getenv("RDST_MLP_DBG"); p.dbg = e ? atoi(e) : 0; }
   static int want_stamps = -1;
   if (want_stamps < 0) { const char* e = rdst_dbg_getenv("RDST_MLP_STAMPS"); want_stamps = e ? atoi(e) : 0; }
   if (want_stamps > 0) {
