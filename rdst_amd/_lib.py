@@ -28,6 +28,8 @@ SIGNATURES = {
     "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
                                 _l, _i, _i, _f, _i, _p]),
+    "rdst_ln_linear_bwd2": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
+                                 _l, _i, _i, _f, _i, _p, _p, _l]),
     "rdst_mlp_fused_supported": (_i, [_i, _i, _i]),
     "rdst_mlp_fwd_workspace": (_z, [_i, _i]),
     "rdst_mlp_fwd_packable": (_i, [_i, _i, _i]),
@@ -67,7 +69,7 @@ SIGNATURES = {
     "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
-ABI_VERSION = 5             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
+ABI_VERSION = 6             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 

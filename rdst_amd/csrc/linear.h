@@ -46,7 +46,7 @@ int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float
 int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
                              const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,
                              int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
-                             int64_t M, int K, int N, float s, hipStream_t st);
+                             int64_t M, int K, int N, float s, hipStream_t st, const bf16* acc2 = nullptr, int64_t ldacc2 = 0);
 
 // streaming forward for the E1 shapes, bf16 (lin3_mfma.hip); RDST_ENOTSUP for everything else.
 // wpack: lin3_pack_bytes(K, N) bytes of 16-byte aligned device scratch (NULL -> RDST_ENOTSUP).

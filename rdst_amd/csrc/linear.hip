@@ -279,11 +279,19 @@ template <typename T>
 int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act, const float* Wt,
           const T* dY, int64_t lddy, T* dX, int64_t lddx, const T* acc, int64_t ldacc, float* dW, float* dbias,
           float* dln_w,
-          float* dln_b, float* wsp, int64_t M, int K, int N, float s, hipStream_t st) {
+          float* dln_b, float* wsp, int64_t M, int K, int N, float s, hipStream_t st, const T* acc2 = nullptr, int64_t ldacc2 = 0) {
   // workspace carve: [dA: M*K] [slabW: splits*N*K] [small: kSmallBlocks * max(N, 2K)]
   float* dA = wsp;
   float* slabW = dA + (ln_w ? M * K : 0);
   float* small = slabW + slab_floats(M, K, N);
+  if (acc2) {   // a second addend of dX: only the one-pass LayerNorm-Linear backward of the E1 shapes takes it (nothing is launched otherwise)
+    if constexpr (sizeof(T) == 2) {
+      if (Wt && ln_w && ln_b && dW && dbias && dln_w && dln_b && dX && K <= 128 && (int64_t)N * (K + 1) <= M * K)
+        return linear_ln_bwd_fused_bf16(X, ldx, ln_w, ln_b, stats, Wt, dY, lddy, dX, lddx, acc, ldacc, dW, dbias, dln_w, dln_b, slabW,
+                                        dA, M, K, N, s, st, acc2, ldacc2);
+    }
+    return RDST_ENOTSUP;
+  }
   LinIn<T> fin{X, ldx, stats, ln_w, ln_b, in_act};
   if (Wt) {
     // LayerNorm-fused Linear with everything requested in one call: the weight-gradient pass runs on x-hat and
@@ -450,12 +458,12 @@ extern "C" size_t rdst_ln_linear_bwd_workspace(int64_t M, int K, int N) {
   return sizeof(float) * ((size_t)M * K + slab_floats(M, K, N) + (size_t)kSmallBlocks * mx + 2 * (size_t)K + 64);
 }
 
-extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
+extern "C" int rdst_ln_linear_bwd2(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
                                   int in_act, const float* Wt, const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx,
                                   const void* dX_add, int64_t ld_dx_add, float* dW, float* dbias, float* dln_w, float* dln_b,
                                   void* workspace,
                                   size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
-                                  void* stream) {
+                                  void* stream, const void* dX_add2, int64_t ld_dx_add2) {
   if (!X || !dY || !workspace) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: null pointer");
   if (M < 0 || K <= 0 || N <= 0) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: bad dimensions");
   if (ln_w && !stats) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: LayerNorm needs the forward's stats");
@@ -466,6 +474,7 @@ extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   float* wsp = (float*)workspace;
+  if (dX_add2 && (!Wt || dtype != RDST_BF16)) return RDST_ENOTSUP;
   if (!Wt) {
     if (dtype == RDST_F32)
       return ln_only_bwd<float>((const float*)X, ld_x, ln_w, stats, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dln_w, dln_b, wsp, M, K, out_scale, st);
@@ -473,5 +482,15 @@ extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w
   }
   if (dtype == RDST_F32)
     return bwd_t<float>((const float*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
-  return bwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
+  return bwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st,
+                     (const bf16*)dX_add2, ld_dx_add2);
+}
+
+extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* stats,
+                                  int in_act, const float* Wt, const void* dY, int64_t ld_dy, void* dX, int64_t ld_dx,
+                                  const void* dX_add, int64_t ld_dx_add, float* dW, float* dbias, float* dln_w, float* dln_b,
+                                  void* workspace, size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
+                                  void* stream) {
+  return rdst_ln_linear_bwd2(X, ld_x, ln_w, ln_b, stats, in_act, Wt, dY, ld_dy, dX, ld_dx, dX_add, ld_dx_add, dW, dbias, dln_w, dln_b,
+                             workspace, workspace_bytes, M, K, N, out_scale, dtype, stream, nullptr, 0);
 }

@@ -25,6 +25,7 @@ using MM = Mma<bf16>;
 struct LB3Args {
   const bf16* X; int64_t ldx; const float* stats; const float* lnw; const float* W;
   const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx; const bf16* Acc; int64_t ldacc;
+  const bf16* Acc2; int64_t ldacc2;   // second addend of dX, read straight from memory by the lane that stores the row chunk
   float* slab; int64_t slab_stride;
   int64_t M; int64_t ntiles; int tiles_per_wg;
 };
@@ -248,6 +249,21 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
   u32x2_t xs[4], as[4];
   float rstd = 0.f;
   int64_t prow = -1;
+  // second addend (the strided gradient slice of a dense join): the two 16-B chunks this lane will store are requested
+  // when the tile's rows are known and added in finish(), one barrier later (LN) — no LDS, no loader slots
+  const bool has_acc2 = p.Acc2 != nullptr;
+  u32x4_a4 a2[2];
+  a2[0] = u32x4_a4{0u, 0u, 0u, 0u}; a2[1] = a2[0];
+  auto fetch2 = [&]() {
+    if (!has_acc2) return;
+    const int64_t row = prow < p.M ? prow : p.M - 1;
+#pragma unroll
+    for (int gp2 = 0; gp2 < 2; ++gp2) {
+      const int cb = 32 * dct + 8 * (2 * gp2 + hh);
+      const int cc = cb + 8 <= K ? cb : K - 8;   // (a chunk past the row's end is re-pointed inside it and masked in finish())
+      a2[gp2] = *reinterpret_cast<const u32x4_a4*>(p.Acc2 + row * p.ldacc2 + cc);
+    }
+  };
   auto finish = [&](int pb) {
     float s1 = 0.f, s2 = 0.f;
     if (LN) {
@@ -278,6 +294,18 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
           c8[4 + e] = __uint_as_float(sw[1]);
         }
         const int cb = 32 * dct + 8 * (2 * gp2 + hh);
+        if (has_acc2) {   // chunk loaded at min(cb, K - 8): element e of the store is element e + (cb - that) of the load
+          const int sh = cb + 8 <= K ? 0 : cb - (K - 8);
+          const float f2[8] = {bf16lo(a2[gp2].x), bf16hi(a2[gp2].x), bf16lo(a2[gp2].y), bf16hi(a2[gp2].y),
+                               bf16lo(a2[gp2].z), bf16hi(a2[gp2].z), bf16lo(a2[gp2].w), bf16hi(a2[gp2].w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v = (e + sh == k) ? f2[k] : v;
+            c8[e] += v;
+          }
+        }
         if (cb + 8 <= K) {
           u32x4_a4 u;
           u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
@@ -324,6 +352,7 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
       as[g4] = *reinterpret_cast<const LDS_AS u32x2_t*>(xrow + CF::OFF_AC + 16 * g4);
     }
     prow = tile * 32 + r;
+    fetch2();
     if (LN) {
       rstd = reinterpret_cast<const float*>(buf + CF::OFF_SM)[r];
       float s1 = 0.f, s2 = 0.f;
@@ -373,15 +402,16 @@ int lb3_launch(LB3Args& p, int64_t max_wgs, int* grid_out, hipStream_t st) {
 // The E1 shapes of the one-pass Linear backward; RDST_ENOTSUP for everything else (the caller falls back to
 // lnlin_bwd_kernel).  Leaves one slab row per workgroup (*grid_out of them); the caller queues the reductions.
 int lnlin3_bwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* stats, const float* Wt, const bf16* dY,
-                    int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc, float* slab, int64_t slab_stride,
-                    int64_t M, int K, int N, int64_t max_wgs, int* grid_out, hipStream_t st) {
+                    int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc, const bf16* acc2, int64_t ldacc2,
+                    float* slab, int64_t slab_stride, int64_t M, int K, int N, int64_t max_wgs, int* grid_out, hipStream_t st) {
   static int off = -1;
   if (off < 0) { const char* e = rdst_dbg_getenv("RDST_LB3_OFF"); off = e ? atoi(e) : 0; }
   if (off) return RDST_ENOTSUP;
   const bool ln = ln_w != nullptr;
   LB3Args p{};
   p.X = X; p.ldx = ldx; p.stats = stats; p.lnw = ln_w; p.W = Wt; p.dY = dY; p.lddy = lddy; p.dX = dX; p.lddx = lddx;
-  p.Acc = acc; p.ldacc = ldacc; p.slab = slab; p.slab_stride = slab_stride; p.M = M; p.ntiles = (M + 31) / 32;
+  p.Acc = acc; p.ldacc = ldacc; p.Acc2 = acc2; p.ldacc2 = ldacc2; p.slab = slab; p.slab_stride = slab_stride; p.M = M;
+  p.ntiles = (M + 31) / 32;
 #define RDST_LB3(KK, NN, LL) if (K == KK && N == NN && ln == LL) return lb3_launch<KK, NN, LL>(p, max_wgs, grid_out, st);
   RDST_LB3(60, 180, true) RDST_LB3(90, 270, true) RDST_LB3(120, 360, true)
   RDST_LB3(60, 30, true) RDST_LB3(90, 30, true) RDST_LB3(120, 30, true)

@@ -1378,8 +1378,8 @@ extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, cons
 int wgrad_reduce_launch(const float* slab, int nwg, int N, int K, float s, float* dW, float* dbias, hipStream_t st);
 
 int lnlin3_bwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* stats, const float* Wt, const bf16* dY,
-                    int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc, float* slab, int64_t slab_stride,
-                    int64_t M, int K, int N, int64_t max_wgs, int* grid_out, hipStream_t st);
+                    int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc, int64_t ldacc, const bf16* acc2, int64_t ldacc2,
+                    float* slab, int64_t slab_stride, int64_t M, int K, int N, int64_t max_wgs, int* grid_out, hipStream_t st);
 
 // fixed-order sums of the per-workgroup bf16 G4 slabs (+ the LayerNorm finish) of the one-pass Linear backward kernels
 static int lnlin_bwd_reduce(float* slab, int grid, int64_t slab_stride, bool ln, const float* Wt, const float* ln_w,
@@ -1401,7 +1401,7 @@ static int lnlin_bwd_reduce(float* slab, int grid, int64_t slab_stride, bool ln,
 int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats,
                              const float* Wt, const bf16* dY, int64_t lddy, bf16* dX, int64_t lddx, const bf16* acc,
                              int64_t ldacc, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G,
-                             int64_t M, int K, int N, float s, hipStream_t st) {
+                             int64_t M, int K, int N, float s, hipStream_t st, const bf16* acc2, int64_t ldacc2) {
   static int off = -1;
   if (off < 0) { const char* e = rdst_dbg_getenv("RDST_LNLIN_V1"); off = e ? atoi(e) : 0; }   // 1: all off, 2: the plain-Linear form off
   const bool ln = ln_w != nullptr;
@@ -1424,10 +1424,11 @@ int linear_ln_bwd_fused_bf16(const bf16* X, int64_t ldx, const float* ln_w, cons
   const int64_t slab_stride = (int64_t)((N + 3) / 4) * (K + 1);   // bf16 G4 slab: 8-byte groups
   {  // the re-cut kernel for the E1 shapes (lnlin3_mfma.hip)
     int g3 = 0;
-    const int rc3 = lnlin3_bwd_bf16(X, ldx, ln_w, stats, Wt, dY, lddy, dX, lddx, acc, ldacc, slab, slab_stride, M, K, N,
-                                    linear_wgrad_max_wgs(N), &g3, st);
+    if (acc2 && (((uintptr_t)acc2 & 3) || (ldacc2 & 1) || (uint64_t)M * (uint64_t)ldacc2 * 2 >= (1ull << 31))) return RDST_ENOTSUP;
+    const int rc3 = lnlin3_bwd_bf16(X, ldx, ln_w, stats, Wt, dY, lddy, dX, lddx, acc, ldacc, acc2, ldacc2, slab, slab_stride, M, K,
+                                    N, linear_wgrad_max_wgs(N), &g3, st);
     if (rc3 == 0) return lnlin_bwd_reduce(slab, g3, slab_stride, ln, Wt, ln_w, ln_b, dW, dbias, dln_w, dln_b, G, N, K, st);
-    if (rc3 != RDST_ENOTSUP) return rc3;
+    if (rc3 != RDST_ENOTSUP || acc2) return rc3;   // (only the re-cut kernel takes a second addend)
   }
   const int CP = 32 * nct, LDW = nct == 4 ? 288 : CP * 2 + 16, LDX = nct == 4 ? 336 : CP * 2 + 16, NP = 32 * NW, LDY = lnlin_ldy(NP);
   const int smem = NP * LDW + 2 * 32 * LDX + 32 * LDY + 128 + nct * 32 * 8;

@@ -88,11 +88,20 @@ class DenseSTLayer(nn.Module):
         self.depth = depth
         self.pre_norm = pre_norm
 
-    def new_features(self, x, x_size, out_slot=None):
+    def new_features(self, x, x_size, out_slot=None, sink=None):
         """dense_scale * tail(body(head(x))): the channels this layer appends."""
         y = _apply_dim_modifier(self.head, x)
-        y = self.body(y, x_size)
+        y = self.body(y, x_size, sink=sink) if sink is not None else self.body(y, x_size)
         return _apply_dim_modifier(self.tail, y, out_scale=self.dense_scale, out_slot=out_slot)
+
+    def _grad_sink(self, x):
+        """An ops.GradSink when the body's first Swin block is the only other consumer of x and takes the join's
+        gradient slice inside its backward (head = Identity, the block runs as one autograd node); else None."""
+        blocks = self.body.blocks
+        if isinstance(self.head, nn.Identity) and len(blocks) > 0 and blocks[0].fuses_input_gradient() \
+                and x.requires_grad and torch.is_grad_enabled():
+            return ops.GradSink()
+        return None
 
     def forward(self, x, x_size):
         return torch.cat((x, self.new_features(x, x_size)), 2)
@@ -100,12 +109,13 @@ class DenseSTLayer(nn.Module):
     def forward_dense(self, x, x_size, buf):
         """The same with x already lying in the first channels of the RDSTB's dense buffer: the new channels are
         written next to it in place and the wider view is returned (no copy of x)."""
+        sink = self._grad_sink(x)
         if not _slot_ok(self.tail):
-            new = self.new_features(x, x_size)
+            new = self.new_features(x, x_size, sink=sink)
             buf.slot(x.shape[-1], new.shape[-1]).copy_(new.detach())   # values only: `new` itself stays in the graph
-            return ops.dense_join(x, new, buf)
-        new = self.new_features(x, x_size, out_slot=(buf, x.shape[-1]))
-        return ops.dense_join(x, new, buf)
+            return ops.dense_join(x, new, buf, sink)
+        new = self.new_features(x, x_size, out_slot=(buf, x.shape[-1]), sink=sink)
+        return ops.dense_join(x, new, buf, sink)
 
 
 def _res_connection(resi_connection, cin, cout):

@@ -206,7 +206,14 @@ class SwinTransformerBlock(nn.Module):
         diff = mw.unsqueeze(1) - mw.unsqueeze(2)
         return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
 
-    def forward(self, x, x_size):
+    def fuses_input_gradient(self):
+        """True when forward() runs as the single autograd node that can add a dense join's gradient slice inside its
+        backward (ops.GradSink): no stochastic depth in training, qkv bias present."""
+        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.:
+            return False
+        return self.attn.qkv.bias is not None
+
+    def forward(self, x, x_size, sink=None):
         H, W = x_size
         n1w, n1b = _ln_params(self.norm1)
         n2w, n2b = _ln_params(self.norm2)
@@ -227,7 +234,7 @@ class SwinTransformerBlock(nn.Module):
             return self.mlp(x, norm=self.norm2, residual=x)
         return ops.swin_block(x, n1w, n1b, at.qkv.weight, at.qkv.bias, at.relative_position_bias_table, at.proj.weight,
                               at.proj.bias, n2w, n2b, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, H, W,
-                              self.num_heads, self.window_size, self.shift_size, at.scale)
+                              self.num_heads, self.window_size, self.shift_size, at.scale, sink=sink)
 
     def extra_repr(self) -> str:
         return f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, " \
@@ -257,9 +264,10 @@ class BasicLayer(nn.Module):
             for i in range(depth)])
         self.downsample = None
 
-    def forward(self, x, x_size):
-        for blk in self.blocks:
-            x = blk(x, x_size)
+    def forward(self, x, x_size, sink=None):
+        """sink (ops.GradSink, optional): handed to the FIRST block, the consumer of x (see DenseSTLayer.forward_dense)."""
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, x_size, sink=sink) if (i == 0 and sink is not None) else blk(x, x_size)
         return x
 
     def extra_repr(self) -> str:

@@ -307,17 +307,28 @@ def window_attention(qkv: torch.Tensor, table: torch.Tensor, H: int, W: int, hea
 
 
 def _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy, lddy, dx, lddx, dx_add, ld_add, dw, db, dlw, dlb,
-                     M, K, N, out_scale, code, dev, join=True, keep=None):
+                     M, K, N, out_scale, code, dev, join=True, keep=None, dx_add2=None, ld_add2=0):
     """rdst_ln_linear_bwd with the weight-gradient half on the side stream (see TWO_STREAM_BACKWARD).
     join=False leaves the side stream un-joined (the caller joins once, later) and parks the workspace in
-    `keep` so it outlives the asynchronous kernel."""
+    `keep` so it outlives the asynchronous kernel.  dx_add2: a second (strided) addend of dx — folded into the
+    kernel where it takes one (rdst_ln_linear_bwd2), added afterwards otherwise."""
     nbytes = lib.rdst_ln_linear_bwd_workspace(M, K, N)
 
     def call(dx_, add_, dw_, db_, dlw_, dlb_, wsp_):
+        if dx_add2 is not None and dx_ is not None:
+            rc = lib.rdst_ln_linear_bwd2(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
+                                         dy.data_ptr(), lddy, _ptr(dx_), lddx, _ptr(add_), ld_add, _ptr(dw_), _ptr(db_),
+                                         _ptr(dlw_), _ptr(dlb_), wsp_.data_ptr(), nbytes, M, K, N, out_scale, code,
+                                         _stream(), dx_add2.data_ptr(), ld_add2)
+            if rc != _lib.ENOTSUP:
+                _lib.check(rc, "rdst_ln_linear_bwd2")
+                return
         _lib.check(lib.rdst_ln_linear_bwd(x.data_ptr(), ldx, _ptr(lw), _ptr(lb), _ptr(stats), in_act, _ptr(w),
                                           dy.data_ptr(), lddy, _ptr(dx_), lddx, _ptr(add_), ld_add, _ptr(dw_), _ptr(db_),
                                           _ptr(dlw_), _ptr(dlb_), wsp_.data_ptr(), nbytes, M, K, N, out_scale, code,
                                           _stream()), "rdst_ln_linear_bwd")
+        if dx_add2 is not None and dx_ is not None:
+            dx_.add_(dx_add2)
 
     wgrad = dw is not None or db is not None
     dgrad = dx is not None or dlw is not None or dlb is not None
@@ -427,25 +438,43 @@ class _IntoDense(torch.autograd.Function):
         return g, None
 
 
+class GradSink:
+    """Carries the prefix slice of a dense join's gradient to the Swin block that consumed the prefix: `prefix` feeds
+    the DenseSTLayer's body AND the join, so autograd would add the body's dX and this strided slice in a separate
+    kernel (24 per E1 step).  With a sink the join returns None for the prefix and the body's first block adds the
+    slice inside its last backward kernel.  The join's backward always runs first (it consumes what the body made)."""
+
+    def __init__(self):
+        self.extra = None
+
+    def take(self):
+        e, self.extra = self.extra, None
+        return e
+
+
 class _DenseJoin(torch.autograd.Function):
     """cat(prefix, new) where both already lie side by side in the dense buffer: returns the wider view."""
 
     @staticmethod
-    def forward(ctx, prefix, new, buf):
+    def forward(ctx, prefix, new, buf, sink=None):
         ctx.c = prefix.shape[-1]
+        ctx.sink = sink
         return buf.slot(0, prefix.shape[-1] + new.shape[-1])
 
     @staticmethod
     def backward(ctx, g):
-        return g[..., :ctx.c], g[..., ctx.c:], None
+        if ctx.sink is not None and ctx.needs_input_grad[0]:
+            ctx.sink.extra = g[..., :ctx.c]
+            return None, g[..., ctx.c:], None, None
+        return g[..., :ctx.c], g[..., ctx.c:], None, None
 
 
 def into_dense(x: torch.Tensor, buf: DenseBuffer) -> torch.Tensor:
     return _IntoDense.apply(x, buf)
 
 
-def dense_join(prefix: torch.Tensor, new: torch.Tensor, buf: DenseBuffer) -> torch.Tensor:
-    return _DenseJoin.apply(prefix, new, buf)
+def dense_join(prefix: torch.Tensor, new: torch.Tensor, buf: DenseBuffer, sink: "GradSink" = None) -> torch.Tensor:
+    return _DenseJoin.apply(prefix, new, buf, sink)
 
 
 def ln_linear(x: torch.Tensor, ln_w: Optional[torch.Tensor], ln_b: Optional[torch.Tensor],
@@ -468,7 +497,8 @@ class _SwinBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, H, W, heads, ws,
-                shift, scale):
+                shift, scale, sink=None):
+        ctx.sink = sink
         _need_gpu(x, qkvw, table, projw, fc1w, fc2w)
         lib = _lib.load()
         C = x.shape[-1]
@@ -629,21 +659,29 @@ class _SwinBlock(torch.autograd.Function):
                                       heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
         # LN1 + qkv, plus the residual fan-out of x:  dx = dx1 + LN1'(dqkv Wqkv)
         dx = torch.empty(x.shape, dtype=dt, device=dev) if need[0] else None
+        extra = ctx.sink.take() if ctx.sink is not None else None   # the dense join's gradient slice for x (GradSink)
+        if extra is not None and need[0]:
+            extra, ld_extra = _rows(extra)
+            keep.append(extra)
+        else:
+            extra, ld_extra = None, 0
         _linear_bwd_call(lib, x, ldx, n1w, n1b, stats1, ACT_NONE, qkvw, dqkv, 3 * C, dx, C, dx1 if need[0] else None, C,
-                         dqkvw, dqkvb, dn1w, dn1b, M, C, 3 * C, 1.0, code, dev, join=False, keep=keep)
+                         dqkvw, dqkvb, dn1w, dn1b, M, C, 3 * C, 1.0, code, dev, join=False, keep=keep, dx_add2=extra,
+                         ld_add2=ld_extra)
         if TWO_STREAM_BACKWARD:
             torch.cuda.current_stream().wait_stream(_side_stream(dev))   # the one join of this block
         if not need[5]:
             dtab = None
         return (dx, dn1w, dn1b, dqkvw, dqkvb, dtab, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b, dfc2w, dfc2b,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def swin_block(x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, H, W, heads, ws, shift,
-               scale):
-    """SwinTransformerBlock.forward (networks/swin_transformer_sr.py:234-274) as one autograd node."""
+               scale, sink=None):
+    """SwinTransformerBlock.forward (networks/swin_transformer_sr.py:234-274) as one autograd node.  sink: a GradSink
+    whose slice (set by a dense join of x) is added to dx inside the block's last backward kernel."""
     return _SwinBlock.apply(x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, H, W, heads,
-                            ws, shift, scale)
+                            ws, shift, scale, sink)
 
 
 # ------------------------------------------------------------------------------------------------
