@@ -25,7 +25,7 @@ using MM = Mma<bf16>;
 struct LB3Args {
   const bf16* X; int64_t ldx; const float* stats; const float* lnw; const float* W;
   const bf16* dY; int64_t lddy; bf16* dX; int64_t lddx; const bf16* Acc; int64_t ldacc;
-  const bf16* Acc2; int64_t ldacc2;   // second addend of dX, read straight from memory by the lane that stores the row chunk
+  const bf16* Acc2; int64_t ldacc2;   // second addend of dX (same chunks as Acc, summed with it on the way into LDS)
   float* slab; int64_t slab_stride;
   int64_t M; int64_t ntiles; int tiles_per_wg;
 };
@@ -76,8 +76,10 @@ struct LB3 {
 template <class CF, bool LN, int SY, int SX, int SA>
 struct LB3Loader {
   static constexpr int NS = SY + SX + SA;
-  int lds_off[NS > 0 ? NS : 1], meta[NS > 0 ? NS : 1];   // meta = byte offset in the row | tile row << 16 | on << 24 | aligned << 28
+  int meta[NS > 0 ? NS : 1];   // byte offset in the row | tile row << 16 | on << 24 | aligned << 28 (the LDS position is re-derived
+                               // from it at every stash: one more loop-invariant register per slot was what spilled at K = 120, N = 360)
   u32x4_a4 rd[NS > 0 ? NS : 1];
+  u32x4_a4 rd2[SA > 0 ? SA : 1];   // the second addend's chunks (dX_add2), summed with dX_add at stash time
   float2 rst[SX > 0 ? SX : 1];
   static __device__ __forceinline__ int kind(int u) { return u < SY ? 0 : u < SY + SX ? 1 : 2; }
   __device__ __forceinline__ void setup(int tid_r, int ntr, bool has_acc) {
@@ -91,7 +93,6 @@ struct LB3Loader {
       int o = chk * 16;
       if (o + 16 > rowbytes) o = rowbytes - 16;
       meta[u] = o | (row << 16) | ((on ? 1 : 0) << 24) | (((o & 15) == 0 ? 1 : 0) << 28);
-      lds_off[u] = (kd == 0 ? CF::OFF_DY + row * CF::LDY : (kd == 2 ? CF::OFF_AC : 0) + row * CF::LDX) + o;
     }
   }
   __device__ __forceinline__ void fetch(const LB3Args& p, int64_t tile) {   // unconditional loads from clamped rows
@@ -104,6 +105,9 @@ struct LB3Loader {
       const char* base = reinterpret_cast<const char*>(kd == 0 ? p.dY : kd == 1 ? p.X : (p.Acc ? p.Acc : p.X));
       const uint32_t ldb = (uint32_t)((kd == 0 ? p.lddy : kd == 1 ? p.ldx : p.ldacc) * 2);
       rd[u] = *reinterpret_cast<const u32x4_a4*>(base + (size_t)(row * ldb + (uint32_t)(meta[u] & 0xffff)));
+      if (kd == 2 && p.Acc2)
+        rd2[u - SY - SX] = *reinterpret_cast<const u32x4_a4*>(reinterpret_cast<const char*>(p.Acc2) +
+                                                              (size_t)(row * (uint32_t)(p.ldacc2 * 2) + (uint32_t)(meta[u] & 0xffff)));
       if (LN && kd == 1) rst[u - SY] = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)row);
     }
   }
@@ -117,6 +121,18 @@ struct LB3Loader {
       const bool valid = (uint32_t)(tile * 32) + (uint32_t)mrow < Mu;
       Pack16 v;
       v.w[0] = valid ? rd[u].x : 0u; v.w[1] = valid ? rd[u].y : 0u; v.w[2] = valid ? rd[u].z : 0u; v.w[3] = valid ? rd[u].w : 0u;
+      if (kd == 2 && p.Acc2) {   // dX_add + dX_add2 (fp32 sum, one bf16 rounding); dX_add may be absent
+        const u32x4_a4 a = rd[u], b2 = rd2[u - SY - SX];
+        const bool h1 = p.Acc != nullptr;
+        float f[8];
+        f[0] = bf16lo(b2.x) + (h1 ? bf16lo(a.x) : 0.f); f[1] = bf16hi(b2.x) + (h1 ? bf16hi(a.x) : 0.f);
+        f[2] = bf16lo(b2.y) + (h1 ? bf16lo(a.y) : 0.f); f[3] = bf16hi(b2.y) + (h1 ? bf16hi(a.y) : 0.f);
+        f[4] = bf16lo(b2.z) + (h1 ? bf16lo(a.z) : 0.f); f[5] = bf16hi(b2.z) + (h1 ? bf16hi(a.z) : 0.f);
+        f[6] = bf16lo(b2.w) + (h1 ? bf16lo(a.w) : 0.f); f[7] = bf16hi(b2.w) + (h1 ? bf16hi(a.w) : 0.f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = valid ? f[e] : 0.f;
+        v = MM::pack(f);
+      }
       if (LN && kd == 1) {
         const float2 st2 = rst[u - SY];
         float f[8];
@@ -127,7 +143,10 @@ struct LB3Loader {
         v = MM::pack(f);
         if ((meta[u] & 0xffff) == 0) reinterpret_cast<float*>(buf + CF::OFF_SM)[mrow] = st2.y;
       }
-      char* dst = buf + lds_off[u];
+      int mt = meta[u];
+      asm volatile("" : "+v"(mt));   // (not hoisted out of the tile loop)
+      const int lrow = (mt >> 16) & 31, lo = mt & 0xffff;
+      char* dst = buf + (kd == 0 ? CF::OFF_DY + lrow * CF::LDY : (kd == 2 ? CF::OFF_AC : 0) + lrow * CF::LDX) + lo;
       if ((meta[u] >> 28) & 1) *reinterpret_cast<Pack16*>(dst) = v;
       else {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst);
@@ -144,7 +163,7 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
   constexpr int NCT = CF::NCT, NW = CF::NW, KN = CF::KN, TN = CF::TN, TC = CF::TC, NGC = CF::NGC, NWG = CF::NWG, NT = CF::NT;
   constexpr int LDX = CF::LDX, LDY = CF::LDY;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
-  const bool has_acc = p.Acc != nullptr;
+  const bool has_acc = p.Acc != nullptr || p.Acc2 != nullptr;
 
   // ---- prologue: zero both tile buffers (pads, absent dX_add), ones column of x-hat ----
   lds_zero16(smem, CF::SMEM, tid, NT);
@@ -249,21 +268,6 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
   u32x2_t xs[4], as[4];
   float rstd = 0.f;
   int64_t prow = -1;
-  // second addend (the strided gradient slice of a dense join): the two 16-B chunks this lane will store are requested
-  // when the tile's rows are known and added in finish(), one barrier later (LN) — no LDS, no loader slots
-  const bool has_acc2 = p.Acc2 != nullptr;
-  u32x4_a4 a2[2];
-  a2[0] = u32x4_a4{0u, 0u, 0u, 0u}; a2[1] = a2[0];
-  auto fetch2 = [&]() {
-    if (!has_acc2) return;
-    const int64_t row = prow < p.M ? prow : p.M - 1;
-#pragma unroll
-    for (int gp2 = 0; gp2 < 2; ++gp2) {
-      const int cb = 32 * dct + 8 * (2 * gp2 + hh);
-      const int cc = cb + 8 <= K ? cb : K - 8;   // (a chunk past the row's end is re-pointed inside it and masked in finish())
-      a2[gp2] = *reinterpret_cast<const u32x4_a4*>(p.Acc2 + row * p.ldacc2 + cc);
-    }
-  };
   auto finish = [&](int pb) {
     float s1 = 0.f, s2 = 0.f;
     if (LN) {
@@ -294,18 +298,6 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
           c8[4 + e] = __uint_as_float(sw[1]);
         }
         const int cb = 32 * dct + 8 * (2 * gp2 + hh);
-        if (has_acc2) {   // chunk loaded at min(cb, K - 8): element e of the store is element e + (cb - that) of the load
-          const int sh = cb + 8 <= K ? 0 : cb - (K - 8);
-          const float f2[8] = {bf16lo(a2[gp2].x), bf16hi(a2[gp2].x), bf16lo(a2[gp2].y), bf16hi(a2[gp2].y),
-                               bf16lo(a2[gp2].z), bf16hi(a2[gp2].z), bf16lo(a2[gp2].w), bf16hi(a2[gp2].w)};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v = (e + sh == k) ? f2[k] : v;
-            c8[e] += v;
-          }
-        }
         if (cb + 8 <= K) {
           u32x4_a4 u;
           u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
@@ -352,7 +344,6 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
       as[g4] = *reinterpret_cast<const LDS_AS u32x2_t*>(xrow + CF::OFF_AC + 16 * g4);
     }
     prow = tile * 32 + r;
-    fetch2();
     if (LN) {
       rstd = reinterpret_cast<const float*>(buf + CF::OFF_SM)[r];
       float s1 = 0.f, s2 = 0.f;
