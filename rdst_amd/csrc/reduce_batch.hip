@@ -5,7 +5,7 @@
 namespace rbatch {
 namespace {
 
-constexpr int MAXJ = 8;
+constexpr int MAXJ = 16;   // jobs per launch: a DenseSTLayer's backward (2 Swin blocks + its tail Linear) queues 11 sums and 5 finishes
 struct SumBatch { SumJob j[MAXJ]; int first[MAXJ + 1]; int n; };   // first[k] = first block of job k
 struct FinBatch { FinJob j[MAXJ]; int first[MAXJ + 1]; int n; };
 

@@ -406,7 +406,7 @@ class _LnLinear(torch.autograd.Function):
         db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(N, dtype=torch.float32, device=dev)) \
             if (has_bias and need[4]) else None
         _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy_r, lddy, dx, K, None, 0, dw, db, dlw, dlb, M, K, N,
-                         out_scale, _dtype_code(x), dev)
+                         out_scale, _dtype_code(x), dev, keep=_ReduceBatch.keep if _ReduceBatch.depth > 0 else None)
         dres = dy if (has_res and need[5]) else None
         return dx, dlw, dlb, dw, db, dres, None, None, None
 
@@ -438,6 +438,40 @@ class _IntoDense(torch.autograd.Function):
         return g, None
 
 
+class _ReduceBatch:
+    """Nesting-aware rdst_reduce_batch_begin / _end.  A Swin block's backward opens a batch for its own four ops; a
+    DenseSTLayer (dense join with a GradSink) opens an OUTER one in the join's backward — the first node of the layer's
+    backward — which the layer's first Swin block closes at the end of its own — the last node — so the slab sums and
+    LayerNorm finishes of the whole layer (two blocks + the tail Linear) run as 2 launches instead of 6.  `keep` holds
+    the ops' workspaces (the slabs) until the batch has run."""
+    depth = 0
+    keep: list = []
+
+    @staticmethod
+    def begin(lib):
+        if _ReduceBatch.depth == 0:
+            _lib.check(lib.rdst_reduce_batch_begin(), "rdst_reduce_batch_begin")
+        _ReduceBatch.depth += 1
+
+    @staticmethod
+    def end(lib, keep=None):
+        if keep:
+            _ReduceBatch.keep.extend(keep)
+        _ReduceBatch.depth -= 1
+        if _ReduceBatch.depth == 0:
+            try:
+                _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
+            finally:
+                _ReduceBatch.keep = []
+
+    @staticmethod
+    def abandon(lib):
+        """Close whatever a failed / partial backward left open (its queued reductions are run, not dropped)."""
+        if _ReduceBatch.depth > 0:
+            _ReduceBatch.depth = 1
+            _ReduceBatch.end(lib)
+
+
 class GradSink:
     """Carries the prefix slice of a dense join's gradient to the Swin block that consumed the prefix: `prefix` feeds
     the DenseSTLayer's body AND the join, so autograd would add the body's dX and this strided slice in a separate
@@ -446,10 +480,15 @@ class GradSink:
 
     def __init__(self):
         self.extra = None
+        self.batch_open = False   # the join opened the layer's reduction batch (_ReduceBatch); the taker closes it
 
     def take(self):
         e, self.extra = self.extra, None
         return e
+
+    def take_batch(self):
+        b, self.batch_open = self.batch_open, False
+        return b
 
 
 class _DenseJoin(torch.autograd.Function):
@@ -465,6 +504,11 @@ class _DenseJoin(torch.autograd.Function):
     def backward(ctx, g):
         if ctx.sink is not None and ctx.needs_input_grad[0]:
             ctx.sink.extra = g[..., :ctx.c]
+            if g.is_cuda and not TWO_STREAM_BACKWARD:
+                lib = _lib.load()
+                _ReduceBatch.abandon(lib)   # (only after a backward that did not run to its end)
+                _ReduceBatch.begin(lib)
+                ctx.sink.batch_open = True
             return None, g[..., ctx.c:], None, None
         return g[..., :ctx.c], g[..., ctx.c:], None, None
 
@@ -586,14 +630,17 @@ class _SwinBlock(torch.autograd.Function):
         # the slab reductions of the four ops below are recorded and run as two launches at the end (rdst_reduce_batch_*);
         # their workspaces are locals of this function, alive until then
         batched = not TWO_STREAM_BACKWARD
+        outer = batched and ctx.sink is not None and ctx.sink.take_batch()   # this block ends its DenseSTLayer's batch too
         if batched:
-            _lib.check(lib.rdst_reduce_batch_begin(), "rdst_reduce_batch_begin")
+            _ReduceBatch.begin(lib)
         try:
             return _SwinBlock._backward_body(ctx, lib, dy_r, lddy, need, keep, dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w,
                                              dn2b, dfc1w, dfc1b, dfc2w, dfc2b)
         finally:
             if batched:
-                _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
+                _ReduceBatch.end(lib, keep)
+            if outer:
+                _ReduceBatch.end(lib)
 
     @staticmethod
     def _backward_body(ctx, lib, dy_r, lddy, need, keep, dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b,
