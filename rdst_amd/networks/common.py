@@ -22,13 +22,13 @@ class Conv2d(nn.Conv2d):
     network uses: token-major (B,H,W,Cin) in/out with the activation/scale/residual/pixel-shuffle
     epilogues of K4/K5."""
 
-    def forward_rows(self, x, *, in_act=ops.ACT_NONE, residual=None, out_scale=1.0, shuffle=1):
+    def forward_rows(self, x, *, in_act=ops.ACT_NONE, residual=None, out_scale=1.0, shuffle=1, out_slot=None):
         k = self.kernel_size[0]
         if (self.kernel_size[0] != self.kernel_size[1] or k not in (1, 3) or self.stride != (1, 1)
                 or self.padding != (k // 2, k // 2) or self.dilation != (1, 1) or self.groups != 1):
             raise NotImplementedError("rdst_amd Conv2d: only k in {1,3}, stride 1, padding k//2, groups 1")
         return ops.conv_rows(x, self.weight, self.bias, in_act=in_act, residual=residual, out_scale=out_scale,
-                             shuffle=shuffle)
+                             shuffle=shuffle, out_slot=out_slot)
 
     def forward(self, x):
         return ops.rows_to_nchw(self.forward_rows(ops.nchw_to_rows(x, torch.float32)))

@@ -130,13 +130,14 @@ def _res_connection(resi_connection, cin, cout):
     return None
 
 
-def _apply_res_connection(conv, x, residual=None, out_scale=1.0):
-    """conv(x) * out_scale + residual on rows; the LeakyReLUs of '3conv' ride on the next conv's load."""
+def _apply_res_connection(conv, x, residual=None, out_scale=1.0, out_slot=None):
+    """conv(x) * out_scale + residual on rows; the LeakyReLUs of '3conv' ride on the next conv's load.
+    out_slot = (DenseBuffer, channel): the last conv writes there (the next RDSTB's dense buffer)."""
     if isinstance(conv, Conv2d):
-        return conv.forward_rows(x, residual=residual, out_scale=out_scale)
+        return conv.forward_rows(x, residual=residual, out_scale=out_scale, out_slot=out_slot)
     y = conv[0].forward_rows(x)
     y = conv[2].forward_rows(y, in_act=ops.ACT_LEAKY02)
-    return conv[4].forward_rows(y, in_act=ops.ACT_LEAKY02, residual=residual, out_scale=out_scale)
+    return conv[4].forward_rows(y, in_act=ops.ACT_LEAKY02, residual=residual, out_scale=out_scale, out_slot=out_slot)
 
 
 class RDSTB(nn.Module):
@@ -171,13 +172,23 @@ class RDSTB(nn.Module):
         self.patch_unembed = PatchUnEmbed(img_size=img_size, patch_size=patch_size, in_chans=0, embed_dim=idim,
                                           norm_layer=None)
 
-    def forward(self, x, x_size):
+    def dense_width(self):
+        return self.input_dim + sum(m.growth_rate_out for m in self.body)
+
+    def make_buffer(self, B, L, dtype, device):
+        """The dense buffer forward() works in; a caller that creates it ahead can have the PRODUCER of x write x into
+        its first channels (out_slot = (buf, 0)), which spares the one copy an RDSTB makes."""
+        return ops.DenseBuffer((B, L), self.dense_width(), dtype, device)
+
+    def forward(self, x, x_size, buf=None, out_slot=None):
+        """buf: this block's dense buffer (make_buffer), x possibly already in its first channels; out_slot: where the
+        fusion conv writes the block's output (the next block's buffer)."""
         B, L, C = x.shape
         H, W = x_size
         if x.is_cuda and len(self.body) > 0:
             # dense buffer: every DenseSTLayer appends its channels in place (no torch.cat of the growing prefix)
-            width = C + sum(m.growth_rate_out for m in self.body)
-            buf = ops.DenseBuffer((B, L), width, x.dtype, x.device)
+            if buf is None:
+                buf = self.make_buffer(B, L, x.dtype, x.device)
             y = ops.into_dense(x, buf)
             for m in self.body:
                 y = m.forward_dense(y, x_size, buf)
@@ -186,7 +197,7 @@ class RDSTB(nn.Module):
             for m in self.body:
                 y = m(y, x_size)
         out = _apply_res_connection(self.conv, y.view(B, H, W, y.shape[-1]), residual=x.view(B, H, W, C),
-                                    out_scale=self.residual_scale)
+                                    out_scale=self.residual_scale, out_slot=out_slot)
         return out.view(B, L, C)
 
 
@@ -339,12 +350,22 @@ class RDSTSR(nn.Module):
         B, H, W, E = feat.shape
         x_size = (H, W)
         t = feat.view(B, H * W, E)
+        # every RDSTB's dense buffer is created ahead, so that the producer of a block's input (the patch norm, the
+        # previous block's fusion conv) writes it straight into the buffer's first channels: no copy per block
+        blocks = list(self.body)
+        chain = t.is_cuda and len(blocks) > 0 and all(isinstance(b, RDSTB) and len(b.body) > 0 and hasattr(b, "conv")
+                                                      and b.input_dim == E for b in blocks)
+        bufs = [b.make_buffer(B, H * W, t.dtype, t.device) for b in blocks] if chain else [None] * len(blocks)
         if self.patch_embed.norm is not None:
-            t = _norm_only(t, self.patch_embed.norm)
+            first = (bufs[0], 0) if (chain and not self.ape and isinstance(self.patch_embed.norm, nn.LayerNorm)) else None
+            t = _norm_only(t, self.patch_embed.norm, out_slot=first)
         if self.ape:
             t = t + self.absolute_pos_embed.to(t.dtype)
-        for blk in self.body:
-            t = blk(t, x_size)
+        for i, blk in enumerate(blocks):
+            if chain:
+                t = blk(t, x_size, buf=bufs[i], out_slot=(bufs[i + 1], 0) if i + 1 < len(blocks) else None)
+            else:
+                t = blk(t, x_size)
         return t
 
     def forward_features(self, x):

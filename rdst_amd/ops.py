@@ -433,6 +433,7 @@ class _IntoDense(torch.autograd.Function):
         v.copy_(x)
         return v
 
+
     @staticmethod
     def backward(ctx, g):
         return g, None
@@ -514,6 +515,8 @@ class _DenseJoin(torch.autograd.Function):
 
 
 def into_dense(x: torch.Tensor, buf: DenseBuffer) -> torch.Tensor:
+    if x.data_ptr() == buf.t.data_ptr() and x.stride()[:-1] == buf.t.stride()[:-1] and x.shape[:-1] == buf.t.shape[:-1]:
+        return x   # its producer already wrote it into the buffer's first channels (out_slot)
     return _IntoDense.apply(x, buf)
 
 
@@ -736,7 +739,7 @@ def swin_block(x, n1w, n1b, qkvw, qkvb, table, projw, projb, n2w, n2b, fc1w, fc1
 # ------------------------------------------------------------------------------------------------
 class _ConvRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, in_act, out_scale, shuffle):
+    def forward(ctx, x, weight, bias, residual, in_act, out_scale, shuffle, out_slot=None):
         _need_gpu(x, weight, bias, residual)
         lib = _lib.load()
         if x.dim() != 4:
@@ -749,7 +752,11 @@ class _ConvRows(torch.autograd.Function):
         x_r, ldx = _rows(x)
         w, b = _param(weight), _param(bias)
         cy = Cout // (r * r)
-        y = torch.empty((B, H * r, W * r, cy), dtype=x.dtype, device=x.device)
+        if out_slot is None:
+            y, ldy = torch.empty((B, H * r, W * r, cy), dtype=x.dtype, device=x.device), cy
+        else:   # (DenseBuffer, first channel): the kernel writes its channels straight into the next RDSTB's dense buffer
+            y = out_slot[0].slot(out_slot[1], cy).view(B, H * r, W * r, cy)
+            ldy = out_slot[0].width
         r_r, ldr = (None, 0)
         if residual is not None:
             if residual.dtype != x.dtype or tuple(residual.shape) != tuple(y.shape):
@@ -762,7 +769,7 @@ class _ConvRows(torch.autograd.Function):
         else:
             _wsp, wptr, nws = None, None, 0
         _lib.check(lib.rdst_conv_fwd(x_r.data_ptr(), ldx, int(in_act), w.data_ptr(), _ptr(b), _ptr(r_r), ldr,
-                                     y.data_ptr(), cy, wptr, nws, B, H, W, Cin, Cout, k, float(out_scale), r,
+                                     y.data_ptr(), ldy, wptr, nws, B, H, W, Cin, Cout, k, float(out_scale), r,
                                      code, _stream()), "rdst_conv_fwd")
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.save_for_backward(x_r, w)
@@ -802,15 +809,15 @@ class _ConvRows(torch.autograd.Function):
         else:
             call(dx, dw, db, _workspace(nbytes, dev))
         dres = dy if (has_res and need[3]) else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 def conv_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], *, in_act: int = ACT_NONE,
-              residual: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle: int = 1) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle: int = 1, out_slot=None) -> torch.Tensor:
     """k x k conv (k = 1, 3; zero pad k//2) on token-major x (B,H,W,Cin) with nn.Conv2d weights
     (Cout,Cin,k,k): y = (conv(in_act(x)) + bias) * out_scale + residual, PixelShuffle(shuffle) folded
     into the store -> (B, H*r, W*r, Cout/r^2).  See include/rdst_hip.h, K4/K5/K6."""
-    return _ConvRows.apply(x, weight, bias, residual, in_act, out_scale, shuffle)
+    return _ConvRows.apply(x, weight, bias, residual, in_act, out_scale, shuffle, out_slot)
 
 
 # ------------------------------------------------------------------------------------------------
