@@ -263,10 +263,15 @@ size_t rdst_u_scratch_bytes(void);
  *   transposed = 1: the data gradient of such a convolution (input = dY in the FORWARD's output geometry (Hin, Win),
  *            output = dX in the forward's input geometry (Hout, Wout)): in[b, (oy + k/2 - ky) / stride, ...] where divisible,
  *            with Wp = the forward's weights as [k*k][Cin_fwd padded][Cout_fwd].
- * (C1 + C2) * elementsize must be a multiple of 32 bytes and C1 * elementsize a multiple of the reduction chunk. */
+ * (C1 + C2) * elementsize must be a multiple of 32 bytes and C1 * elementsize a multiple of the reduction chunk.
+ *   bn1    = NULL, or the (scale[C1], shift[C1]) head of a rdst_u_bn_stats `coef`: source 1 is then read through
+ *            relu(scale x + shift) — the train-mode BatchNorm + ReLU in front of this convolution (smp's Conv2dReLU,
+ *            resnet's conv-bn-relu) applied while the input is staged, so that the activation never materialises; zero
+ *            padding applies to the ACTIVATION.  fp32 / fp32x3, 3x3, stride 1, forward form only (RDST_ENOTSUP otherwise). */
 int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const void* X2, int64_t ld2, int C2, const void* Wp,
                 const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win, int Hout,
-                int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream);
+                int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream,
+                const float* bn1);
 
 /* encoder.conv1: 7x7 stride 2 pad 3, Cin <= 4 -> 64, from the fp32 NCHW image; and its data gradient back to the image
  * (times the device scalar `upstream`, NULL = 1).  W = fp32 (64, Cin, 7, 7) as nn.Conv2d stores it. */
@@ -285,7 +290,8 @@ int rdst_u_bn_stats(const void* X, int64_t ld, int64_t P, int C, const float* ga
  * downsample branch and the activation in one pass. */
 int rdst_u_bn_apply(const void* X, int64_t ldx, const float* coef, const void* X2, int64_t ldx2, const float* coef2,
                     const void* R, int64_t ldr, int relu, void* Y, int64_t ldy, int64_t P, int C, int dtype, void* stream);
-/* Backward of Y = act(BatchNorm_train(Xraw) + ...) to Xraw: g = dY * [Ymask > 0] (Ymask NULL: g = dY),
+/* Backward of Y = act(BatchNorm_train(Xraw) + ...) to Xraw: g = dY * [Ymask > 0] (Ymask NULL: g = dY; Ymask == Xraw, the
+ * same pointer: Y = relu(BatchNorm(Xraw)) was never materialised and the mask is recomputed from Xraw and coef),
  * dX = a (g - mean(g) - xhat mean(g xhat)); Gout (may be NULL) receives g (+ Gadd), the gradient of the "+ ..." operand. */
 int rdst_u_bn_bwd(const void* dY, int64_t lddy, const void* Ymask, int64_t ldm, const void* Xraw, int64_t ldx,
                   const float* coef, void* dX, int64_t lddx, void* Gout, int64_t ldg, const void* Gadd, int64_t ldga,

@@ -52,12 +52,14 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
   const int lpp = C / VN, ppb = 256 / lpp;
   const int cg = threadIdx.x % lpp, q = threadIdx.x / lpp;
   const int64_t per = (P + gridDim.x - 1) / gridDim.x, p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
-  float s0[VN], s1[VN], mean[VN], rstd[VN];
+  float s0[VN], s1[VN], mean[VN], rstd[VN], sca[VN], shf[VN];
 #pragma unroll
   for (int e = 0; e < VN; ++e) {
     s0[e] = s1[e] = 0.f;
     mean[e] = MODE ? coef[2 * C + cg * VN + e] : 0.f;
     rstd[e] = MODE ? coef[3 * C + cg * VN + e] : 0.f;
+    sca[e] = MODE ? coef[cg * VN + e] : 0.f;
+    shf[e] = MODE ? coef[C + cg * VN + e] : 0.f;
   }
   if (q < ppb)
     for (int64_t p = p0 + q; p < p1; p += ppb) {
@@ -69,7 +71,10 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
       } else {
         float g[VN], m[VN];
         ldv<T>(dY + p * lddy + cg * VN, g);
-        if (Mk) {
+        if (Mk == X) {   // the mask is relu'(BatchNorm(x)) itself: recomputed with bn_apply_kernel's fma, nothing read
+#pragma unroll
+          for (int e = 0; e < VN; ++e) g[e] = fmaf(sca[e], x[e], shf[e]) > 0.f ? g[e] : 0.f;
+        } else if (Mk) {
           ldv<T>(Mk + p * ldm + cg * VN, m);
 #pragma unroll
           for (int e = 0; e < VN; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
@@ -190,18 +195,25 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dY, int64_t lddy, const T* __restrict__ Mk, int64_t ldm,
                                                            const T* __restrict__ X, int64_t ldx, const float* __restrict__ c3,
                                                            T* __restrict__ dX, int64_t lddx, T* __restrict__ G, int64_t ldg,
-                                                           const T* __restrict__ Ga, int64_t ldga, int64_t P, int C) {
+                                                           const T* __restrict__ Ga, int64_t ldga, int64_t P, int C,
+                                                           const float* __restrict__ coef) {
   constexpr int VN = V<T>::N;
   const int lpp = C / VN, ppb = 256 / lpp;
   const int cg = threadIdx.x % lpp;
-  float c0[VN], k1[VN], k2[VN];
+  float c0[VN], k1[VN], k2[VN], sca[VN], shf[VN];
 #pragma unroll
-  for (int e = 0; e < VN; ++e) { c0[e] = c3[cg * VN + e]; k1[e] = c3[C + cg * VN + e]; k2[e] = c3[2 * C + cg * VN + e]; }
+  for (int e = 0; e < VN; ++e) {
+    c0[e] = c3[cg * VN + e]; k1[e] = c3[C + cg * VN + e]; k2[e] = c3[2 * C + cg * VN + e];
+    sca[e] = coef[cg * VN + e]; shf[e] = coef[C + cg * VN + e];
+  }
   for (int64_t p = (int64_t)blockIdx.x * ppb + threadIdx.x / lpp; p < P; p += (int64_t)gridDim.x * ppb) {
     float g[VN], x[VN], m[VN];
     ldv<T>(dY + p * lddy + cg * VN, g);
     ldv<T>(X + p * ldx + cg * VN, x);
-    if (Mk) {
+    if (Mk == X) {   // mask = relu'(BatchNorm(x)), recomputed (see colsum_kernel)
+#pragma unroll
+      for (int e = 0; e < VN; ++e) g[e] = fmaf(sca[e], x[e], shf[e]) > 0.f ? g[e] : 0.f;
+    } else if (Mk) {
       ldv<T>(Mk + p * ldm + cg * VN, m);
 #pragma unroll
       for (int e = 0; e < VN; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
@@ -561,13 +573,13 @@ extern "C" int rdst_u_bn_bwd(const void* dY, int64_t lddy, const void* Ymask, in
                        (const float*)Ymask, ldm, coef, P, C, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, P, C, coef, c3);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dY, lddy, (const float*)Ymask, ldm,
-                       (const float*)Xraw, ldx, c3, (float*)dX, lddx, (float*)Gout, ldg, (const float*)Gadd, ldga, P, C);
+                       (const float*)Xraw, ldx, c3, (float*)dX, lddx, (float*)Gout, ldg, (const float*)Gadd, ldga, P, C, coef);
   } else {
     hipLaunchKernelGGL((colsum_kernel<bf16, 1>), dim3(nb), dim3(256), 0, st, (const bf16*)Xraw, ldx, (const bf16*)dY, lddy,
                        (const bf16*)Ymask, ldm, coef, P, C, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, P, C, coef, c3);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16>), dim3(g), dim3(256), 0, st, (const bf16*)dY, lddy, (const bf16*)Ymask, ldm,
-                       (const bf16*)Xraw, ldx, c3, (bf16*)dX, lddx, (bf16*)Gout, ldg, (const bf16*)Gadd, ldga, P, C);
+                       (const bf16*)Xraw, ldx, c3, (bf16*)dX, lddx, (bf16*)Gout, ldg, (const bf16*)Gadd, ldga, P, C, coef);
   }
   return rdst_launch_status("rdst_u_bn_bwd");
 }

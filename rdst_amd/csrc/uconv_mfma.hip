@@ -36,6 +36,8 @@ struct UConvP {
   int B, Hin, Win, Hout, Wout, Cin, Cout, Npad, k, stride, transposed;
   int64_t P;   // output pixels
   int dbg;     // ablation switches (RDST_DEBUG builds only)
+  const float* bn1;   // [scale C1][shift C1] (fp32) or NULL: the first source is read through relu(scale x + shift) — the
+                      // train-mode BatchNorm + ReLU in front of this convolution, applied while the halo is staged (halo kernel)
 };
 
 template <typename T, int BM, int BN, int KB, int WM, int WN, bool SPLIT>
@@ -343,6 +345,10 @@ __global__ void __launch_bounds__(256) uconv_halo_kernel(const UConvP p) {
 
   const int CH = p.Cin / EPC;
   u32x4_a4 ra[APN], rb[2][BP];   // weight slabs: two register sets, fetched TWO taps ahead of their use
+  // BatchNorm + ReLU of the first source on the way in (p.bn1): every piece of a thread is the same channel quad of the
+  // chunk (256 threads are a multiple of the pieces per row), so one (scale, shift) quad per chunk serves all its pieces
+  u32x4_a4 bsc = {0u, 0u, 0u, 0u}, bsh = {0u, 0u, 0u, 0u};
+  bool bnx = false;   // the chunk in `ra` goes through bsc / bsh (wave-uniform)
   auto fetchA = [&](int ch) {
     const int c0 = ch * EPC;
     const bool first = c0 < p.C1;
@@ -351,14 +357,30 @@ __global__ void __launch_bounds__(256) uconv_halo_kernel(const UConvP p) {
 #pragma unroll
     for (int a = 0; a < APN; ++a)
       ra[a] = *reinterpret_cast<const u32x4_a4*>(base + (uint64_t)(uint32_t)(first ? hp1[a] : hp2[a]) * ldb + (hoff[a] >> 24) * 16);
+    if constexpr (ES == 4) {
+      bnx = first && p.bn1 != nullptr;
+      if (bnx) {
+        const int c = c0 + (int)(hoff[0] >> 24) * 4;
+        bsc = *reinterpret_cast<const u32x4_a4*>(p.bn1 + c);
+        bsh = *reinterpret_cast<const u32x4_a4*>(p.bn1 + p.C1 + c);
+      }
+    }
   };
   auto stashA = [&]() {
 #pragma unroll
     for (int a = 0; a < APN; ++a) {
       if (!((hin >> a) & 1u)) continue;
       const bool ok = (hok >> a) & 1u;
-      u32x4_a4 v;
-      v.x = ok ? ra[a].x : 0u; v.y = ok ? ra[a].y : 0u; v.z = ok ? ra[a].z : 0u; v.w = ok ? ra[a].w : 0u;
+      u32x4_a4 v = ra[a];
+      if constexpr (ES == 4) {
+        if (bnx) {   // relu(scale x + shift), the very fma of bn_apply_kernel: the same bits as the materialised activation
+          { const float t = fmaf(__uint_as_float(bsc.x), __uint_as_float(v.x), __uint_as_float(bsh.x)); v.x = __float_as_uint(t > 0.f ? t : 0.f); }
+          { const float t = fmaf(__uint_as_float(bsc.y), __uint_as_float(v.y), __uint_as_float(bsh.y)); v.y = __float_as_uint(t > 0.f ? t : 0.f); }
+          { const float t = fmaf(__uint_as_float(bsc.z), __uint_as_float(v.z), __uint_as_float(bsh.z)); v.z = __float_as_uint(t > 0.f ? t : 0.f); }
+          { const float t = fmaf(__uint_as_float(bsc.w), __uint_as_float(v.w), __uint_as_float(bsh.w)); v.w = __float_as_uint(t > 0.f ? t : 0.f); }
+        }
+      }
+      v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;   // (zero padding AFTER the activation)
       const uint32_t pc = hoff[a] >> 24;
       char* rowp = Ah + (hoff[a] & 0xffffffu);
       if (SPLIT) {
@@ -604,6 +626,7 @@ int pick_kb(const UConvP& p, hipStream_t st) {
     if (fits(128)) return pick_halo<T, 128, SPLIT>(p, st);
     if (fits(64)) return pick_halo<T, 64, SPLIT>(p, st);
   }
+  if (p.bn1) return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: bn1 is taken by the halo kernel only");
   if (fits(128)) return pick_bn<T, 128, SPLIT>(p, st);
   if (fits(64)) return pick_bn<T, 64, SPLIT>(p, st);
   if constexpr (!SPLIT)
@@ -616,8 +639,11 @@ int pick_kb(const UConvP& p, hipStream_t st) {
 
 extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const void* X2, int64_t ld2, int C2, const void* Wp,
                            const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win,
-                           int Hout, int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream) {
+                           int Hout, int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream,
+                           const float* bn1) {
   if (!X1 || !Wp || !Y) return rdst_fail(RDST_EINVAL, "rdst_u_conv: null pointer");
+  if (bn1 && (dtype == RDST_BF16 || ksize != 3 || stride != 1 || transposed || (C1 * 4) % 64 || ((C1 + C2) * 4) % 64 || ((uintptr_t)bn1 & 3)))
+    return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: bn1 (BatchNorm + ReLU on the way in) needs the fp32 / fp32x3 3x3 stride-1 forward form");
   if (dtype != RDST_F32 && dtype != RDST_BF16 && dtype != RDST_F32X3) return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad dtype %d", dtype);
   if (B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || C1 <= 0 || C2 < 0 || Cout <= 0)
     return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad shape");
@@ -638,6 +664,7 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
   p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout; p.Cin = C1 + C2; p.Cout = Cout; p.Npad = Npad;
   p.k = ksize; p.stride = stride; p.transposed = transposed ? 1 : 0;
   p.P = (int64_t)B * Hout * Wout;
+  p.bn1 = bn1;
   {
     const char* e = rdst_dbg_getenv("RDST_UCONV_DBG");
     p.dbg = e ? atoi(e) : 0;

@@ -123,9 +123,16 @@ class _Runner:
         self.scratch = mod._scratch()
         self.packs = mod._packs()
         self.st = torch.cuda.current_stream().cuda_stream
+        # fp32 / fp32x3: relu(BatchNorm(.)) in front of a 3x3 stride-1 convolution is applied while that convolution stages its
+        # input (rdst_u_conv's bn1) and its backward recomputes the ReLU mask from the raw tensor (rdst_u_bn_bwd with
+        # mask = raw): the activation tensors a1 of every block and the outputs of decoder blocks 0..3 are never written
+        self.fuse = self.code in (_lib.F32, _lib.F32X3)
 
     # ---- thin wrappers -------------------------------------------------------------------------------------------------
-    def conv(self, x1, name, *, transposed=False, x2=None, up1=False, stride=1, out_hw=None, add=None, bias=None, cout=None):
+    def conv(self, x1, name, *, transposed=False, x2=None, up1=False, stride=1, out_hw=None, add=None, bias=None, cout=None,
+             bn1=None):
+        """bn1 = the BatchNorm coefficients of x1 when x1 is a RAW convolution output: the convolution then reads it through
+        relu(BatchNorm(x1)) (see `fuse`), which is never written."""
         wp, npad, k = self.packs[(name, transposed)]
         B, H1, W1, C1 = x1.shape
         Hin, Win = (2 * H1, 2 * W1) if up1 else (H1, W1)
@@ -135,7 +142,7 @@ class _Runner:
         y = torch.empty((B, out_hw[0], out_hw[1], cout), dtype=self.dt, device=self.dev)
         _lib.check(self.lib.rdst_u_conv(x1.data_ptr(), _ld(x1), C1, int(up1), _ptr(x2), _ld(x2), C2, wp.data_ptr(), _ptr(bias),
                                         _ptr(add), _ld(add), y.data_ptr(), cout, B, Hin, Win, out_hw[0], out_hw[1], cout, npad, k,
-                                        stride, int(transposed), self.code, self.st), "rdst_u_conv")
+                                        stride, int(transposed), self.code, self.st, _ptr(bn1)), "rdst_u_conv")
         return y
 
     def bn_stats(self, x, bn: nn.BatchNorm2d, update=True):
@@ -198,8 +205,12 @@ class _Runner:
                 pl = blk.conv1.out_channels
                 r1 = self.conv(x, name + ".conv1", stride=blk.stride, cout=pl)
                 c1 = self.bn_stats(r1, blk.bn1)
-                a1 = self.bn_apply(r1, c1)
-                r2 = self.conv(a1, name + ".conv2", cout=pl)
+                if self.fuse:
+                    a1 = None
+                    r2 = self.conv(r1, name + ".conv2", cout=pl, bn1=c1)
+                else:
+                    a1 = self.bn_apply(r1, c1)
+                    r2 = self.conv(a1, name + ".conv2", cout=pl)
                 c2 = self.bn_stats(r2, blk.bn2)
                 if blk.downsample is not None:
                     rd = self.conv(x, name + ".downsample.0", stride=blk.stride, cout=pl)
@@ -219,18 +230,28 @@ class _Runner:
         skips = [feats[4], feats[3], feats[2], feats[1], None]
         if save is not None:
             save["dec"] = []
+        nblk = len(self.m.decoder.blocks)
+        xcoef = None   # x is a raw convolution output to be read through relu(BatchNorm(x)) with these coefficients
         for i, blk in enumerate(self.m.decoder.blocks):
             name = f"decoder.blocks.{i}"
             co = blk.conv1[0].out_channels
-            r1 = self.conv(x, name + ".conv1.0", x2=skips[i], up1=True, cout=co)
+            cx, cs = x.shape[-1], 0 if skips[i] is None else skips[i].shape[-1]
+            r1 = self.conv(x, name + ".conv1.0", x2=skips[i], up1=True, cout=co, bn1=xcoef)
             c1 = self.bn_stats(r1, blk.conv1[1])
-            a1 = self.bn_apply(r1, c1)
-            r2 = self.conv(a1, name + ".conv2.0", cout=co)
+            if self.fuse:
+                a1 = None
+                r2 = self.conv(r1, name + ".conv2.0", cout=co, bn1=c1)
+            else:
+                a1 = self.bn_apply(r1, c1)
+                r2 = self.conv(a1, name + ".conv2.0", cout=co)
             c2 = self.bn_stats(r2, blk.conv2[1])
-            out = self.bn_apply(r2, c2)
+            if self.fuse and i + 1 < nblk:   # the last block's output is a feature the losses / the head read: it is written
+                out, x, xcoef = None, r2, c2
+            else:
+                out = self.bn_apply(r2, c2)
+                x, xcoef = out, None
             if save is not None:
-                save["dec"].append((name, x.shape[-1], 0 if skips[i] is None else skips[i].shape[-1], r1, c1, a1, r2, c2, out))
-            x = out
+                save["dec"].append((name, cx, cs, r1, c1, a1, r2, c2, out))
         return x
 
     def head(self, dec):
@@ -246,9 +267,10 @@ class _Runner:
             dy = d_dec
             for i in range(len(save["dec"]) - 1, -1, -1):
                 name, cx, cs, r1, c1, a1, r2, c2, out = save["dec"][i]
-                dr2 = self.bn_bwd(dy, out, r2, c2)
-                da1 = self.conv(dr2, name + ".conv2.0", transposed=True, cout=a1.shape[-1])
-                dr1 = self.bn_bwd(da1, a1, r1, c1)
+                # (an activation that was never written: mask = the raw tensor itself, recomputed by the kernel)
+                dr2 = self.bn_bwd(dy, out if out is not None else r2, r2, c2)
+                da1 = self.conv(dr2, name + ".conv2.0", transposed=True, cout=r1.shape[-1])
+                dr1 = self.bn_bwd(da1, a1 if a1 is not None else r1, r1, c1)
                 dcat = self.conv(dr1, name + ".conv1.0", transposed=True, cout=cx + cs)
                 B, H, W, _ = dcat.shape
                 k = 5 - i                                    # the feature this block's x came from (block 0: features[5])
@@ -282,14 +304,14 @@ class _Runner:
                     if first and extra is not None:
                         raise RuntimeError("SegUNet_F: a layer >= 2 without a downsample branch")   # not a resnet34
                     dr2, g = self.bn_bwd(dy, out, r2, c2, want_g=True)
-                    da1 = self.conv(dr2, name + ".conv2", transposed=True, cout=a1.shape[-1])
-                    dr1 = self.bn_bwd(da1, a1, r1, c1)
+                    da1 = self.conv(dr2, name + ".conv2", transposed=True, cout=r1.shape[-1])
+                    dr1 = self.bn_bwd(da1, a1 if a1 is not None else r1, r1, c1)
                     dy = self.conv(dr1, name + ".conv1", transposed=True, cout=cin, add=g)
                 else:
                     dr2 = self.bn_bwd(dy, out, r2, c2)
                     drd = self.bn_bwd(dy, out, rd, cd)
-                    da1 = self.conv(dr2, name + ".conv2", transposed=True, cout=a1.shape[-1])
-                    dr1 = self.bn_bwd(da1, a1, r1, c1)
+                    da1 = self.conv(dr2, name + ".conv2", transposed=True, cout=r1.shape[-1])
+                    dr1 = self.bn_bwd(da1, a1 if a1 is not None else r1, r1, c1)
                     hw = (xshape[1], xshape[2])
                     tmp = self.conv(drd, name + ".downsample.0", transposed=True, stride=stride, out_hw=hw, cout=cin,
                                     add=extra if first else None)
