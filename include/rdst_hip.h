@@ -271,7 +271,11 @@ size_t rdst_u_scratch_bytes(void);
 int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const void* X2, int64_t ld2, int C2, const void* Wp,
                 const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win, int Hout,
                 int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream,
-                const float* bn1);
+                const float* bn1, float* stats, int* stats_blocks);
+/*   stats  = NULL, or room for [blocks][2][Cout] floats, blocks <= B * ceil(Hout / 8) * ceil(Wout / 8): every workgroup leaves the
+ *            sum and the sum of squares of its output pixels per channel (3x3 stride 1, no bias / addend), *stats_blocks (host)
+ *            receives the number of blocks written; rdst_u_bn_stats_from finishes them — the BatchNorm statistics of the
+ *            convolution's output without another pass over it. */
 
 /* encoder.conv1: 7x7 stride 2 pad 3, Cin <= 4 -> 64, from the fp32 NCHW image; and its data gradient back to the image
  * (times the device scalar `upstream`, NULL = 1).  W = fp32 (64, Cin, 7, 7) as nn.Conv2d stores it. */
@@ -286,6 +290,8 @@ int rdst_u_stem_dgrad(const void* dR, int64_t ld, const float* W, const float* u
 int rdst_u_bn_stats(const void* X, int64_t ld, int64_t P, int C, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, float* coef, void* scratch, int dtype,
                     void* stream);
+int rdst_u_bn_stats_from(const float* partials, int nblk, int64_t P, int C, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* coef, void* scratch, void* stream);
 /* Y = act(a X + b [+ a2 X2 + b2] [+ R]), act = ReLU when relu != 0: BatchNorm apply, the BasicBlock's identity /
  * downsample branch and the activation in one pass. */
 int rdst_u_bn_apply(const void* X, int64_t ldx, const float* coef, const void* X2, int64_t ldx2, const float* coef2,

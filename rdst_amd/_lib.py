@@ -54,7 +54,9 @@ SIGNATURES = {
     "rdst_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _l, _p]),
     # the seg-UNet of the perceptual loss (ABI v5)
     "rdst_u_scratch_bytes": (_z, []),
-    "rdst_u_conv": (_i, [_p, _l, _i, _i, _p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "rdst_u_conv": (_i, [_p, _l, _i, _i, _p, _l, _i, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p,
+                         C.POINTER(C.c_int)]),
+    "rdst_u_bn_stats_from": (_i, [_p, _i, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "rdst_u_stem_fwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_u_stem_dgrad": (_i, [_p, _l, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "rdst_u_bn_stats": (_i, [_p, _l, _l, _i, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p]),

@@ -138,6 +138,29 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(P > 1 ? var * (double)P / (double)(P - 1) : var);
 }
 
+// [nblk][W] partial rows -> [nslice][W]: slice s adds its rows in double, 256 / W row phases per workgroup combined in fixed
+// order.  Between a producer that leaves one partial row per workgroup (the convolution's epilogue: up to 16 thousand rows
+// of 2 C floats for the 256 x 256 decoder layers) and the one-wave-per-channel finish, which walks rows C floats apart.
+__global__ void __launch_bounds__(256) fold_partials_kernel(const float* __restrict__ in, int nblk, int W, float* __restrict__ out) {
+  __shared__ double red[256];
+  const int per = (nblk + gridDim.x - 1) / gridDim.x, b0 = blockIdx.x * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  const int nph = W < 256 ? 256 / W : 1;
+  for (int col0 = 0; col0 < W; col0 += 256) {
+    const int col = col0 + (int)(threadIdx.x % (W < 256 ? W : 256)), ph = threadIdx.x / (W < 256 ? W : 256);
+    double a = 0.0;
+    if (col < W && ph < nph)
+      for (int b = b0 + ph; b < b1; b += nph) a += (double)in[(int64_t)b * W + col];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (ph == 0 && col < W) {
+      double t = 0.0;
+      for (int k = 0; k < nph; ++k) t += red[k * (W < 256 ? W : 256) + (threadIdx.x % (W < 256 ? W : 256))];
+      out[(int64_t)blockIdx.x * W + col] = (float)t;
+    }
+    __syncthreads();
+  }
+}
+
 // (c0, k1, k2) with dX = c0 g + k1 + k2 x  ==  a (g - mean(g) - xhat mean(g xhat))
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t P, int C,
                                                               const float* __restrict__ coef, float* __restrict__ c3) {
@@ -538,6 +561,26 @@ extern "C" int rdst_u_bn_stats(const void* X, int64_t ld, int64_t P, int C, cons
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, part, nb, P, C, gamma, beta, eps, momentum, running_mean,
                      running_var, coef);
   return rdst_launch_status("rdst_u_bn_stats");
+}
+
+// the same from per-workgroup partials [nblk][2][C] a producer left (rdst_u_conv's `stats`): only the fixed-order finish runs
+extern "C" int rdst_u_bn_stats_from(const float* partials, int nblk, int64_t P, int C, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* coef, void* scratch, void* stream) {
+  if (!partials || nblk <= 0 || !gamma || !beta || !coef || !scratch || P <= 0)
+    return rdst_fail(RDST_EINVAL, "rdst_u_bn_stats_from: bad argument");
+  if (C > MAXC) return rdst_fail(RDST_ENOTSUP, "rdst_u_bn_stats_from: C = %d > %d", C, MAXC);
+  hipStream_t st = (hipStream_t)stream;
+  if (nblk > 256) {   // many short rows: fold them into 64 first (see fold_partials_kernel)
+    float* part = (float*)((char*)scratch + OFF_PART);
+    constexpr int NS = 64;
+    static_assert(NS <= NPART, "scratch");
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(NS), dim3(256), 0, st, partials, nblk, 2 * C, part);
+    partials = part;
+    nblk = NS;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, partials, nblk, P, C, gamma, beta, eps, momentum,
+                     running_mean, running_var, coef);
+  return rdst_launch_status("rdst_u_bn_stats_from");
 }
 
 extern "C" int rdst_u_bn_apply(const void* X, int64_t ldx, const float* coef, const void* X2, int64_t ldx2, const float* coef2,

@@ -36,6 +36,10 @@ struct UConvP {
   int B, Hin, Win, Hout, Wout, Cin, Cout, Npad, k, stride, transposed;
   int64_t P;   // output pixels
   int dbg;     // ablation switches (RDST_DEBUG builds only)
+  int* stats_blocks;  // host: receives gridDim.x when `stats` is written
+  float* stats;       // NULL, or [gridDim.x][2][Cout]: per-workgroup sum / sum of squares of the output channels over the tile's
+                      // pixels (the BatchNorm statistics of this convolution's output, halo kernel): summed in fixed order by
+                      // rdst_u_bn_stats_from — the separate column-sum pass over the output is gone
   const float* bn1;   // [scale C1][shift C1] (fp32) or NULL: the first source is read through relu(scale x + shift) — the
                       // train-mode BatchNorm + ReLU in front of this convolution, applied while the halo is staged (halo kernel)
 };
@@ -559,6 +563,45 @@ __global__ void __launch_bounds__(256) uconv_halo_kernel(const UConvP p) {
       }
       __builtin_amdgcn_wave_barrier();
     }
+  if (p.stats) {   // (no bias, no addend: checked by the launcher) the accumulators ARE the outputs
+    float s0[TN], s1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int m = (wm * TM + i) * 32 + acc_row(v, h);
+        const bool ok = y0 + m / TW < p.Hout && x0 + m % TW < p.Wout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float a = ok ? acc[i][j][v] : 0.f;
+          s0[j] += a;
+          s1[j] = fmaf(a, a, s1[j]);
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {   // lanes r and r + 32 hold the same channel
+      s0[j] += __shfl_xor(s0[j], 32, 64);
+      s1[j] += __shfl_xor(s1[j], 32, 64);
+    }
+    __syncthreads();   // the bounce tiles are done with
+    float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
+    if (h == 0)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        red[((wm * BN) + (wn * TN + j) * 32 + r) * 2] = s0[j];
+        red[((wm * BN) + (wn * TN + j) * 32 + r) * 2 + 1] = s1[j];
+      }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t0 += red[(w * BN + tid) * 2]; t1 += red[(w * BN + tid) * 2 + 1]; }
+      p.stats[((int64_t)blockIdx.x * 2) * p.Cout + n0 + tid] = t0;
+      p.stats[((int64_t)blockIdx.x * 2 + 1) * p.Cout + n0 + tid] = t1;
+    }
+  }
 }
 
 template <typename T, int TH, int TW, int BN, int KB, int WM, int WN, bool SPLIT>
@@ -570,6 +613,7 @@ int launch_halo(const UConvP& p, hipStream_t st) {
   auto kern = uconv_halo_kernel<T, TH, TW, BN, KB, WM, WN, SPLIT>;
   const int ntx = (p.Wout + TW - 1) / TW, nty = (p.Hout + TH - 1) / TH;
   const dim3 grid((unsigned)((int64_t)p.B * ntx * nty), (unsigned)(p.Npad / BN));
+  if (p.stats_blocks) *p.stats_blocks = (int)grid.x;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   return rdst_launch_status("rdst_u_conv");
 }
@@ -626,7 +670,7 @@ int pick_kb(const UConvP& p, hipStream_t st) {
     if (fits(128)) return pick_halo<T, 128, SPLIT>(p, st);
     if (fits(64)) return pick_halo<T, 64, SPLIT>(p, st);
   }
-  if (p.bn1) return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: bn1 is taken by the halo kernel only");
+  if (p.bn1 || p.stats) return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: bn1 / stats are taken by the halo kernel only");
   if (fits(128)) return pick_bn<T, 128, SPLIT>(p, st);
   if (fits(64)) return pick_bn<T, 64, SPLIT>(p, st);
   if constexpr (!SPLIT)
@@ -640,8 +684,10 @@ int pick_kb(const UConvP& p, hipStream_t st) {
 extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const void* X2, int64_t ld2, int C2, const void* Wp,
                            const float* bias, const void* add, int64_t ld_add, void* Y, int64_t ld_y, int B, int Hin, int Win,
                            int Hout, int Wout, int Cout, int Npad, int ksize, int stride, int transposed, int dtype, void* stream,
-                           const float* bn1) {
+                           const float* bn1, float* stats, int* stats_blocks) {
   if (!X1 || !Wp || !Y) return rdst_fail(RDST_EINVAL, "rdst_u_conv: null pointer");
+  if (stats && (!stats_blocks || bias || add || ksize != 3 || stride != 1))
+    return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: stats needs the 3x3 stride-1 form without bias / addend (and stats_blocks)");
   if (bn1 && (dtype == RDST_BF16 || ksize != 3 || stride != 1 || transposed || (C1 * 4) % 64 || ((C1 + C2) * 4) % 64 || ((uintptr_t)bn1 & 3)))
     return rdst_fail(RDST_ENOTSUP, "rdst_u_conv: bn1 (BatchNorm + ReLU on the way in) needs the fp32 / fp32x3 3x3 stride-1 forward form");
   if (dtype != RDST_F32 && dtype != RDST_BF16 && dtype != RDST_F32X3) return rdst_fail(RDST_EINVAL, "rdst_u_conv: bad dtype %d", dtype);
@@ -665,6 +711,7 @@ extern "C" int rdst_u_conv(const void* X1, int64_t ld1, int C1, int up1, const v
   p.k = ksize; p.stride = stride; p.transposed = transposed ? 1 : 0;
   p.P = (int64_t)B * Hout * Wout;
   p.bn1 = bn1;
+  p.stats = stats; p.stats_blocks = stats ? stats_blocks : nullptr;
   {
     const char* e = rdst_dbg_getenv("RDST_UCONV_DBG");
     p.dbg = e ? atoi(e) : 0;

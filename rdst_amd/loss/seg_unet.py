@@ -26,6 +26,7 @@ the throughput mode (bf16 activations, fp32 accumulation and statistics), the de
 from __future__ import annotations
 
 import os
+import ctypes
 from typing import Dict, List, Optional
 
 import torch
@@ -130,9 +131,11 @@ class _Runner:
 
     # ---- thin wrappers -------------------------------------------------------------------------------------------------
     def conv(self, x1, name, *, transposed=False, x2=None, up1=False, stride=1, out_hw=None, add=None, bias=None, cout=None,
-             bn1=None):
+             bn1=None, bn=None):
         """bn1 = the BatchNorm coefficients of x1 when x1 is a RAW convolution output: the convolution then reads it through
-        relu(BatchNorm(x1)) (see `fuse`), which is never written."""
+        relu(BatchNorm(x1)) (see `fuse`), which is never written.  bn = the nn.BatchNorm2d behind this convolution: returns
+        (y, coef) with the statistics taken from the convolution's own epilogue where the kernel offers that (3x3 stride 1),
+        from a pass over y otherwise."""
         wp, npad, k = self.packs[(name, transposed)]
         B, H1, W1, C1 = x1.shape
         Hin, Win = (2 * H1, 2 * W1) if up1 else (H1, W1)
@@ -140,10 +143,26 @@ class _Runner:
         if out_hw is None:
             out_hw = ((Hin - 1) // stride + 1, (Win - 1) // stride + 1) if not transposed else (Hin * stride, Win * stride)
         y = torch.empty((B, out_hw[0], out_hw[1], cout), dtype=self.dt, device=self.dev)
+        epi = (bn is not None and self.fuse and k == 3 and stride == 1 and not transposed and bias is None and add is None
+               and (C1 * 4) % 64 == 0 and ((C1 + C2) * 4) % 64 == 0)
+        if epi:
+            part = torch.empty((B * ((out_hw[0] + 7) // 8) * ((out_hw[1] + 7) // 8), 2, cout), dtype=torch.float32, device=self.dev)
+            nblk = ctypes.c_int(0)
         _lib.check(self.lib.rdst_u_conv(x1.data_ptr(), _ld(x1), C1, int(up1), _ptr(x2), _ld(x2), C2, wp.data_ptr(), _ptr(bias),
                                         _ptr(add), _ld(add), y.data_ptr(), cout, B, Hin, Win, out_hw[0], out_hw[1], cout, npad, k,
-                                        stride, int(transposed), self.code, self.st, _ptr(bn1)), "rdst_u_conv")
-        return y
+                                        stride, int(transposed), self.code, self.st, _ptr(bn1), part.data_ptr() if epi else None,
+                                        ctypes.byref(nblk) if epi else None), "rdst_u_conv")
+        if bn is None:
+            return y
+        if not epi:
+            return y, self.bn_stats(y, bn)
+        coef = torch.empty(4 * cout, dtype=torch.float32, device=self.dev)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        _lib.check(self.lib.rdst_u_bn_stats_from(part.data_ptr(), nblk.value, y.numel() // cout, cout, bn.weight.data_ptr(),
+                                                 bn.bias.data_ptr(), float(bn.eps), float(mom), _ptr(bn.running_mean),
+                                                 _ptr(bn.running_var), coef.data_ptr(), self.scratch.data_ptr(), self.st),
+                   "rdst_u_bn_stats_from")
+        return y, coef
 
     def bn_stats(self, x, bn: nn.BatchNorm2d, update=True):
         C = x.shape[-1]
@@ -203,15 +222,13 @@ class _Runner:
             for bi, blk in enumerate(layer):
                 name = f"encoder.layer{li}.{bi}"
                 pl = blk.conv1.out_channels
-                r1 = self.conv(x, name + ".conv1", stride=blk.stride, cout=pl)
-                c1 = self.bn_stats(r1, blk.bn1)
+                r1, c1 = self.conv(x, name + ".conv1", stride=blk.stride, cout=pl, bn=blk.bn1)
                 if self.fuse:
                     a1 = None
-                    r2 = self.conv(r1, name + ".conv2", cout=pl, bn1=c1)
+                    r2, c2 = self.conv(r1, name + ".conv2", cout=pl, bn1=c1, bn=blk.bn2)
                 else:
                     a1 = self.bn_apply(r1, c1)
-                    r2 = self.conv(a1, name + ".conv2", cout=pl)
-                c2 = self.bn_stats(r2, blk.bn2)
+                    r2, c2 = self.conv(a1, name + ".conv2", cout=pl, bn=blk.bn2)
                 if blk.downsample is not None:
                     rd = self.conv(x, name + ".downsample.0", stride=blk.stride, cout=pl)
                     cd = self.bn_stats(rd, blk.downsample[1])
@@ -236,15 +253,13 @@ class _Runner:
             name = f"decoder.blocks.{i}"
             co = blk.conv1[0].out_channels
             cx, cs = x.shape[-1], 0 if skips[i] is None else skips[i].shape[-1]
-            r1 = self.conv(x, name + ".conv1.0", x2=skips[i], up1=True, cout=co, bn1=xcoef)
-            c1 = self.bn_stats(r1, blk.conv1[1])
+            r1, c1 = self.conv(x, name + ".conv1.0", x2=skips[i], up1=True, cout=co, bn1=xcoef, bn=blk.conv1[1])
             if self.fuse:
                 a1 = None
-                r2 = self.conv(r1, name + ".conv2.0", cout=co, bn1=c1)
+                r2, c2 = self.conv(r1, name + ".conv2.0", cout=co, bn1=c1, bn=blk.conv2[1])
             else:
                 a1 = self.bn_apply(r1, c1)
-                r2 = self.conv(a1, name + ".conv2.0", cout=co)
-            c2 = self.bn_stats(r2, blk.conv2[1])
+                r2, c2 = self.conv(a1, name + ".conv2.0", cout=co, bn=blk.conv2[1])
             if self.fuse and i + 1 < nblk:   # the last block's output is a feature the losses / the head read: it is written
                 out, x, xcoef = None, r2, c2
             else:

@@ -35,7 +35,7 @@ for name, c1, c2, up, co, k, s, hin, tr in LAYERS:
     y = [torch.empty(B, Ho, Ho, co, device=DEV, dtype=dt) for _ in range(NB)]
     def run(i, st):
         L.check(lib.rdst_u_conv(x1[i].data_ptr(), c1, c1, up, None if x2[i] is None else x2[i].data_ptr(), c2, c2, wp.data_ptr(), None, None, 0,
-                                y[i].data_ptr(), co, B, H, W, Ho, Ho, co, npad, k, s, tr, code, st, None), "u_conv")
+                                y[i].data_ptr(), co, B, H, W, Ho, Ho, co, npad, k, s, tr, code, st, None, None, None), "u_conv")
     run(0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
