@@ -121,10 +121,11 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
   char* Ks = Qs + secsz;
   char* Vs = Ks + secsz;
   char* Os = Vs + secsz;           // dOut
-  char* dQs = Os + secsz;
-  char* dKs = dQs + secsz;
-  char* dVs = dKs + secsz;
-  float* tabL = reinterpret_cast<float*>(dVs + secsz);      // [HEADS][15][TS]
+  // (the dQ / dK / dV tiles are stored to HBM straight from the accumulator registers — lane = channel, register = token:
+  // a store instruction covers 32 consecutive channels of two token rows — instead of through three more LDS sections and
+  // a row copy-out: four sections instead of seven, so the fp32 kernel fits the LDS at C = 90 and 120 too, where it used to
+  // hand over to the scalar kernel: 0.9 / 1.18 ms per launch)
+  float* tabL = reinterpret_cast<float*>(Os + secsz);      // [HEADS][15][TS]
   float* dtabL = tabL + HEADS * 15 * TS;                     // [HEADS][15][TS]
   float4* stats = reinterpret_cast<float4*>(dtabL + HEADS * 15 * TS);  // [HEADS][64] {m, 1/l, delta, -}
 
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
   for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
     const int b = win / nW, wi = win - b * nW;
     const int wr = wi / g.nWw, wc = wi - wr * g.nWw;
+    auto out_row = [&](int row) { return p.dqkv + win_token8(b, wr, wc, row, g) * p.ldq; };   // dqkv row of window token `row`
     // ---- HBM -> LDS: qkv rows (3 sections, Q scaled) and dOut rows ---------------------------------
     {
       CH regs[MAXR][ITERS];
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         const int co = lane < cps ? lane : cps - 1;
         rego[i] = *reinterpret_cast<const CH*>(reinterpret_cast<const char*>(p.dout + tok * p.ldd) + (size_t)co * GRAN);
       }
-      __syncthreads();  // previous window fully copied out
+      __syncthreads();  // every wave is done with the previous window's sections
 #pragma unroll
       for (int i = 0; i < MAXR; ++i) {
         const int row = wv + NWAVES * i;
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         if (colin) {
 #pragma unroll
           for (int v = 0; v < 16; ++v)
-            *(reinterpret_cast<T*>(dQs + (size_t)(t * 32 + acc_row(v, h)) * ldt) + col) = from_f32<T>(acc[v] * p.scale);
+            out_row(t * 32 + acc_row(v, h))[col] = from_f32<T>(acc[v] * p.scale);
         }
       }
     }
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
           if (colin) {
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-              *(reinterpret_cast<T*>(dVs + (size_t)(t * 32 + acc_row(v, h)) * ldt) + col) = from_f32<T>(av[v]);
+              out_row(t * 32 + acc_row(v, h))[2 * C + col] = from_f32<T>(av[v]);
           }
         }
         {
@@ -374,20 +376,9 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
           if (colin) {
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-              *(reinterpret_cast<T*>(dKs + (size_t)(t * 32 + acc_row(v, h)) * ldt) + col) = from_f32<T>(ak[v] * kfix);
+              out_row(t * 32 + acc_row(v, h))[C + col] = from_f32<T>(ak[v] * kfix);
           }
         }
-      }
-    }
-    __syncthreads();
-    // ---- LDS -> HBM: dqkv rows = [dQ | dK | dV] -------------------------------------------------------
-    for (int row = wv; row < 64; row += NWAVES) {
-      const int64_t tok = win_token8(b, wr, wc, row, g);
-      char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq);
-      for (int c = lane; c < per_row; c += 64) {
-        const int off = c * GRAN;
-        const int sec = (off >= secb) + (off >= 2 * secb);
-        *reinterpret_cast<CH*>(dst + off) = *reinterpret_cast<const CH*>(dQs + sec * (secsz - secb) + row * ldt + off);
       }
     }
   }
@@ -435,7 +426,7 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
   int ldt = ((sec + 31) / 32) * 32;
   if ((ldt / 16) % 2 == 0) ldt += 16;
   p.ldt = ldt;
-  const size_t smem = (size_t)7 * 64 * ldt + (size_t)2 * HEADS * 15 * TS * 4 + (size_t)HEADS * 64 * 16;
+  const size_t smem = (size_t)4 * 64 * ldt + (size_t)2 * HEADS * 15 * TS * 4 + (size_t)HEADS * 64 * 16;
   if (smem > 160 * 1024) return RDST_ENOTSUP;
   const int64_t nwin = (int64_t)g.B * g.nWh * g.nWw;
   int64_t grid = 256;
@@ -451,6 +442,7 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), smem, st, p);                                     \
   }
   if (gran == 16 && iters == 1) RDST_WB_LAUNCH(16, 1)
+  else if (gran == 16 && iters == 2) RDST_WB_LAUNCH(16, 2)   // fp32, C = 120: 90 chunks of 16 B per qkv row
   else if (gran == 8 && iters == 1) RDST_WB_LAUNCH(8, 1)
   else if (gran == 8 && iters <= 3) RDST_WB_LAUNCH(8, 3)
   else if (gran == 4 && iters <= 3) RDST_WB_LAUNCH(4, 3)
