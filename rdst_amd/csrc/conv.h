@@ -54,6 +54,13 @@ int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, co
                      int64_t lddx, const bf16* acc, int64_t ldacc, float* dW, float* dbias, float* slab, const ConvGeom& g,
                      float s, hipStream_t st);
 size_t conv_c1_slab_floats(int Cin);
+// the mirror shape, one INPUT channel -> Cout (the head conv on a single-channel image), bf16: forward and weight gradient
+// on the same tile kernels; RDST_ENOTSUP for other shapes
+int conv_in1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr, bf16* Y,
+                      int64_t ldy, const ConvGeom& g, float s, hipStream_t st);
+int conv_in1_wgrad_bf16(const bf16* X, int64_t ldx, int in_act, const bf16* dY, int64_t lddy, float* dW, float* dbias, float* slab,
+                        const ConvGeom& g, float s, hipStream_t st);
+size_t conv_in1_slab_floats(int Cout);
 
 // register-stationary 3x3 kernels for the E1 shapes, bf16 (conv3_mfma.hip); RDST_ENOTSUP for everything else.
 // wpack: conv3_pack_bytes(Cin, Cout) bytes of 16-byte aligned device scratch (NULL -> RDST_ENOTSUP).

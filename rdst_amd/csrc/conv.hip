@@ -132,6 +132,7 @@ int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bia
           int64_t ldy, const ConvGeom& g, float s, void* wpack, bool prepacked, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (int rc = conv_c1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+    if (int rc = conv_in1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
     if (int rc = conv3_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, prepacked, st); rc != RDST_ENOTSUP) return rc;
   }
   if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
@@ -157,6 +158,9 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
     float* c1slab = reinterpret_cast<float*>(mscr + conv_mfma_scratch_bytes(ConvGeom{g.B, g.H, g.W, g.Cin, g.Cout, g.ks, g.pad, 2}));
     if (int rc = conv_c1_bwd_bf16(X, ldx, in_act, Wc, dY, lddy, dX, lddx, acc, ldacc, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP)
       return rc;
+    if (!dX && (dW || dbias) && g.r == 1) {   // one input channel (the head conv: no data gradient, the input is the image)
+      if (int rc = conv_in1_wgrad_bf16(X, ldx, in_act, dY, lddy, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP) return rc;
+    }
   }
   bool dxdone = false;
   if constexpr (sizeof(T) == 2) {   // register-stationary dgrad reads the (possibly pixel-shuffled) dY as it lies
@@ -273,7 +277,7 @@ extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
   ConvGeom g{B, H, W, Cin, Cout, ksize, ksize / 2, 2};  // r = 2 reserves room for an un-shuffled dY
   return conv3_pack_bytes(Cin, Cout) + (ksize == 3 ? conv3_wgrad_slab_bytes(Cin, Cout) : 0) + sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
-         conv_mfma_scratch_bytes(g) + sizeof(float) * conv_c1_slab_floats(Cin);
+         conv_mfma_scratch_bytes(g) + sizeof(float) * (Cin == 1 ? conv_in1_slab_floats(Cout) : conv_c1_slab_floats(Cin));
 }
 
 extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const void* dY, int64_t ld_dy,

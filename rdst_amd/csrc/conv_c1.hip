@@ -208,7 +208,12 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_fwd_kernel(const C1Args p)
 }
 
 // dX[q][c] = s * sum_taps dY[q - (tap offset)] W[c][tap] (+ Acc): window element (r, c) of the halo, rows grow + r, columns
-// gcol0 + j + c, is the dY of tap (ky, kx) = (2 - r, 2 - c), i.e. tap index 8 - 3r - c
+// gcol0 + j + c, is the dY of tap (ky, kx) = (2 - r, 2 - c), i.e. tap index 8 - 3r - c.
+// HEAD: the MIRROR problem, the forward of a conv from ONE input channel to Cin outputs (the head conv of RDSTSR,
+// rdst_variations.py:1213 `default_conv(in_chans, embed_dim, 3)` with in_chans = 1): Y[p][c] = (sum_taps x[p + (tap offset)]
+// W[c][tap] + bias[c]) s (+ R) — the same window with tap index 3r + c, a bias per channel.  (The names keep the data-gradient
+// reading: dY = the one-channel tensor, dX = the Cin-channel one, Acc = the residual.)
+template <bool HEAD>
 __global__ void __launch_bounds__(C1_THREADS) conv_c1_dgrad_kernel(const C1Args p) {
   __shared__ float dyt[C1_NPIX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ps = lane >> 3, grp = lane & 7;
@@ -224,6 +229,9 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_dgrad_kernel(const C1Args 
       for (int t = 0; t < 9; ++t) { w2[e2][t].x = w[2 * e2][t]; w2[e2][t].y = w[2 * e2 + 1][t]; }
   }
   const int gidx = wave * 8 + ps, grow = gidx >> 2, gcol0 = (gidx & 3) * 8;
+  float bsv[8];   // HEAD: bias[c] * s of the lane's 8 channels
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsv[e] = (HEAD && p.bias && l.on && e >= l.lo) ? p.bias[l.c0 + e] * p.s : 0.f;
   float dyv[C1_NDY];
   const C1Range rg = c1_range(p);
   if (rg.t0 < rg.t1) c1_dy_load(p, c1_tile(p, rg.t0), dyv, p.s, tid);
@@ -253,12 +261,16 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_dgrad_kernel(const C1Args 
         for (int c = 0; c < 3; ++c) {
           const f32x2 dv = (f32x2)(d[r][(j + c) % 3]);
 #pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) o[e2] = __builtin_elementwise_fma(dv, w2[e2][8 - 3 * r - c], o[e2]);
+          for (int e2 = 0; e2 < 4; ++e2) o[e2] = __builtin_elementwise_fma(dv, w2[e2][HEAD ? 3 * r + c : 8 - 3 * r - c], o[e2]);
         }
       const int x = t.x0 + gcol0 + j;
       if (!(y < g.H && x < g.W) || !l.on) continue;
       const int64_t pix = ((int64_t)t.b * g.H + y) * g.W + x;
       float of[8] = {o[0].x, o[0].y, o[1].x, o[1].y, o[2].x, o[2].y, o[3].x, o[3].y};
+      if (HEAD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) of[e] += bsv[e];
+      }
       if (p.Acc) {
         float f[8];
         c1_unpack8(*reinterpret_cast<const u32x4_a4*>(p.Acc + pix * p.ldacc + l.c0), f);
@@ -279,14 +291,18 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_dgrad_kernel(const C1Args 
   }
 }
 
-// dW[c][tap] += X[q][c] dY[q - (tap offset)] (q = input pixel, read ONCE): the same window as the data gradient
+// dW[c][tap] += X[q][c] dY[q - (tap offset)] (q = input pixel, read ONCE): the same window as the data gradient.
+// HEAD: the weight gradient of the one-input-channel conv, dW[c][tap] += dYh[p][c] x[p + (tap offset)] (X = the Cin-channel
+// gradient dYh, dY = the one-channel input x), tap index 3r + c, and d(bias)[c] = sum_p dYh[p][c] per channel.
+template <bool HEAD>
 __global__ void __launch_bounds__(C1_THREADS) conv_c1_wgrad_kernel(const C1Args p) {
   __shared__ float dyt[C1_NPIX];
-  __shared__ float part[C1_THREADS / 64][8][73];
+  __shared__ float part[C1_THREADS / 64][8][81];   // 72 weight taps + d(bias): one scalar (column 72) or, HEAD, 8 per-channel sums (73..80)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ps = lane >> 3, grp = lane & 7;
   const ConvGeom g = p.g;
   const C1Lane l = c1_lane(grp, g.Cin);
   f32x2 acc[4][9];
+  f32x2 accbh[4] = {(f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f)};   // HEAD: per-channel d(bias)
   float accb = 0.f;
 #pragma unroll
   for (int e2 = 0; e2 < 4; ++e2)
@@ -331,9 +347,14 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_wgrad_kernel(const C1Args 
         for (int c = 0; c < 3; ++c) {
           const f32x2 dv = (f32x2)(d[r][(j + c) % 3]);
 #pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) acc[e2][8 - 3 * r - c] = __builtin_elementwise_fma(f2[e2], dv, acc[e2][8 - 3 * r - c]);
+          for (int e2 = 0; e2 < 4; ++e2)
+            acc[e2][HEAD ? 3 * r + c : 8 - 3 * r - c] = __builtin_elementwise_fma(f2[e2], dv, acc[e2][HEAD ? 3 * r + c : 8 - 3 * r - c]);
         }
       accb += valid ? d[1][(j + 1) % 3] : 0.f;   // centre tap = dY at the pixel itself: d(bias)
+      if (HEAD) {
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) accbh[e2] += f2[e2];
+      }
     }
   }
   // lanes of one channel group (pixel slots: lane bits 3..5), then the waves, then one slab row per workgroup
@@ -355,23 +376,38 @@ __global__ void __launch_bounds__(C1_THREADS) conv_c1_wgrad_kernel(const C1Args 
   accb += __shfl_xor(accb, 8, 64);
   accb += __shfl_xor(accb, 16, 64);
   accb += __shfl_xor(accb, 32, 64);
+  float bh[8] = {accbh[0].x, accbh[0].y, accbh[1].x, accbh[1].y, accbh[2].x, accbh[2].y, accbh[3].x, accbh[3].y};
+  if (HEAD) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bh[e] += __shfl_xor(bh[e], 8, 64);
+      bh[e] += __shfl_xor(bh[e], 16, 64);
+      bh[e] += __shfl_xor(bh[e], 32, 64);
+    }
+  }
   if (ps == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e)
 #pragma unroll
       for (int t = 0; t < 9; ++t) part[wave][grp][e * 9 + t] = accs[e][t];
     part[wave][grp][72] = accb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[wave][grp][73 + e] = bh[e];
   }
   __syncthreads();
-  float* my = p.slab + (int64_t)blockIdx.x * (g.Cin * 9 + 1);
-  for (int i = tid; i < 8 * 73; i += C1_THREADS) {
-    const int gi = i / 73, k = i - gi * 73;
+  // slab row: [Cin * 9 weight taps][d(bias): 1 value, HEAD: Cin values]
+  float* my = p.slab + (int64_t)blockIdx.x * (g.Cin * 9 + (HEAD ? g.Cin : 1));
+  for (int i = tid; i < 8 * 81; i += C1_THREADS) {
+    const int gi = i / 81, k = i - gi * 81;
     float a = 0.f;
 #pragma unroll
     for (int wv = 0; wv < C1_THREADS / 64; ++wv) a += part[wv][gi][k];
     const C1Lane lg = c1_lane(gi, g.Cin);
     if (k == 72) {
-      if (gi == 0) my[g.Cin * 9] = a * p.s;
+      if (!HEAD && gi == 0) my[g.Cin * 9] = a * p.s;
+    } else if (k > 72) {
+      const int e = k - 73;
+      if (HEAD && lg.on && e >= lg.lo) my[g.Cin * 9 + lg.c0 + e] = a * p.s;
     } else {
       const int e = k / 9, t = k - e * 9;
       if (lg.on && e >= lg.lo) my[(lg.c0 + e) * 9 + t] = a * p.s;
@@ -444,6 +480,41 @@ int conv_c1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, co
 }
 
 size_t conv_c1_slab_floats(int Cin) { return (size_t)(1024 + 1) * (Cin * 9 + 1); }   // 1024 partial rows + the reduced row
+size_t conv_in1_slab_floats(int Cout) { return (size_t)(1024 + 1) * (Cout * 10); }
+
+// The mirror shape: 3x3 conv from ONE input channel to Cout (the head conv of RDSTSR on a single-channel image), bf16 rows.
+// Forward = conv_c1_dgrad_kernel<true>, weight gradient = conv_c1_wgrad_kernel<true> (no data gradient: the input is the image).
+bool in1_ok(const ConvGeom& g, int in_act) {
+  return g.Cin == 1 && g.ks == 3 && g.r == 1 && in_act == 0 && g.Cout >= 8 && g.Cout <= 64 && (g.Cout & 1) == 0;
+}
+int conv_in1_fwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const bf16* R, int64_t ldr, bf16* Y,
+                      int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
+  if (!in1_ok(g, in_act) || ((uintptr_t)Y & 3) || (ldy & 1) || ((uintptr_t)R & 3) || (ldr & 1)) return RDST_ENOTSUP;
+  C1Args p{};
+  ConvGeom gm = g;
+  gm.Cin = g.Cout; gm.Cout = 1;            // the kernels' view: Cin = the wide side
+  p.W = Wc; p.bias = bias; p.dY = X; p.lddy = ldx; p.dX = Y; p.lddx = ldy; p.Acc = R; p.ldacc = ldr; p.g = gm; p.s = s;
+  const int grid = c1_grid(p, 1024);
+  hipLaunchKernelGGL(conv_c1_dgrad_kernel<true>, dim3(grid), dim3(C1_THREADS), 0, st, p);
+  return rdst_launch_status("conv_in1_fwd");
+}
+int conv_in1_wgrad_bf16(const bf16* X, int64_t ldx, int in_act, const bf16* dY, int64_t lddy, float* dW, float* dbias, float* slab,
+                        const ConvGeom& g, float s, hipStream_t st) {
+  if (!in1_ok(g, in_act) || ((uintptr_t)dY & 3) || (lddy & 1)) return RDST_ENOTSUP;
+  C1Args p{};
+  ConvGeom gm = g;
+  gm.Cin = g.Cout; gm.Cout = 1;
+  p.X = dY; p.ldx = lddy; p.dY = X; p.lddy = ldx; p.g = gm; p.s = s; p.slab = slab;
+  const int grid = c1_grid(p, 1024);
+  hipLaunchKernelGGL(conv_c1_wgrad_kernel<true>, dim3(grid), dim3(C1_THREADS), 0, st, p);
+  if (int rc = rdst_launch_status("conv_in1_wgrad")) return rc;
+  const int n = g.Cout * 9, row = n + g.Cout;
+  float* red = slab + (size_t)grid * row;
+  if (int rc = slab_reduce(slab, red, grid, row, st)) return rc;
+  if (dW) (void)hipMemcpyAsync(dW, red, sizeof(float) * n, hipMemcpyDeviceToDevice, st);
+  if (dbias) (void)hipMemcpyAsync(dbias, red + n, sizeof(float) * g.Cout, hipMemcpyDeviceToDevice, st);
+  return 0;
+}
 
 // dW (1, Cin, 3, 3), dbias (1), dX (optional) of the one-output-channel conv; slab >= conv_c1_slab_floats()
 int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, const bf16* dY, int64_t lddy, bf16* dX,
@@ -458,7 +529,7 @@ int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, co
   p.g = g; p.s = s; p.slab = slab;
   if (dW || dbias) {
     const int grid = c1_grid(p, 1024);
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel, dim3(grid), dim3(C1_THREADS), 0, st, p);
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<false>, dim3(grid), dim3(C1_THREADS), 0, st, p);
     if (int rc = rdst_launch_status("conv_c1_wgrad")) return rc;
     const int n = g.Cin * 9;
     // one reduction over [grid][n + 1]: dW then dbias are contiguous in the slab row; the destinations are not
@@ -469,7 +540,7 @@ int conv_c1_bwd_bf16(const bf16* X, int64_t ldx, int in_act, const float* Wc, co
   }
   if (dX) {
     const int grid = c1_grid(p, 1024);
-    hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3(grid), dim3(C1_THREADS), 0, st, p);
+    hipLaunchKernelGGL(conv_c1_dgrad_kernel<false>, dim3(grid), dim3(C1_THREADS), 0, st, p);
     if (int rc = rdst_launch_status("conv_c1_dgrad")) return rc;
   }
   return 0;

@@ -99,6 +99,31 @@ CONV = [  # B, H, W, Cin, Cout, k, act, residual, scale, shuffle
 ]
 
 
+@pytest.mark.parametrize("B,H,W,Cout,scale", [(2, 9, 7, 60, 1.0), (3, 40, 70, 60, 0.5), (1, 16, 16, 36, 1.0)])
+def test_head_conv_one_input_channel(B, H, W, Cout, scale):
+    """The head conv of RDSTSR on a single-channel image (rdst_variations.py:1213, default_conv(1, embed_dim, 3)), bf16: its
+    input is the (mean-shifted) image, which needs no gradient — forward and weight gradient run on the tile kernels of
+    conv_c1.hip in their mirrored form (tiles ragged in both directions, several tiles per workgroup chunk, a channel count that
+    is not a multiple of 8)."""
+    from rdst_amd import ops
+    x = rand((B, H, W, 1), 1).bfloat16().float()
+    w = rand((Cout, 1, 3, 3), 2, 1 / 3.0)
+    b = 0.1 * rand((Cout,), 3)
+    gy = rand((B, H, W, Cout), 5).bfloat16().float()
+    wr, br = _leaf(w), _leaf(b)
+    yr = F.conv2d(x.permute(0, 3, 1, 2), wr, br, padding=1).permute(0, 2, 3, 1) * scale
+    yr.backward(gy)
+    xg, wg, bg = x.to(DEV).bfloat16(), _gpu(w), _gpu(b)     # xg: no gradient requested
+    yg = ops.conv_rows(xg, wg, bg, out_scale=scale)
+    yg.backward(gy.to(DEV).bfloat16())
+    torch.cuda.synchronize()
+    assert (yg.float().cpu() - yr.detach()).abs().max().item() <= 2e-2 * max(1.0, yr.abs().max().item())
+
+    def rel(a, b_):
+        return (a.float().cpu() - b_).norm().item() / max(b_.norm().item(), 1e-12)
+    assert rel(wg.grad, wr.grad) <= 1e-2 and rel(bg.grad, br.grad) <= 1e-2
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,act,res,scale,r", CONV)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_rows(B, H, W, Cin, Cout, k, act, res, scale, r, dtype):
