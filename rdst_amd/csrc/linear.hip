@@ -99,6 +99,155 @@ __global__ void __launch_bounds__(256) ln_apply_kernel(const T* __restrict__ X, 
   Y[m * ldy + k] = from_f32<T>(v);
 }
 
+// ---- LayerNorm-only rows, bf16, 8 <= K <= 64 (the patch norm and the final norm of RDSTSR: K = 60): 8 lanes per row ------
+// A row's K channels are 8 chunks of 16 B (lane = chunk, the last chunk of a row that is not a multiple of 8 overlaps its
+// neighbour and counts only its own channels), a wave works on 8 rows at once, row sums over the 8 lanes on the DPP path.
+// Forward: statistics + apply in one pass (was row_stats_kernel + ln_apply_kernel: one wave per row, 2-byte loads);
+// backward: dY read as it lies (was scale_to_f32_kernel into an fp32 copy + ln_bwd_rows_kernel: one wave per row).
+typedef uint32_t ln8_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float ln8_sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ void ln8_unpack(const ln8_u32x4& v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u); f[2] = __uint_as_float(v.y << 16);
+  f[3] = __uint_as_float(v.y & 0xffff0000u); f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t ln8_pack2(float a, float b) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, __float2bfloat16(a)) | ((uint32_t)__builtin_bit_cast(uint16_t, __float2bfloat16(b)) << 16);
+}
+struct Ln8Lane { int c0, lo; bool on; };
+__device__ __forceinline__ Ln8Lane ln8_lane(int grp, int K) {
+  Ln8Lane l;
+  l.on = 8 * grp < K;
+  l.c0 = 8 * grp + 8 <= K ? 8 * grp : K - 8;
+  l.lo = 8 * grp - l.c0;
+  if (!l.on) { l.c0 = 0; l.lo = 8; }
+  return l;
+}
+__device__ __forceinline__ void ln8_store(bf16* dst, const float (&o)[8], const Ln8Lane& l) {
+  if (!l.on) return;
+  if (l.lo == 0) {
+    ln8_u32x4 u;
+    u.x = ln8_pack2(o[0], o[1]); u.y = ln8_pack2(o[2], o[3]); u.z = ln8_pack2(o[4], o[5]); u.w = ln8_pack2(o[6], o[7]);
+    *reinterpret_cast<ln8_u32x4*>(dst + l.c0) = u;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e >= l.lo) dst[l.c0 + e] = __float2bfloat16(o[e]);
+  }
+}
+
+__global__ void __launch_bounds__(256) ln8_fwd_kernel(const bf16* __restrict__ X, int64_t ldx, const float* __restrict__ g,
+                                                      const float* __restrict__ b, const bf16* R, int64_t ldr, bf16* Y, int64_t ldy,
+                                                      float* __restrict__ stats, int64_t M, int K, float s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ps = lane >> 3, grp = lane & 7;
+  const Ln8Lane l = ln8_lane(grp, K);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gm[e] = g[l.c0 + e]; bt[e] = b[l.c0 + e]; }
+  const float invK = 1.0f / (float)K;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 8; r0 < M; r0 += (int64_t)gridDim.x * 32) {
+    const int64_t row = r0 + ps < M ? r0 + ps : M - 1;
+    const bool valid = r0 + ps < M;
+    float f[8];
+    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(X + row * ldx + l.c0), f);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += (l.on && e >= l.lo) ? f[e] : 0.f;
+    const float mean = ln8_sum8(sum) * invK;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f[e] -= mean;
+      sq = (l.on && e >= l.lo) ? fmaf(f[e], f[e], sq) : sq;
+    }
+    const float rstd = 1.0f / sqrtf(ln8_sum8(sq) * invK + kLnEps);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f[e] * rstd * gm[e] + bt[e]) * s;
+    if (R) {
+      float rr[8];
+      ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(R + row * ldr + l.c0), rr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += rr[e];
+    }
+    if (valid) {
+      ln8_store(Y + row * ldy, o, l);
+      if (grp == 0) *reinterpret_cast<float2*>(stats + 2 * row) = make_float2(mean, rstd);
+    }
+  }
+}
+
+// dX = rstd (g - mean(g) - xhat mean(g xhat)) + acc, g = dY s gamma; per-block partial d(gamma) / d(beta) -> slab [block][2][K]
+__global__ void __launch_bounds__(256) ln8_bwd_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma, bf16* dX,
+                                                      int64_t lddx, const bf16* acc, int64_t ldacc, float* __restrict__ slab, int64_t M,
+                                                      int K, float s) {
+  __shared__ float red[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ps = lane >> 3, grp = lane & 7;
+  const Ln8Lane l = ln8_lane(grp, K);
+  float gm[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gm[e] = gamma[l.c0 + e]; dg[e] = 0.f; db[e] = 0.f; }
+  const float invK = 1.0f / (float)K;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 8; r0 < M; r0 += (int64_t)gridDim.x * 32) {
+    const int64_t row = r0 + ps < M ? r0 + ps : M - 1;
+    const bool valid = r0 + ps < M;
+    const float2 st = *reinterpret_cast<const float2*>(stats + 2 * row);
+    float da[8], xh[8], gg[8];
+    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(dY + row * lddy + l.c0), da);
+    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(X + row * ldx + l.c0), xh);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool mine = l.on && e >= l.lo && valid;
+      da[e] = mine ? da[e] * s : 0.f;
+      xh[e] = (xh[e] - st.x) * st.y;
+      gg[e] = da[e] * gm[e];
+      s1 += gg[e];
+      s2 = fmaf(gg[e], xh[e], s2);
+      dg[e] = fmaf(da[e], xh[e], dg[e]);
+      db[e] += da[e];
+    }
+    s1 = ln8_sum8(s1) * invK;
+    s2 = ln8_sum8(s2) * invK;
+    if (dX && valid) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = st.y * (gg[e] - s1 - xh[e] * s2);
+      if (acc) {
+        float a[8];
+        ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(acc + row * ldacc + l.c0), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += a[e];
+      }
+      ln8_store(dX + row * lddx, o, l);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {   // the 8 row slots of the wave (lane bits 3..5), fixed butterfly
+    dg[e] += __shfl_xor(dg[e], 8, 64); dg[e] += __shfl_xor(dg[e], 16, 64); dg[e] += __shfl_xor(dg[e], 32, 64);
+    db[e] += __shfl_xor(db[e], 8, 64); db[e] += __shfl_xor(db[e], 16, 64); db[e] += __shfl_xor(db[e], 32, 64);
+  }
+  if (ps == 0 && l.on)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e >= l.lo) { red[wave][0][l.c0 + e] = dg[e]; red[wave][1][l.c0 + e] = db[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * K; i += 256) {
+    const int which = i / K, k = i - which * K;
+    slab[(int64_t)blockIdx.x * 2 * K + i] = red[0][which][k] + red[1][which][k] + red[2][which][k] + red[3][which][k];
+  }
+}
+static inline bool ln8_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, int K) {
+  auto al = [](const void* q, int64_t l) { return ((uintptr_t)q & 3) == 0 && (l & 1) == 0; };
+  return K >= 8 && K <= 64 && (K & 1) == 0 && al(a, lda) && al(b, ldb) && al(c, ldc);
+}
+
 // ---- functors -------------------------------------------------------------------------------------
 template <typename T>
 struct LinIn {  // f(X)[m][k]
@@ -257,6 +406,14 @@ int fwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_
     return rdst_launch_status("row_stats");
   };
   if (!Wt) {
+    if constexpr (sizeof(T) == 2) {
+      if (ln8_ok(X, ldx, Y, ldy, R, ldr, K)) {
+        const int64_t nb = (M + 31) / 32;
+        hipLaunchKernelGGL(ln8_fwd_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, st, X, ldx, ln_w, ln_b, R, ldr, Y, ldy,
+                           stats, M, K, s);
+        return rdst_launch_status("ln8_fwd");
+      }
+    }
     if (int rc = run_stats()) return rc;
     const int64_t n = M * K;
     hipLaunchKernelGGL((ln_apply_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, ldx, stats, ln_w,
@@ -402,6 +559,15 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
   float* dA = wsp;
   float* small = dA + M * K;
   const int64_t n = M * K;
+  if constexpr (sizeof(T) == 2) {
+    if (K <= 64 && ln8_ok(X, ldx, dY, lddy, dX, lddx, K) && ln8_ok(acc, ldacc, nullptr, 0, nullptr, 0, K)) {
+      const int64_t nb = (M + 31) / 32;
+      const int blocks = (int)(nb < kSmallBlocks ? nb : kSmallBlocks);
+      hipLaunchKernelGGL(ln8_bwd_kernel, dim3(blocks), dim3(256), 0, st, dY, lddy, X, ldx, stats, ln_w, dX, lddx, acc, ldacc, small, M, K, s);
+      if (int rc = rdst_launch_status("ln8_bwd")) return rc;
+      return slab_reduce2(small, dln_w, dln_b, blocks, K, st);
+    }
+  }
   hipLaunchKernelGGL((scale_to_f32_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dY, lddy, dA, M, K, s);
   if (int rc = rdst_launch_status("scale_to_f32")) return rc;
   if (K > 512) return rdst_fail(RDST_ENOTSUP, "rdst_ln_linear_bwd: LayerNorm width %d > 512", K);
