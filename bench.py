@@ -72,9 +72,10 @@ def _alg(name, a, elt):
     if name == "rdst_ln_linear_fwd":
         M, K, N = a[14:17]
         return M * (K + N + (N if a[7] else 0)) * elt, (2 * M * K * N if a[5] else 0)
-    if name == "rdst_ln_linear_bwd":
+    if name in ("rdst_ln_linear_bwd", "rdst_ln_linear_bwd2"):   # (bwd2: + the second addend's K channels per token)
         M, K, N = a[19:22]
-        return (M * (K + N + (K if a[9] else 0) + (K if a[11] else 0)) * elt,
+        add2 = K if (name.endswith("2") and a[25]) else 0
+        return (M * (K + N + (K if a[9] else 0) + (K if a[11] else 0) + add2) * elt,
                 2 * M * K * N * ((1 if a[9] else 0) + (1 if a[13] else 0)) if a[6] else 0)
     if name == "rdst_mlp_fwd":
         M, C, hid = a[13:16]
@@ -97,8 +98,9 @@ def _alg(name, a, elt):
 class Recorder:
     """Wraps the C-ABI entry points of the loaded library: records (name, args) of every call and can leave the calls of
     one entry point out (`skip`), which is how an op's time INSIDE the step is measured (step with - step without)."""
-    OPS = ("rdst_wattn_fwd", "rdst_wattn_bwd", "rdst_ln_linear_fwd", "rdst_ln_linear_bwd", "rdst_mlp_fwd", "rdst_mlp_bwd",
-           "rdst_conv_fwd", "rdst_conv_bwd", "rdst_nchw_to_rows", "rdst_rows_to_nchw")
+    OPS = ("rdst_wattn_fwd", "rdst_wattn_bwd", "rdst_ln_linear_fwd", "rdst_ln_linear_bwd", "rdst_ln_linear_bwd2", "rdst_mlp_fwd",
+           "rdst_mlp_bwd", "rdst_conv_fwd", "rdst_conv_bwd", "rdst_nchw_to_rows", "rdst_rows_to_nchw")
+    STREAM_ARG = {"rdst_ln_linear_bwd2": 24}   # position of the stream argument where it is not the last one
 
     def __init__(self, lib):
         self.lib, self.calls, self.skip, self.orig = lib, [], None, {}
@@ -142,8 +144,9 @@ def _replay_calls(lib, calls, reps=3):
         st = torch.cuda.current_stream().cuda_stream
         with torch.cuda.graph(g, stream=side):
             st = torch.cuda.current_stream().cuda_stream
-            for n, a in calls:
-                getattr(lib, n)(*a[:-1], st)       # same operands, the capturing stream
+            for n, a in calls:                      # same operands, the capturing stream
+                i = Recorder.STREAM_ARG.get(n, len(a) - 1)
+                getattr(lib, n)(*a[:i], st, *a[i + 1:])
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     return _timed_replay(g, reps) / len(calls)
@@ -466,14 +469,18 @@ def fp32_line(device, x, tgt, B, lib):
     return line
 
 
+def _op_key(n):
+    return "rdst_ln_linear_bwd" if n == "rdst_ln_linear_bwd2" else n   # one op, two entry points (with / without a second addend)
+
+
 def _op_table(lib, recorded, elt, reps, mfma_peak):
     groups = {}
     for n, a in recorded:
-        groups.setdefault(n, []).append((n, a))
+        groups.setdefault(_op_key(n), []).append((n, a))
     table = []
     for n, calls in groups.items():
         ms = _replay_calls(lib, calls, reps)
-        by = [_alg(n, a, elt) for _, a in calls]
+        by = [_alg(cn, a, elt) for cn, a in calls]
         nbytes, flops = sum(b for b, _ in by) / len(calls), sum(f for _, f in by) / len(calls)
         hbm, mf = nbytes / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), flops / (ms * 1e-3) / mfma_peak
         table.append({"op": n, "launches_per_step": len(calls), "avg_us": round(1e3 * ms, 2),
@@ -489,7 +496,7 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
     mfma_peak = MFMA_PEAK_TFLOPS[dtype_name] * 1e12
     groups = {}
     for n, a in recorded:
-        groups.setdefault(n, []).append((n, a))
+        groups.setdefault(_op_key(n), []).append((n, a))
     table = _op_table(lib, recorded, elt, reps, mfma_peak)
     out["kernels"] = {"how": "all launches of a C-ABI entry point recorded while the step graph was captured, replayed back to "
                              "back from one HIP graph on the step's own operands (cold: a step's activations are GBs), HIP "
