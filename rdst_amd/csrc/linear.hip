@@ -467,6 +467,20 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
           rc = linear_dgrad_ln2_mfma<T>(X, ldx, stats, ln_w, Wt, dY, lddy, dX, lddx, acc, ldacc, M, K, N, s, st);
           if (rc == 0) return 0;
           if (rc != RDST_ENOTSUP) return rc;
+          if (N >= 64) {
+            // N too wide for the kernel's resident weights (fp32 qkv at C = 90 / 120: 3C x C floats > LDS): the data gradient is
+            // LINEAR in dY — dX = LN'(dY[:, :N1] W[:N1]) + LN'(dY[:, N1:] W[N1:]) — so two launches over halves of the
+            // output features, the second accumulating onto the first (in place), replace the scalar GEMM + LayerNorm-backward
+            // pair this shape used to fall back to
+            const int N1 = (N / 2 + 3) / 4 * 4;
+            rc = linear_dgrad_ln2_mfma<T>(X, ldx, stats, ln_w, Wt, dY, lddy, dX, lddx, acc, ldacc, M, K, N1, s, st);
+            if (rc == 0) {
+              rc = linear_dgrad_ln2_mfma<T>(X, ldx, stats, ln_w, Wt + (int64_t)N1 * K, dY + N1, lddy, dX, lddx, dX, lddx, M, K, N - N1, s, st);
+              if (rc != RDST_ENOTSUP) return rc;   // (a refused SECOND half leaves dX half done: rebuilt from scratch below)
+            } else if (rc != RDST_ENOTSUP) {
+              return rc;
+            }
+          }
           // dX not covered: finish it below; dW / dbias / d(gamma) / d(beta) are done
           dW = nullptr; dbias = nullptr; dln_w = nullptr; dln_b = nullptr;
         } else if (rc != RDST_ENOTSUP) {
