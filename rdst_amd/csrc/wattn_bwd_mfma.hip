@@ -24,9 +24,7 @@ namespace {
 
 constexpr int TS = 24;
 constexpr int HEADS = 6;
-constexpr int NWAVES = 2 * HEADS;
-constexpr int NTHREADS = 64 * NWAVES;
-constexpr int MAXR = (64 + NWAVES - 1) / NWAVES;  // token rows staged per wave
+constexpr int NUNITS = 2 * HEADS;   // (query / key tile, head) units of a window
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -66,14 +64,15 @@ __device__ __forceinline__ Pack16 masked_pack(const char* base, int c0, int c_lo
 }
 
 // acc (32 x 32, rows = tokens of tile `rt`, cols = channel tile ct) += X^T . Bsec
-//   X[kk][v]: accumulator tiles whose ROW index (tokens of tile kk) is contracted; Bsec rows = those tokens.
+//   X[kk][v]: accumulator tiles whose ROW index (tokens of tile kk) is contracted; Bsec rows = those tokens;
+//   col0 = first of the 32 columns (bf16: a multiple of 32 — the transposed reads want aligned chunks; fp32: any).
 template <typename T>
-__device__ __forceinline__ void acc_xt_b(f32x16& acc, const f32x16 (&X)[2], const char* Bsec, int ldt, int ct, bool colin,
+__device__ __forceinline__ void acc_xt_b(f32x16& acc, const f32x16 (&X)[2], const char* Bsec, int ldt, int col0, bool colin,
                                          int lane) {
   const int r = lane & 31, h = lane >> 5;
   if constexpr (sizeof(T) == 2) {
     const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int colB = ct * 32 + 16 * (gq & 1) + 4 * pp;
+    const int colB = col0 + 16 * (gq & 1) + 4 * pp;
     const uint32_t cm = colin ? 0xffffffffu : 0u;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -94,7 +93,7 @@ __device__ __forceinline__ void acc_xt_b(f32x16& acc, const f32x16 (&X)[2], cons
   } else {
     const float* Bf = reinterpret_cast<const float*>(Bsec);
     const int ldb = ldt / 4;
-    const int col = ct * 32 + r;
+    const int col = col0 + r;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -105,29 +104,42 @@ __device__ __forceinline__ void acc_xt_b(f32x16& acc, const f32x16 (&X)[2], cons
   }
 }
 
-template <typename T, int GRAN, int ITERS>
-__global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T> p) {
+// NWAVES = 12: one unit per wave (bf16: 170 registers per wave are enough).  NWAVES = 8 (fp32): two waves per SIMD with
+// 256 registers each, waves 0-3 own two units — the 12-wave form of the fp32 kernel spilled 160-170 registers per lane
+// (3.4 GB of scratch traffic per launch); the matrix-core work per SIMD is the same three units either way.
+// CT > 0: the channel count is a compile-time constant (LDS row stride and head width with it): with run-time strides
+// every one of the ~100 LDS positions of a unit is its own multiply and its own register, all hoisted out of the window
+// loop and spilled (440 vector instructions and 136 scratch stores in front of the loop in the fp32 kernel).
+template <typename T> constexpr int wb_ldt(int C) {
+  int ldt = ((C * (int)sizeof(T) + 31) / 32) * 32;
+  return (ldt / 16) % 2 == 0 ? ldt + 16 : ldt;
+}
+template <typename T, int GRAN, int ITERS, int NWAVES, int CT>
+__global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArgs<T> p) {
+  constexpr int NTHREADS = 64 * NWAVES;
+  constexpr int MAXR = (64 + NWAVES - 1) / NWAVES;   // token rows staged per wave
+  constexpr int NU = (NUNITS + NWAVES - 1) / NWAVES;  // units per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using MM = Mma<T>;
   using CH = typename Chunk<GRAN>::type;
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
+  // fp32: the 32-column window of the accumulate products starts at the head's first channel (one window per head; with
+  // windows at multiples of 32 half of the heads of C = 90 / 120 straddle two: 32 more MFMAs per product)
+  constexpr bool HEADCOL = !BF;
   const WinGeom g = p.g;
-  const int C = g.C, d = p.d, ldt = p.ldt;
+  const int C = CT > 0 ? CT : g.C, d = CT > 0 ? CT / HEADS : p.d, ldt = CT > 0 ? wb_ldt<T>(CT) : p.ldt;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int secsz = 64 * ldt;
-  char* Qs = smem;                 // Q * scale (* log2 e)
-  char* Ks = Qs + secsz;
-  char* Vs = Ks + secsz;
-  char* Os = Vs + secsz;           // dOut
+  // sections: Q * scale (* log2 e) | K | V | dOut, 64 rows of ldt bytes each
   // (the dQ / dK / dV tiles are stored to HBM straight from the accumulator registers — lane = channel, register = token:
   // a store instruction covers 32 consecutive channels of two token rows — instead of through three more LDS sections and
   // a row copy-out: four sections instead of seven, so the fp32 kernel fits the LDS at C = 90 and 120 too, where it used to
   // hand over to the scalar kernel: 0.9 / 1.18 ms per launch)
-  float* tabL = reinterpret_cast<float*>(Os + secsz);      // [HEADS][15][TS]
-  float* dtabL = tabL + HEADS * 15 * TS;                     // [HEADS][15][TS]
-  float4* stats = reinterpret_cast<float4*>(dtabL + HEADS * 15 * TS);  // [HEADS][64] {m, 1/l, delta, -}
+  float* tab0 = reinterpret_cast<float*>(smem + 4 * secsz);   // [HEADS][15][TS]
+  float* dtabL = tab0 + HEADS * 15 * TS;                       // [HEADS][15][TS]
+  // then float4 stats[HEADS][64] {m, 1/l, delta, -}
 
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
   const float tabscale = BF ? LOG2E : 1.0f;
@@ -139,40 +151,59 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
   for (int i = tid; i < HEADS * 225; i += NTHREADS) {
     const int hd = i / 225, rem = i - hd * 225;
     const int dy = rem / 15, dx = rem - dy * 15;
-    tabL[(hd * 15 + dy) * TS + dx] = p.table[rem * HEADS + hd] * tabscale;
+    tab0[(hd * 15 + dy) * TS + dx] = p.table[rem * HEADS + hd] * tabscale;
   }
   {  // zero the pad columns of the four input sections once
     const int padw = (ldt - C * (int)sizeof(T)) / 4;
     for (int idx = tid; idx < 4 * 64 * padw; idx += NTHREADS) {
       const int row = idx / padw, w = idx - row * padw;
-      *reinterpret_cast<uint32_t*>(Qs + (size_t)row * ldt + C * sizeof(T) + 4 * w) = 0u;
+      *reinterpret_cast<uint32_t*>(smem + (size_t)row * ldt + C * sizeof(T) + 4 * w) = 0u;
     }
   }
   const int secb = C * (int)sizeof(T);
   const int cps = secb / GRAN;
   const int per_row = 3 * cps;
 
-  const int t = wv & 1, hd = wv >> 1;       // this wave's tile and head
-  const int c_lo = hd * d, c_hi = c_lo + d;
-  const int t_lo = c_lo / KP, t_hi = (c_hi - 1) / KP;
-  const int ct_lo = c_lo / 32, ct_hi = (c_hi - 1) / 32;
   const int thr = g.ws - g.shift;
   const float NEG = -100.0f * tabscale;
-  const int yl = t * 4 + (r >> 3), xl = r & 7;  // window coords of this lane's token (tile t)
-  const bool fyl = yl < thr, fxl = xl < thr;
 
   // d(table): dS^T summed element-wise over all windows of this workgroup in registers (LDS float atomics
   // cost ~180 cycles per wave-instruction: 230 of 370 us when issued per window); binned once at the end.
-  f32x16 Dsum[2];
+  f32x16 Dsum[NU][2];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
+  for (int ui = 0; ui < NU; ++ui)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) Dsum[kt][v] = 0.f;
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) Dsum[ui][kt][v] = 0.f;
+  // unit ui of this wave: tile t (32 tokens) of head hd
+#define RDST_WB_UNIT(ui)                                                                       \
+  const int u = wv + NWAVES * (ui);                                                            \
+  const int t = u & 1, hd = u >> 1;                                                            \
+  const int c_lo = hd * d, c_hi = c_lo + d;                                                    \
+  const int t_lo = c_lo / KP, t_hi = (c_hi - 1) / KP;                                          \
+  const int ct_lo = c_lo / 32, ct_hi = (c_hi - 1) / 32;                                        \
+  const int yl = t * 4 + (r >> 3); /* window coords of this lane's token (tile t): (yl, xl) */ \
+  const bool fyl = yl < thr, fxl = xl < thr;
 
   for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
     const int b = win / nW, wi = win - b * nW;
     const int wr = wi / g.nWw, wc = wi - wr * g.nWw;
     auto out_row = [&](int row) { return p.dqkv + win_token8(b, wr, wc, row, g) * p.ldq; };   // dqkv row of window token `row`
+    // the lane index is made opaque per window: the ~200 LDS positions of a unit are window-invariant, and hipcc
+    // otherwise computes each of them (section + row x stride + lane part as its own register, not as an instruction
+    // offset) in front of the window loop and spills them; recomputed per window they are base + immediate
+    int tidw = tid;
+    asm volatile("" : "+v"(tidw));
+    const int lane = tidw & 63, r = lane & 31, h = lane >> 5;
+    const int xl = r & 7;
+    char* const smw = smem;
+    char* const Qs = smw;
+    char* const Ks = Qs + secsz;
+    char* const Vs = Ks + secsz;
+    char* const Os = Vs + secsz;
+    const float* const tabL = reinterpret_cast<const float*>(Os + secsz);
+    float4* const stats = reinterpret_cast<float4*>(const_cast<float*>(tabL) + 2 * HEADS * 15 * TS);
     // ---- HBM -> LDS: qkv rows (3 sections, Q scaled) and dOut rows ---------------------------------
     {
       CH regs[MAXR][ITERS];
@@ -214,7 +245,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
                 }
                 __builtin_memcpy(&v, w, GRAN);
               }
-              *reinterpret_cast<CH*>(smem + sec * (secsz - secb) + row * ldt + off) = v;
+              *reinterpret_cast<CH*>(smw + sec * (secsz - secb) + row * ldt + off) = v;
             }
           }
           if (lane < cps) *reinterpret_cast<CH*>(Os + row * ldt + lane * GRAN) = rego[i];
@@ -225,9 +256,21 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
 
     const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
+    // the shift mask as a comparison of region numbers (2 [row >= thr] + [column >= thr], each only where the window is the
+    // last of its row / column): mr / mc are made opaque per window, otherwise hipcc turns the 64 per-element predicates
+    // into window-invariant lane masks, computes all of them in front of the window loop and spills them
+    int mr = mrow ? 1 : 0, mc = mcol ? 1 : 0;
+    asm volatile("" : "+v"(mr), "+v"(mc));
+    int rx4[4];   // column part of the region of token column (v & 3) + 4 h
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rx4[j] = mc & (int)(j + 4 * h >= thr);
 
     // ================= pass T: keys on registers, query (tile t) on the lane ======================
-    if (!(RDST_DBGV(p.dbg) & 2)) {
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui) {
+      if (NU > 1 && wv + NWAVES * ui >= NUNITS) break;
+      if (RDST_DBGV(p.dbg) & 2) break;
+      RDST_WB_UNIT(ui)
       f32x16 X[2], D[2];
       const float* tb = tabL + hd * 15 * TS + (yl + 7) * TS + (xl + 7) - 4 * h;
 #pragma unroll
@@ -250,13 +293,13 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         }
       }
       if (masked) {
+        const int rl = 2 * (mr & (int)!fyl) + (mc & (int)!fxl);   // shift region of the lane's token
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
-            const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
-            const bool diff = (mrow && (fyl != (yj < thr))) || (mcol && (fxl != (xj < thr)));
-            X[kt][v] += diff ? NEG : 0.f;
+            const int yj = kt * 4 + (v >> 2);
+            X[kt][v] += rl != 2 * (mr & (int)(yj >= thr)) + rx4[v & 3] ? NEG : 0.f;
           }
       }
       float m = -INFINITY;
@@ -292,16 +335,17 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         for (int v = 0; v < 16; ++v) {
           const float ds = X[kt][v] * (D[kt][v] - dl);  // dS^T
           D[kt][v] = ds;
-          Dsum[kt][v] += ds;
+          Dsum[ui][kt][v] += ds;
         }
       // dQ_h (tile t) = scale * (dS^T)^T K_h
-      for (int ct = ct_lo; ct <= ct_hi; ++ct) {
+      for (int ci = 0; ci < (HEADCOL ? 1 : ct_hi - ct_lo + 1); ++ci) {
         f32x16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const int col = ct * 32 + r;
+        const int col0 = HEADCOL ? c_lo : (ct_lo + ci) * 32;
+        const int col = col0 + r;
         const bool colin = col >= c_lo && col < c_hi;
-        acc_xt_b<T>(acc, D, Ks, ldt, ct, colin, lane);
+        acc_xt_b<T>(acc, D, Ks, ldt, col0, colin, lane);
         if (colin) {
 #pragma unroll
           for (int v = 0; v < 16; ++v)
@@ -312,7 +356,11 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
     __syncthreads();  // statistics of both query tiles are in LDS
 
     // ================= pass N: queries on registers, key (tile t) on the lane ======================
-    if (!(RDST_DBGV(p.dbg) & 4)) {
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui) {
+      if (NU > 1 && wv + NWAVES * ui >= NUNITS) break;
+      if (RDST_DBGV(p.dbg) & 4) break;
+      RDST_WB_UNIT(ui)
       f32x16 Y[2], E[2];
       const float* tb = tabL + hd * 15 * TS + (7 - yl) * TS + (7 - xl) + 4 * h;
 #pragma unroll
@@ -335,13 +383,13 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
         }
       }
       if (masked) {
+        const int rl = 2 * (mr & (int)!fyl) + (mc & (int)!fxl);
 #pragma unroll
         for (int it = 0; it < 2; ++it)
 #pragma unroll
           for (int v = 0; v < 16; ++v) {
-            const int yi = it * 4 + (v >> 2), xi = (v & 3) + 4 * h;
-            const bool diff = (mrow && (fyl != (yi < thr))) || (mcol && (fxl != (xi < thr)));
-            Y[it][v] += diff ? NEG : 0.f;
+            const int yi = it * 4 + (v >> 2);
+            Y[it][v] += rl != 2 * (mr & (int)(yi >= thr)) + rx4[v & 3] ? NEG : 0.f;
           }
       }
 #pragma unroll
@@ -353,15 +401,16 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
           Y[it][v] = pr;
           E[it][v] = pr * (E[it][v] - st.z);                                                                // dS
         }
-      for (int ct = ct_lo; ct <= ct_hi; ++ct) {
-        const int col = ct * 32 + r;
+      for (int ci = 0; ci < (HEADCOL ? 1 : ct_hi - ct_lo + 1); ++ci) {
+        const int col0 = HEADCOL ? c_lo : (ct_lo + ci) * 32;
+        const int col = col0 + r;
         const bool colin = col >= c_lo && col < c_hi;
         const float kfix = BF ? LN2 : 1.0f;
         {
           f32x16 av;
 #pragma unroll
           for (int v = 0; v < 16; ++v) av[v] = 0.f;
-          acc_xt_b<T>(av, Y, Os, ldt, ct, colin, lane);   // dV_h = P^T dO_h
+          acc_xt_b<T>(av, Y, Os, ldt, col0, colin, lane);   // dV_h = P^T dO_h
           if (colin) {
 #pragma unroll
             for (int v = 0; v < 16; ++v)
@@ -372,7 +421,7 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
           f32x16 ak;
 #pragma unroll
           for (int v = 0; v < 16; ++v) ak[v] = 0.f;
-          acc_xt_b<T>(ak, E, Qs, ldt, ct, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
+          acc_xt_b<T>(ak, E, Qs, ldt, col0, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
           if (colin) {
 #pragma unroll
             for (int v = 0; v < 16; ++v)
@@ -382,13 +431,19 @@ __global__ void __launch_bounds__(NTHREADS) wattn_bwd_mfma_kernel(const WbArgs<T
       }
     }
   }
-  {
+#pragma unroll
+  for (int ui = 0; ui < NU; ++ui) {
+    if (NU > 1 && wv + NWAVES * ui >= NUNITS) break;
+    const int xl = r & 7;
+    RDST_WB_UNIT(ui)
+    (void)c_hi; (void)t_lo; (void)t_hi; (void)ct_lo; (void)ct_hi; (void)fyl; (void)fxl;
     float* dtb = dtabL + hd * 15 * TS + (yl + 7) * TS + (xl + 7) - 4 * h;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) atomicAdd(&dtb[-((kt * 4 + (v >> 2)) * TS + (v & 3))], Dsum[kt][v]);
+      for (int v = 0; v < 16; ++v) atomicAdd(&dtb[-((kt * 4 + (v >> 2)) * TS + (v & 3))], Dsum[ui][kt][v]);
   }
+#undef RDST_WB_UNIT
   __syncthreads();
   float* my = p.slab + (int64_t)blockIdx.x * HEADS * 225;
   for (int i = tid; i < HEADS * 225; i += NTHREADS) {
@@ -423,8 +478,7 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
     if (sec % gs == 0 && ok(qkv, ld) && ok(dout, ldd) && ok(dqkv, ldq)) { gran = gs; break; }
   }
   if (!gran) return RDST_ENOTSUP;
-  int ldt = ((sec + 31) / 32) * 32;
-  if ((ldt / 16) % 2 == 0) ldt += 16;
+  const int ldt = wb_ldt<T>(g.C);
   p.ldt = ldt;
   const size_t smem = (size_t)4 * 64 * ldt + (size_t)2 * HEADS * 15 * TS * 4 + (size_t)HEADS * 64 * 16;
   if (smem > 160 * 1024) return RDST_ENOTSUP;
@@ -435,17 +489,27 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
   *nslab = (int)grid;
   const int per_row = 3 * sec / gran;
   const int iters = (per_row + 63) / 64;
-#define RDST_WB_LAUNCH(GR, IT)                                                                                       \
+  constexpr int NWV = sizeof(T) == 4 ? 8 : NUNITS;
+#define RDST_WB_LAUNCH(GR, IT, CT)                                                                                   \
   {                                                                                                                  \
-    auto kern = wattn_bwd_mfma_kernel<T, GR, IT>;                                                                    \
+    auto kern = wattn_bwd_mfma_kernel<T, GR, IT, NWV, CT>;                                                                 \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), smem, st, p);                                     \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWV), smem, st, p);                                        \
   }
-  if (gran == 16 && iters == 1) RDST_WB_LAUNCH(16, 1)
-  else if (gran == 16 && iters == 2) RDST_WB_LAUNCH(16, 2)   // fp32, C = 120: 90 chunks of 16 B per qkv row
-  else if (gran == 8 && iters == 1) RDST_WB_LAUNCH(8, 1)
-  else if (gran == 8 && iters <= 3) RDST_WB_LAUNCH(8, 3)
-  else if (gran == 4 && iters <= 3) RDST_WB_LAUNCH(4, 3)
+  bool done = false;
+  if constexpr (sizeof(T) == 4) {   // the fp32 parity mode's three widths, channel count at compile time
+    done = true;
+    if (g.C == 60 && gran == 16) RDST_WB_LAUNCH(16, 1, 60)
+    else if (g.C == 90 && gran == 8) RDST_WB_LAUNCH(8, 3, 90)
+    else if (g.C == 120 && gran == 16) RDST_WB_LAUNCH(16, 2, 120)
+    else done = false;
+  }
+  if (done) {}
+  else if (gran == 16 && iters == 1) RDST_WB_LAUNCH(16, 1, 0)
+  else if (gran == 16 && iters == 2) RDST_WB_LAUNCH(16, 2, 0)
+  else if (gran == 8 && iters == 1) RDST_WB_LAUNCH(8, 1, 0)
+  else if (gran == 8 && iters <= 3) RDST_WB_LAUNCH(8, 3, 0)
+  else if (gran == 4 && iters <= 3) RDST_WB_LAUNCH(4, 3, 0)
   else return RDST_ENOTSUP;
 #undef RDST_WB_LAUNCH
   return rdst_launch_status("wattn_bwd_mfma");
