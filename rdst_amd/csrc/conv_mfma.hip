@@ -240,14 +240,15 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
     __syncthreads();
     if (RDST_DBGV(p.dbg) & 16) {
     } else if (MODE == CMODE_FWD) {
-      // Wc[co][ci][tap]: rows co = n0 .. n0+nc-1 are one contiguous block of nc * Cin * 9 floats
-      stage_scatter<T>(p.Wc + (int64_t)n0 * g.Cin * 9, nc, g.Cin * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int n, int j) {
+      // Wc[co][ci][tap]: rows co = n0 .. n0+nc-1, CA * 9 floats of each (CA < Cin: a launch over a slice of the input
+      // channels, p.Wc then points at the slice's first channel)
+      stage_scatter<T>(p.Wc + (int64_t)n0 * g.Cin * 9, nc, p.CA * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int n, int j) {
         const int ci = j / 9, tap = j - ci * 9;
         return tap * tapst + n * p.ldw + ci * (int)sizeof(T);
       });
     } else {
       // dgrad: contraction over co, output column = ci, mirrored tap: per co the segment ci = n0 .. n0+nc-1
-      stage_scatter<T>(p.Wc + (int64_t)n0 * 9, g.Cout, nc * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int co, int j) {
+      stage_scatter<T>(p.Wc + (int64_t)n0 * 9, p.CA, nc * 9, (int64_t)g.Cin * 9, tid, 512, smem, [&](int co, int j) {
         const int n = j / 9, tap = j - n * 9;
         return (8 - tap) * tapst + n * p.ldw + co * (int)sizeof(T);
       });
@@ -1016,10 +1017,22 @@ template <typename T>
 int conv_fwd_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const T* R, int64_t ldr,
                   T* Y, int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
   if (mfma_disabled() || !rows_ok<T>(X, ldx) || g.Cin < 8) return RDST_ENOTSUP;
-  ConvArgs<T> p{};
-  p.A = X; p.lda = ldx; p.CA = g.Cin; p.Wc = Wc; p.bias = bias; p.R = R; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
-  p.in_act = in_act; p.g = g; p.Nout = g.Cout; p.s = s;
-  return launch_conv<T, CMODE_FWD>(p, st, "conv_fwd_mfma");
+  // fp32: the weights of all taps stay in LDS and a wave holds the contracted channels of its pixels as <= 16 k-steps of 8:
+  // more than 128 input channels (the 150 -> 60 fusion conv of an RDSTB) run as launches over equal slices of the input
+  // channels, every launch after the first adding to the output in place (its residual operand)
+  const int nsl = sizeof(T) == 4 ? (g.Cin + 127) / 128 : 1;
+  if (nsl > 1 && (g.Cin % nsl != 0 || g.r != 1)) return RDST_ENOTSUP;
+  const int cs = g.Cin / nsl;
+  for (int i = 0; i < nsl; ++i) {
+    ConvArgs<T> p{};
+    p.A = X + i * cs; p.lda = ldx; p.CA = cs; p.Wc = Wc + (int64_t)i * cs * g.ks * g.ks;
+    p.bias = i == 0 ? bias : nullptr; p.R = i == 0 ? R : Y; p.ldr = i == 0 ? ldr : ldy; p.Y = Y; p.ldy = ldy;
+    p.in_act = in_act; p.g = g; p.Nout = g.Cout; p.s = s;
+    const int rc = launch_conv<T, CMODE_FWD>(p, st, "conv_fwd_mfma");
+    if (rc == RDST_ENOTSUP && i > 0) return rdst_fail(RDST_EINVAL, "conv_fwd_mfma: slice %d of %d declined after slice 0 ran", i, nsl);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 size_t conv_mfma_scratch_bytes(const ConvGeom& g) {
@@ -1053,10 +1066,21 @@ int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const 
                     int64_t lddx, const T* acc, int64_t ldacc, const ConvGeom& g, float s, hipStream_t st) {
   // dYp must already be plain rows (B*H*W, Cout)
   if (mfma_disabled() || !rows_ok<T>(dYp, lddyp) || g.Cout < 8) return RDST_ENOTSUP;
-  ConvArgs<T> p{};
-  p.A = dYp; p.lda = lddyp; p.CA = g.Cout; p.Wc = Wc; p.Y = dX; p.ldy = lddx; p.Xa = X; p.ldxa = ldx;
-  p.in_act = in_act; p.Acc = acc; p.ldacc = ldacc; p.g = g; p.Nout = g.Cin; p.s = s;
-  return launch_conv<T, CMODE_DGRAD>(p, st, "conv_dgrad_mfma");
+  // fp32, more than 128 output channels (the 60 -> 240 convs of the upsampler): launches over slices of the output
+  // channels, the gradient is linear in dY; every launch after the first accumulates onto dX in place
+  const int nsl = sizeof(T) == 4 ? (g.Cout + 127) / 128 : 1;
+  if (nsl > 1 && g.Cout % nsl != 0) return RDST_ENOTSUP;
+  const int cs = g.Cout / nsl;
+  for (int i = 0; i < nsl; ++i) {
+    ConvArgs<T> p{};
+    p.A = dYp + i * cs; p.lda = lddyp; p.CA = cs; p.Wc = Wc + (int64_t)i * cs * g.Cin * g.ks * g.ks;
+    p.Y = dX; p.ldy = lddx; p.Xa = X; p.ldxa = ldx;
+    p.in_act = in_act; p.Acc = i == 0 ? acc : dX; p.ldacc = i == 0 ? ldacc : lddx; p.g = g; p.Nout = g.Cin; p.s = s;
+    const int rc = launch_conv<T, CMODE_DGRAD>(p, st, "conv_dgrad_mfma");
+    if (rc == RDST_ENOTSUP && i > 0) return rdst_fail(RDST_EINVAL, "conv_dgrad_mfma: slice %d of %d declined after slice 0 ran", i, nsl);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 template <typename T>
