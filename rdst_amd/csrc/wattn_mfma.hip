@@ -53,8 +53,14 @@ template <> struct Chunk<4> { typedef uint32_t type; };
 // lands in the Q/K/V sections) is window independent, so it is computed once with the integer
 // divisions it needs and kept in registers; the NEXT window's rows are loaded into registers while
 // the current window is being computed (HBM latency hides behind the MFMA/softmax work).
-template <typename T, int GRAN, int ITERS>
-__global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_kernel(const WaArgs<T> p) {
+// NW waves: wave w owns query tile w & 1 and the heads (w >> 1), + NW / 2, ...  NW = 4 with up to three workgroups per
+// CU; NW = 8 where only one workgroup fits the LDS (fp32, C = 90 / 120: four waves were ONE wave per SIMD, every LDS
+// and matrix-core latency exposed).
+template <typename T, int GRAN, int ITERS, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 1) wattn_fwd_mfma_kernel(const WaArgs<T> p) {
+  constexpr int NT = 64 * NW;      // threads
+  constexpr int RW = 64 / NW;      // token rows a wave stages and copies out
+  constexpr bool HEADCOL = sizeof(T) == 4;   // fp32: the 32-column window of P.V starts at the head's first channel
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using MM = Mma<T>;
   using CH = typename Chunk<GRAN>::type;
@@ -74,14 +80,14 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
   const int nW = g.nWh * g.nWw;
   const int nwin = g.B * nW;
 
-  for (int i = tid; i < heads * 15 * 15; i += 256) {
+  for (int i = tid; i < heads * 15 * 15; i += NT) {
     const int hd = i / 225, rem = i - hd * 225;
     const int dy = rem / 15, dx = rem - dy * 15;
     tabL[(hd * 15 + dy) * TS + dx] = p.table[rem * heads + hd] * tabscale;
   }
   {  // zero the pad columns [C*elt, ldt) of every section once: padded k-steps must read zeros
     const int padw = (ldt - C * (int)sizeof(T)) / 4;
-    for (int idx = tid; idx < 3 * 64 * padw; idx += 256) {
+    for (int idx = tid; idx < 3 * 64 * padw; idx += NT) {
       const int row = idx / padw, w = idx - row * padw;
       *reinterpret_cast<uint32_t*>(Qs + (size_t)row * ldt + C * sizeof(T) + 4 * w) = 0u;
     }
@@ -106,21 +112,22 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
     // token rows of this wave: window rows y = 2*wv, 2*wv+1 (8 tokens each).  Row index of token (y, x):
     // rowbase(y) + col(x), col(x) = c0 + x (- W when it wraps: only the last window column of a shifted block)
     const int c0 = wc * 8 + g.shift;
-    int64_t rbase[2];
+    constexpr int NY = RW / 8;   // window rows of this wave's tokens
+    int64_t rbase[NY];
 #pragma unroll
-    for (int yy = 0; yy < 2; ++yy) {
-      int rr = wr * 8 + wv * 2 + yy + g.shift;
+    for (int yy = 0; yy < NY; ++yy) {
+      int rr = wr * 8 + wv * NY + yy + g.shift;
       if (rr >= g.H) rr -= g.H;
       rbase[yy] = ((int64_t)b * g.H + rr) * g.W;
     }
-    constexpr int NPART = ITERS >= 3 ? 4 : 2;   // stage the wave's 16 token rows in parts to bound the staging registers
-    constexpr int RPP = 16 / NPART;
+    constexpr int NPART = ITERS >= 3 ? 4 : 2;   // stage the wave's token rows in parts to bound the staging registers
+    constexpr int RPP = RW / NPART;
 #pragma unroll
     for (int part = 0; part < NPART; ++part) {
       CH regs[RPP][ITERS];
 #pragma unroll
       for (int i = 0; i < RPP; ++i) {
-        const int ri = part * RPP + i;          // 0..15 within the wave
+        const int ri = part * RPP + i;          // 0..RW-1 within the wave
         int col = c0 + (ri & 7);
         if (col >= g.W) col -= g.W;
         const int64_t tok = (RDST_DBGV(p.dbg) & 2) ? 0 : rbase[ri >> 3] + col;
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
       if (part == 0) __syncthreads();  // previous window's O has been copied out; the tile may be overwritten
 #pragma unroll
       for (int i = 0; i < RPP; ++i) {
-        const int row = wv * 16 + part * RPP + i;
+        const int row = wv * RW + part * RPP + i;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           const int c = lane + 64 * it;
@@ -162,7 +169,7 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
 
     const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
-    for (int hd = hg; hd < ((RDST_DBGV(p.dbg) & 1) ? 0 : heads); hd += 2) {
+    for (int hd = hg; hd < ((RDST_DBGV(p.dbg) & 1) ? 0 : heads); hd += NW / 2) {
       const int c_lo = hd * d, c_hi = c_lo + d;
       const int t_lo = c_lo / KP, t_hi = (c_hi - 1) / KP;
       f32x16 X[2];
@@ -236,11 +243,12 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
 
       // O_h = P V_h over the column tiles that overlap the head
       const int ct_lo = c_lo / 32, ct_hi = (c_hi - 1) / 32;
-      for (int ct = ct_lo; ct <= ct_hi; ++ct) {
+      for (int ci = 0; ci < (HEADCOL ? 1 : ct_hi - ct_lo + 1); ++ci) {
+        const int ct = ct_lo + ci;
         f32x16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const int col = ct * 32 + r;
+        const int col = (HEADCOL ? c_lo : ct * 32) + r;
         const bool colin = col >= c_lo && col < c_hi;
         const uint32_t cmask = colin ? 0xffffffffu : 0u;
         if constexpr (BF) {
@@ -288,12 +296,12 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) wattn_fwd_mfma_ke
     // LDS (Q section now holds O) -> global rows: wave w copies rows w, w+4, ...; no divisions
     if (!(RDST_DBGV(p.dbg) & 4)) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < RW; ++i) {
         int col = c0 + (i & 7);
         if (col >= g.W) col -= g.W;
         const int64_t tok = rbase[i >> 3] + col;
         char* dst = reinterpret_cast<char*>(p.out + tok * p.ldo);
-        const char* src = Qs + (size_t)(wv * 16 + i) * ldt;
+        const char* src = Qs + (size_t)(wv * RW + i) * ldt;
         if (lane < cps) *reinterpret_cast<CH*>(dst + (size_t)lane * GRAN) = *reinterpret_cast<const CH*>(src + (size_t)lane * GRAN);
       }
     }
@@ -340,11 +348,15 @@ int launch_fwd(const T* qkv, int64_t ld, const float* table, T* out, int64_t ldo
   if (wg_per_cu < 1) wg_per_cu = 1;
   int64_t grid = 256 * wg_per_cu;
   if (grid > nwin) grid = nwin;
+#define RDST_WA_LAUNCH1(GR, KM, NWV)                                                                                  \
+  {                                                                                                                  \
+    auto kern = wattn_fwd_mfma_kernel<T, GR, KM, NWV>;                                                               \
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWV), smem, st, p);                                     \
+  }
 #define RDST_WA_LAUNCH(GR, KM)                                                                                        \
   {                                                                                                                  \
-    auto kern = wattn_fwd_mfma_kernel<T, GR, KM>;                                                                    \
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, p);                                          \
+    if (sizeof(T) == 4 && wg_per_cu == 1) RDST_WA_LAUNCH1(GR, KM, 8) else RDST_WA_LAUNCH1(GR, KM, 4)                 \
   }
   if (p.gran == 16 && iters == 1) RDST_WA_LAUNCH(16, 1)
   else if (p.gran == 16 && iters == 2) RDST_WA_LAUNCH(16, 2)
@@ -353,6 +365,7 @@ int launch_fwd(const T* qkv, int64_t ld, const float* table, T* out, int64_t ldo
   else if (p.gran == 4 && iters <= 3) RDST_WA_LAUNCH(4, 3)
   else return RDST_ENOTSUP;
 #undef RDST_WA_LAUNCH
+#undef RDST_WA_LAUNCH1
   return rdst_launch_status("wattn_fwd_mfma");
 }
 
