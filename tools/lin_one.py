@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rdst_amd import ops
-dev = torch.device("cuda:0"); M = 131072; dt = torch.bfloat16
+dev = torch.device("cuda:0"); M = 131072; dt = torch.float32 if os.environ.get("LIN_F32") else torch.bfloat16
 K, N = int(sys.argv[1]), int(sys.argv[2]); ln = int(sys.argv[3])
 x = torch.randn(M, K, device=dev).to(dt)
 w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.zeros(N, device=dev)
