@@ -313,8 +313,8 @@ int launch_fwd16(const W16Args& p, hipStream_t st) {
 // Backward.  One 8-wave workgroup per (window, head pair), all of Q / K / V / dO of the pair in LDS, two passes:
 //   pass 1 (wave = query tile, the forward's orientation: keys in the accumulator registers): S^T -> P^T (normalised,
 //     128 registers), dP^T = V.dO^T per key tile, delta = rowsum(P.dP), dS^T = P^T.(dP^T - delta) -> dQ^T += K^T.dS^T
-//     and d(table) (LDS float adds into the reversed layout of the bias table); (-scale2.max, 1/l, delta) per query go
-//     to LDS for pass 2; dP^T is formed twice (1-2 MFMAs per tile) instead of being kept (128 more registers);
+//     and d(table) (LDS float adds into the reversed layout of the bias table); (-scale2.max - log2 l, -delta) per query
+//     go to LDS for pass 2 (the exponent offset that makes exp2 return P itself, the initial accumulator of dP); dP^T is formed twice (1-2 MFMAs per tile) instead of being kept (128 more registers);
 //   pass 2 (wave = key tile, queries in the accumulator registers, keys on the lanes): S, P, dP, dS recomputed tile by
 //     tile from the saved row statistics, dV^T += dO^T.P and dK^T += Q^T.dS accumulate in registers over the 8 query
 //     tiles (the tiles ARE the B operands; Q / dO are read transposed).
@@ -332,7 +332,7 @@ struct W16B {
   static constexpr int SEC = CF::SEC;
   static constexpr int OFF_TABR = 4 * SEC + 64;                       // reversed table (pass 1): [head][copy][31][32]
   static constexpr int OFF_TABN = OFF_TABR + 2 * 2 * CF::TABF * 4;    // natural table (pass 2)
-  static constexpr int OFF_STAT = OFF_TABN + 2 * 2 * CF::TABF * 4;    // [head][nm | inv | delta][256]
+  static constexpr int OFF_STAT = OFF_TABN + 2 * 2 * CF::TABF * 4;    // [head][nm - log2 l | -delta | (unused)][256]
   static constexpr int OFF_PART = OFF_STAT + 2 * 3 * 256 * 4;         // d(table) row sums of one head: [yi 16][yj 16][32]
   static constexpr size_t SMEM = (size_t)OFF_PART + 16 * 16 * 32 * 4;
 };
@@ -407,9 +407,9 @@ __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
       dob[t - t_lo].w[e] &= h ? mB : mA;
     }
   }
-  auto dp_tile = [&](int kt, f32x16& dp) {
+  auto dp_tile = [&](int kt, f32x16& dp, float init) {
 #pragma unroll
-    for (int v = 0; v < 16; ++v) dp[v] = 0.f;
+    for (int v = 0; v < 16; ++v) dp[v] = init;
 #pragma unroll
     for (int t = t_lo; t <= t_hi; ++t) Mma<bf16>::mma(dp, lds_pack(c.Vrow + kt * 32 * ldt + t * 32), dob[t - t_lo]);
   };
@@ -417,7 +417,7 @@ __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
     f32x16 dp;
-    dp_tile(kt, dp);
+    dp_tile(kt, dp, 0.f);
 #pragma unroll
     for (int v = 0; v < 16; v += 2) {
       d0 = __builtin_fmaf(X[kt][v], dp[v], d0);
@@ -427,22 +427,21 @@ __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
   const float delta = half_swap_sum(d0 + d1);
   if (h == 0) {
     LDS_AS float* st = c.stat + HL * 3 * 256 + c.sc.qt * 32 + c.sc.r;
-    st[0] = nm;
-    st[256] = inv;
-    st[512] = delta;
+    st[0] = nm + __builtin_amdgcn_logf(inv);   // pass 2: P = exp2(scale2 . S + this) — the 1 / l folded into the exponent
+    st[256] = -delta;                          // pass 2: the initial accumulator of dP, so that dS = P . acc
   }
 #pragma unroll
   for (int v = 0; v < 16; ++v) dq[v] = 0.f;
 #pragma unroll
   for (int kt = 0; kt < 8; ++kt) {
     f32x16 dp;
-    dp_tile(kt, dp);
+    dp_tile(kt, dp, -delta);   // dP - delta: -delta is the initial accumulator
     // register v: key (yj = 2 kt + (v >> 3), xj = XL + 4 h) with XL = 8 ((v >> 2) & 1) + (v & 3); column c' = xi - XL + 15
     // of the key row's sums goes to lane c' of `lo` (c' < 16) / lane c' - 16 of `hi`; true column = c' - 4 h
     float lo[2] = {0.f, 0.f}, hi[2] = {0.f, 0.f};
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-      const float ds = X[kt][v] * (dp[v] - delta);
+      const float ds = X[kt][v] * dp[v];
       dp[v] = ds;
       const int yl = v >> 3;
       switch (8 * ((v >> 2) & 1) + (v & 3)) {
@@ -526,8 +525,12 @@ __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
       const f32x2 b2 = tbh[((2 * qt + (v >> 3)) * CF::TROW + 8 * ((v >> 2) & 1) + (v & 3)) / 2];
       X[v] = b2.x;
       X[v + 1] = b2.y;
-      dp[v] = 0.f;
-      dp[v + 1] = 0.f;
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {   // dP starts at -delta of its query row
+      const f32x4v nd = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (256 + qt * 32 + 8 * g4) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dp[4 * g4 + e] = nd[e];
     }
 #pragma unroll
     for (int t = t_lo; t <= t_hi; ++t) {
@@ -543,14 +546,12 @@ __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4v nm = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (qt * 32 + 8 * g4) * 4);
-      const f32x4v iv = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (256 + qt * 32 + 8 * g4) * 4);
-      const f32x4v de = *reinterpret_cast<const LDS_AS f32x4v*>(stb + (512 + qt * 32 + 8 * g4) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int v = 4 * g4 + e;
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(X[v], c.sc.scale2, nm[e])) * iv[e];
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(X[v], c.sc.scale2, nm[e]));
         P[v] = pv;
-        S[v] = pv * (dp[v] - de[e]);
+        S[v] = pv * dp[v];
       }
     }
 #pragma unroll
