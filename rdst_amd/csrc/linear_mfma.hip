@@ -228,7 +228,9 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
         for (int u = 0; u < U; ++u) {
           const int idx = base + 512 * u;
           const int n = idx >> shp, ph = idx & ((1 << shp) - 1);
-          if (idx < total && ph < 2 * Tn) {
+          // (a chunk that is not a whole number of column tiles is the "tight" single chunk of launch_lin: the rows past
+          // it lie over gamma / beta / bias and the staging tiles and must not be written)
+          if (idx < total && ph < 2 * Tn && (n < nc || (p.nch & 31) == 0)) {
             float f[HP];
 #pragma unroll
             for (int q = 0; q < HP / 4; ++q) {
@@ -706,6 +708,14 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   int nch = ((112 * 1024) / p.ldw) / 32 * 32;  // weights resident in LDS (+ staging, gamma/beta/bias) under 160 KB
   if (nch < 32) return RDST_ENOTSUP;
   if (nch > npad) nch = npad;
+  if (MODE == MODE_FWD && nch < npad) {
+    // One chunk after all if the Nout rows themselves fit: the rows Nout .. npad-1 of the last column tile then lie over
+    // gamma / beta / bias and the staging tiles (not staged; read as garbage by the MFMAs:
+    // they only feed output columns >= Nout, which are never stored).  A second chunk re-reads, re-normalises and
+    // re-activates every slab (fp32 fc2 at C = 120, 240 x 120 weights: chunks of 96 + 24 columns, 288 -> 1xx us).
+    const size_t need = (size_t)p.Nout * p.ldw + (size_t)(2 * p.Tn * MM::KP + npad) * sizeof(float) + 16 + abuf_bytes;
+    if (need <= 160 * 1024 && (size_t)npad * p.ldw <= need) nch = p.Nout;
+  }
   p.nch = nch;
   if (p.Tn * MM::KP > 512 || npad > 512) return RDST_ENOTSUP;   // one parameter value per thread in the prologue
   p.aoff = (int)(((size_t)nch * p.ldw + (size_t)(2 * p.Tn * MM::KP + npad) * sizeof(float) + 15) / 16 * 16);

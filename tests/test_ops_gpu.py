@@ -31,6 +31,9 @@ LIN = [  # M, K, N, ln, act, residual, scale
     (160, 90, 270, True, 0, False, 1.0),     # norm1 + qkv at C = 90 (one-pass backward, 9 waves)
     (130, 48, 48, True, 0, True, 0.9),       # LayerNorm only (no weight), scale + residual
     (64, 33, 17, False, 2, False, 1.0),      # odd sizes, LeakyReLU input
+    (384, 90, 270, True, 0, False, 1.0),     # fp32: the weights fit the LDS only as ONE chunk that ends inside a column tile (launch_lin)
+    (320, 240, 120, False, 1, True, 1.0),    # GELU + fc2 at C = 120 (fp32: the same single tight chunk), + residual
+    (416, 120, 240, True, 0, False, 1.0),    # norm2 + fc1 at C = 120 (fp32: tight chunk that is a whole number of tiles)
 ]
 
 
