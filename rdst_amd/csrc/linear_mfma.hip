@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
     } else {
       // dgrad: output column n = K_lin index, contraction k = N_lin index: W (N_lin, K_lin) read row-wise
       // (coalesced), scattered transposed into the LDS image [n][k]
-      lds_zero16(Ws, ncp * p.ldw, tid, 512);
+      lds_zero16(Ws, ((p.nch & 31) ? nc : ncp) * p.ldw, tid, 512);   // (a tight chunk ends with its last row: see launch_lin)
       __syncthreads();
       stage_scatter<T>(p.Wt + n0, p.Kc, nc, (int64_t)p.wK, tid, 512, Ws, [&](int k, int n) { return n * p.ldw + k * (int)sizeof(T); });
     }
@@ -708,7 +708,7 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
   int nch = ((112 * 1024) / p.ldw) / 32 * 32;  // weights resident in LDS (+ staging, gamma/beta/bias) under 160 KB
   if (nch < 32) return RDST_ENOTSUP;
   if (nch > npad) nch = npad;
-  if (MODE == MODE_FWD && nch < npad) {
+  if (nch < npad) {
     // One chunk after all if the Nout rows themselves fit: the rows Nout .. npad-1 of the last column tile then lie over
     // gamma / beta / bias and the staging tiles (not staged; read as garbage by the MFMAs:
     // they only feed output columns >= Nout, which are never stored).  A second chunk re-reads, re-normalises and
