@@ -11,4 +11,11 @@ rr = torch.randn(M, N, device=dev).to(dt) if res else None
 with torch.no_grad():
     for i in range(6):
         ops.ln_linear(x, lw, lb, w, b, in_act=act, residual=rr)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(6):
+        ops.ln_linear(x, lw, lb, w, b, in_act=act, residual=rr)
+    e1.record()
 torch.cuda.synchronize()
+print(f"K={K} N={N} ln={ln} act={act} res={res}: {1e3 * e0.elapsed_time(e1) / 6:7.1f} us per call", flush=True)
