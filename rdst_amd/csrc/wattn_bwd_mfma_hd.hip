@@ -396,10 +396,24 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
       case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; \
     }
 #define RDST_BW_A(HD) bw_phase_a<D, HEADS, HD>(c, pP, pdS, dq, Dsum)
+#ifndef K2_ABL
+#define K2_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no phase A, 2 no phase B, 4 no P / dS images, 8 no copy-out
+#endif
+#if K2_ABL & 1
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pP[a][b2].w[e] = 0u; pdS[a][b2].w[e] = 0u; }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dq[v] = 0.f;
+#else
     RDST_BW_HEADS(RDST_BW_A)
+#endif
     __syncthreads();  // b2: nobody reads K / V any more: the P / dS images may overlay them
     stamp();  // 2 + 6k: phase A done
-    bw_store_p<D, HEADS>(c, pP, pdS);
+    if (!(K2_ABL & 4)) bw_store_p<D, HEADS>(c, pP, pdS);
     // The next window's rows are fetched as early as the registers allow: in flight during phase B, the gradient
     // stores and the copy-out (never across phase A, the register-hungry one: a spilled prefetch register makes the
     // wave WAIT for its load).  Measured cold, per launch: D = 10: 76.5 -> 73.1 us, D = 20: 88.3 -> 81.6 us; D = 15
@@ -413,7 +427,12 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     __syncthreads();  // b3
     stamp();  // 3 + 6k: P/dS stored
 #define RDST_BW_B(HD) bw_phase_b<D, HEADS, HD>(c, dv, dk)
+#if K2_ABL & 2
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { dv[v] = 0.f; dk[v] = 0.f; }
+#else
     RDST_BW_HEADS(RDST_BW_B)
+#endif
     __syncthreads();  // b4: Q, dOut, P, dS are dead: the gradient tiles go where Q / K / V were
     stamp();  // 4 + 6k: phase B done
     if constexpr (!EARLY_FETCH) {
@@ -437,7 +456,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
 #pragma unroll
     for (int k = 0; k < MAXR2; ++k) {
       const int ri = wv + NW2 * k;
-      if (ri < 64 && st_act) {
+      if (ri < 64 && st_act && !(K2_ABL & 8)) {
         const int64_t t = token(w, ri);
         char* dst = reinterpret_cast<char*>(p.dqkv + t * p.ldq) + (size_t)lane * GRAN;
         *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(my_lds + ri * ldt);
