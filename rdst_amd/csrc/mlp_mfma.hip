@@ -26,6 +26,14 @@
 #include "wattn_hd.h"
 #include <stdlib.h>
 
+// ablation bits of the fused Mlp backward (1 no GELU-table reads, 2 no phase-1 MFMAs, 4 no phase 2, 8 no phase-3 MFMAs):
+// from MlpArgs.dbg in a debug build, or fixed at compile time in a release build (-DMLP_ABL=n through tools/abl_build.sh)
+#ifdef MLP_ABL
+#define MLP_DBG(p) (MLP_ABL)
+#else
+#define MLP_DBG(p) RDST_DBGV((p).dbg)
+#endif
+
 namespace {
 using namespace wahd;
 using MM = Mma<bf16>;
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       const float bj = b1s[j];
 #pragma unroll
       for (int v = 0; v < 16; ++v) { ah[v] = bj; ad[v] = 0.f; }
-      if (!(RDST_DBGV(p.dbg) & 2))
+      if (!(MLP_DBG(p) & 2))
 #pragma unroll
       for (int t = 0; t < CF::KC; ++t) {
         const Pack16 xa = lds_pack(xrow + 32 * t), wb = lds_pack(wrow + 32 * t), ya = lds_pack(yrow + 32 * t);
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
           for (int k = 0; k < LB; ++k) {
             uint32_t off;
             fr[k] = gelu_tab_index(ah[8 * s + b + k], off);
-            if (RDST_DBGV(p.dbg) & 1) { en[k].x = off; en[k].y = off + 1; }
+            if (MLP_DBG(p) & 1) { en[k].x = off; en[k].y = off + 1; }
             else en[k] = *reinterpret_cast<const LDS_AS u32x2_t*>(gtab + off);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +383,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     __syncthreads();   // B2: dHp image complete
     stamp();   // 3: phase 1 done
     // ---- phase 2: weight gradients (contraction over the tile's 32 tokens, 2 k-steps)
-    if (!(RDST_DBGV(p.dbg) & 4))
+    if (!(MLP_DBG(p) & 4))
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -392,7 +400,7 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       f32x16 dx2;   // two independent accumulation chains: only one wave per SIMD is in this phase
 #pragma unroll
       for (int v = 0; v < 16; ++v) { dx[v] = 0.f; dx2[v] = 0.f; }
-      if (!(RDST_DBGV(p.dbg) & 8))
+      if (!(MLP_DBG(p) & 8))
 #pragma unroll
       for (int kk = 0; kk < CF::KJ; kk += 2) {
         const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
