@@ -13,6 +13,10 @@
 #include "linear.h"
 #include "mfma.h"
 
+#ifndef M3_ABL
+#define M3_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no GELU, 2 no phase-1 MFMAs, 4 no phase-2 MFMAs, 8 no stores
+#endif
+
 namespace {
 
 constexpr int M3_TT = 128;
@@ -234,7 +238,8 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
 #pragma unroll
             for (int d = 0; d < 4; ++d) bq.w[d] = (2 * d < (h ? c1 : c0)) ? bq.w[d] : 0u;
           }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1[jd][ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+          if (!(M3_ABL & 2)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1[jd][ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+          else acc[ks & 15] += __uint_as_float(bq.w[0]);
         }
         const float2 mr = *reinterpret_cast<const float2*>(st + tok * 2);
         const float rstd = mr.y, nrm = -mr.y * mr.x;
@@ -256,6 +261,7 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           uint32_t off;
+          if (M3_ABL & 1) { fr[v] = 0.f; en[v] = 0x3c003c00u; continue; }
           fr[v] = gelu_tab4_index(u[v], off);
           en[v] = *reinterpret_cast<const uint32_t*>(gtab + off);
         }
@@ -290,7 +296,8 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
 #pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
           const Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w2[jd][ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+          if (!(M3_ABL & 4)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w2[jd][ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+          else acc[ks & 15] += __uint_as_float(bq.w[0]);
         }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -304,7 +311,7 @@ __global__ void __launch_bounds__(64 * m3_nw(C), M3Cfg<C>::WGCU == 2 ? (2 * m3_n
           acc[4 * g4] += B4.x + bf16lo(rx); acc[4 * g4 + 1] += B4.y + bf16hi(rx);
           acc[4 * g4 + 2] += B4.z + bf16lo(ry); acc[4 * g4 + 3] += B4.w + bf16hi(ry);
         }
-        if (grow < p.M) {
+        if (grow < p.M && !(M3_ABL & 8)) {
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
             float c8[8];
