@@ -73,6 +73,38 @@ def test_wattn_bf16_2048_windows_vs_oracle(C, shift):
     assert per_win.max().item() <= 2 * TOL
 
 
+@pytest.mark.parametrize("C,shift", [(60, 4), (90, 0), (120, 4)])
+def test_wattn_fp32_2048_windows_vs_oracle(C, shift):
+    """The fp32 parity mode's K1 / K2 (wattn_mfma.hip, wattn_bwd_mfma.hip: eight waves, the backward with two (tile, head) units
+    on four of them, persistent over 8 windows per workgroup) at the bench size, per-window bounds: a unit or a window that is
+    skipped, done twice or read from the wrong rows cannot hide in the norm."""
+    from rdst_amd import ops
+    heads, ws = 6, 8
+    scale = (C // heads) ** -0.5
+    qkv = rand((B_FULL, HW, HW, 3 * C), 500 + C)
+    table = rand(((2 * ws - 1) ** 2, heads), 2, 0.5)
+    gout = rand((B_FULL, HW, HW, C), 3)
+
+    q_ref = qkv.clone().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout)
+
+    q = qkv.to(DEV).requires_grad_(True)
+    t = table.to(DEV).requires_grad_(True)
+    o = ops.window_attention(q, t, HW, HW, heads, ws, shift, scale)
+    o.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+    ro, rq, rt = _rel(o, o_ref.detach()), _rel(q.grad, q_ref.grad), _rel(t.grad, t_ref.grad)
+    print(f"\nwattn fp32 C={C} shift={shift}: rel L2 out {ro:.2e}  dqkv {rq:.2e}  dtable {rt:.2e}")
+    assert ro <= 2e-6 and rq <= 2e-6 and rt <= 3e-6     # fp32 arithmetic on both sides (measured 2e-7 .. 3e-7)
+    nw = HW // ws
+    for got, want, width in ((o, o_ref.detach(), C), (q.grad, q_ref.grad, 3 * C)):
+        d = (got.float().cpu() - want).view(B_FULL, nw, ws, nw, ws, width)
+        per_win = d.pow(2).sum(dim=(2, 4, 5)).sqrt() / want.view(B_FULL, nw, ws, nw, ws, width).pow(2).sum(dim=(2, 4, 5)).sqrt()
+        assert per_win.max().item() <= 5e-6
+
+
 @pytest.mark.parametrize("C,shift", [(60, 8), (90, 0), (120, 8)])
 def test_wattn16_bf16_bench_size_vs_oracle(C, shift):
     """Window 16 at the size of `bench.py --config ws16` (8 x 128 x 128 tokens = 512 windows = 1536 workgroups of
