@@ -281,6 +281,41 @@ def test_conv_bf16_full_size(B, H, W, Cin, Cout, res, scale, r):
     assert ey.max().item() <= 2 * TOL and ex.max().item() <= 2 * TOL
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,res,scale,r", [
+    (4, 64, 64, 150, 60, True, 0.7, 1),      # fusion conv: fp32 forward as two launches over halves of the input channels
+    (2, 64, 64, 60, 240, False, 1.0, 2),     # upsampler conv: fp32 data gradient as two launches over halves of dY's channels
+])
+def test_conv_fp32_channel_slices(B, H, W, Cin, Cout, res, scale, r):
+    """fp32 parity mode: a conv with more than 128 contracted channels runs on the matrix-core kernels as launches over equal
+    channel slices, each after the first accumulating in place (conv_mfma.hip: conv_fwd_mfma / conv_dgrad_mfma)."""
+    from rdst_amd import ops
+    x = rand((B, H, W, Cin), 1)
+    w = rand((Cout, Cin, 3, 3), 2, (Cin * 9) ** -0.5)
+    b = 0.1 * rand((Cout,), 3)
+    cy = Cout // (r * r)
+    rr_ = rand((B, H * r, W * r, cy), 4) if res else None
+    gy = rand((B, H * r, W * r, cy), 5)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    rres = rr_.clone().requires_grad_(True) if res else None
+    h = F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1)
+    if r > 1:
+        h = F.pixel_shuffle(h, r)
+    yr = h.permute(0, 2, 3, 1) * scale + (rres if res else 0)
+    yr.backward(gy)
+    xg = x.to(DEV).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rg = rr_.to(DEV).requires_grad_(True) if res else None
+    yg = ops.conv_rows(xg, wg, bg, residual=rg, out_scale=scale, shuffle=r)
+    yg.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    out = {"y": _rel(yg, yr.detach()), "dx": _rel(xg.grad, xr.grad), "dW": _rel(wg.grad, wr.grad), "db": _rel(bg.grad, br.grad)}
+    print(f"\nconv fp32 {Cin}->{Cout} r={r} {B}x{H}x{W}: " + "  ".join(f"{k} {v:.2e}" for k, v in out.items()))
+    assert all(v <= 5e-6 for v in out.values()), out
+    ey = (yg.float().cpu() - yr.detach()).reshape(B * H * r, -1).norm(dim=1) / yr.detach().reshape(B * H * r, -1).norm(dim=1)
+    ex = (xg.grad.float().cpu() - xr.grad).reshape(B * H, -1).norm(dim=1) / xr.grad.reshape(B * H, -1).norm(dim=1)
+    assert ey.max().item() <= 1e-5 and ex.max().item() <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # The network: RDST-E1 x4 (BASELINE.json configs[1] architecture), bf16, forward + L1 + backward vs the oracle
 # ------------------------------------------------------------------------------------------------------------------
