@@ -266,28 +266,38 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
   };
   stamp();  // 0
   BwCtx c;
+  // the lane-dependent LDS positions of the context, re-derived per window from an opaque copy of the thread index: built
+  // once in front of the window loop they are a dozen registers live across it, and at 168 registers per wave D = 15 / 20
+  // spilled four (none now: 163 / 168 / 161 registers) — which is what kept D = 15 from fetching the next window early
+  auto lane_ctx = [&](int tidx) {
+    const int lane = tidx & 63, r = lane & 31, h = lane >> 5;
+    const int yi = tl * 4 + (r >> 3), xi = r & 7;
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int tok = tl * 32 + r;
   c.h = h;
-  c.rowT = (lds_cp)(smem + CF::OFF_Q + tok * ldt);
-  c.rowK = (lds_cp)(smem + CF::OFF_K + r * ldt + h * 16);
-  c.trK = (lds_cp)(smem + CF::OFF_K + (4 * h + q) * ldt + (16 * (gq & 1) + 4 * pp) * 2);
-  c.trQ = (lds_cp)(smem + CF::OFF_Q + (8 * h + q) * ldt + (16 * (gq & 1) + 4 * pp) * 2);
-  {
-    const int pbase = CF::OFF_R + hd * 2 * CF::PMAT;
-    c.PWp = (lds_cp)(smem + ((pbase + tok * CF::PROW) ^ ((((r & 15) ^ h)) * 8)));
-    const int row0 = 8 * h + q, row1 = row0 + 4, chunk = tl * 8 + 4 * (gq & 1) + pp;
-    c.PRp0 = (lds_cp)(smem + ((pbase + row0 * CF::PROW) ^ ((chunk ^ (row0 & 15)) * 8)));
-    c.PRp1 = (lds_cp)(smem + ((pbase + row1 * CF::PROW) ^ ((chunk ^ (row1 & 15)) * 8)));
-  }
-  c.idp = (lds_cp)(smem + CF::OFF_ID + lane * 32);
-  {
-    const int u0 = 4 * h - xi + 7;
-    const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
-    c.tb = (const LDS_AS f32x2*)tb;
-  }
+    c.rowT = (lds_cp)(smem + CF::OFF_Q + tok * ldt);
+    c.rowK = (lds_cp)(smem + CF::OFF_K + r * ldt + h * 16);
+    c.trK = (lds_cp)(smem + CF::OFF_K + (4 * h + q) * ldt + (16 * (gq & 1) + 4 * pp) * 2);
+    c.trQ = (lds_cp)(smem + CF::OFF_Q + (8 * h + q) * ldt + (16 * (gq & 1) + 4 * pp) * 2);
+    {
+      const int pbase = CF::OFF_R + hd * 2 * CF::PMAT;
+      c.PWp = (lds_cp)(smem + ((pbase + tok * CF::PROW) ^ ((((r & 15) ^ h)) * 8)));
+      const int row0 = 8 * h + q, row1 = row0 + 4, chunk = tl * 8 + 4 * (gq & 1) + pp;
+      c.PRp0 = (lds_cp)(smem + ((pbase + row0 * CF::PROW) ^ ((chunk ^ (row0 & 15)) * 8)));
+      c.PRp1 = (lds_cp)(smem + ((pbase + row1 * CF::PROW) ^ ((chunk ^ (row1 & 15)) * 8)));
+    }
+    c.idp = (lds_cp)(smem + CF::OFF_ID + lane * 32);
+    {
+      const int u0 = 4 * h - xi + 7;
+      const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
+      c.tb = (const LDS_AS f32x2*)tb;
+    }
+    c.yi = yi;
+    c.xi = xi;
+  };
+  lane_ctx(tid);
   c.thr = thr;
   c.cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
-  c.yi = yi;
-  c.xi = xi;
   c.scale2 = p.scale * LOG2E;
   c.scale = p.scale;
   if (tid < 64) {  // 0/1 operand of the d(table) MFMA: A[m][8h + jj] = 1 where m is the key of pack element jj
@@ -384,6 +394,11 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     __syncthreads();  // b1
     stamp();  // 1 + 6k: staged
     const WinPos w = cur;
+    {
+      int tidw = tid;
+      asm volatile("" : "+v"(tidw));
+      lane_ctx(tidw);
+    }
     c.mrow = g.shift > 0 && w.wr == g.nWh - 1;
     c.mcol = g.shift > 0 && w.wc == g.nWw - 1;
     c.masked = __builtin_amdgcn_readfirstlane((int)(c.mrow || c.mcol)) != 0;
@@ -417,8 +432,8 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     // The next window's rows are fetched as early as the registers allow: in flight during phase B, the gradient
     // stores and the copy-out (never across phase A, the register-hungry one: a spilled prefetch register makes the
     // wave WAIT for its load).  Measured cold, per launch: D = 10: 76.5 -> 73.1 us, D = 20: 88.3 -> 81.6 us; D = 15
-    // (12-byte chunks, already spilling) gets 44 B of scratch that way and 80 -> 91 us: it keeps the late fetch.
-    constexpr bool EARLY_FETCH = D != 15;
+    // (12-byte chunks) spilled that way (80 -> 91 us) until the context was rebuilt per window: now 80.4 -> 78.0 us.
+    constexpr bool EARLY_FETCH = true;
     if constexpr (EARLY_FETCH) {
       const int nxt = win + gridDim.x;
       cur = locate(nxt < nwin ? nxt : win);
