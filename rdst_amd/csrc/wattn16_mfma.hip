@@ -694,13 +694,23 @@ __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
   }
   f32x16 dq0, dq1;
   float* slab_row = p.slab + ((int64_t)win * CF::HEADS + grp * 2) * 961;
+#ifndef W16_ABL
+#define W16_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no pass 1, 2 no pass 2, 4 no d(table) sums
+#endif
+#if W16_ABL & 1
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { dq0[v] = 0.f; dq1[v] = 0.f; }
+#else
   w16_bwd_p1<D, 0>(c, dq0);
+#endif
   __syncthreads();
-  w16_dtable_out<D>(part, slab_row, tid);
+  if (!(W16_ABL & 4)) w16_dtable_out<D>(part, slab_row, tid);
   __syncthreads();
+#if !(W16_ABL & 1)
   w16_bwd_p1<D, 1>(c, dq1);
+#endif
   __syncthreads();
-  w16_dtable_out<D>(part, slab_row + 961, tid);
+  if (!(W16_ABL & 4)) w16_dtable_out<D>(part, slab_row + 961, tid);
   {  // pass 2: wave = key tile wv
     c.kt = wv;
     c.QA = (lds_cp)(Qs + r * ldt + h * 16);
@@ -712,8 +722,10 @@ __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
     c.Kst = (lds_cp)(Ks + (wv * 32 + r) * ldt);
     c.Vst = (lds_cp)(Vs + (wv * 32 + r) * ldt);
     c.tb2 = (const LDS_AS f32x2*)((u0 & 1) ? tabN + CF::TABF + (u0 - 1) : tabN + u0);
+#if !(W16_ABL & 2)
     w16_bwd_p2<D, 0>(c);
     w16_bwd_p2<D, 1>(c);
+#endif
   }
   __syncthreads();   // every wave is done with Q as an operand: the wave's own query rows take dQ
   {
