@@ -214,6 +214,9 @@ int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_r, int has_
  * ops of a batch must be enqueued on `stream`.  Gradients are complete only after _end(). */
 int rdst_reduce_batch_begin(void);
 int rdst_reduce_batch_end(void* stream);
+/* Close an open batch WITHOUT running its queued reductions (a backward that failed half way: the slabs and the
+ * outputs the jobs name may already be freed).  No-op without an open batch.  (ABI 7) */
+int rdst_reduce_batch_abort(void);
 
 /* ---- layout helpers at the NCHW boundary of the module ------------------------------------------
  * nchw (B,C,H,W) fp32 <-> token rows (B*H*W, C) of `dtype`.  The caller-facing tensors of

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rdst_conv_fwd_packable": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rdst_reduce_batch_begin": (_i, []),
     "rdst_reduce_batch_end": (_i, [_p]),
+    "rdst_reduce_batch_abort": (_i, []),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "rdst_upsample2_fwd": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
@@ -71,7 +72,7 @@ SIGNATURES = {
     "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
-ABI_VERSION = 6             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
+ABI_VERSION = 7             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 

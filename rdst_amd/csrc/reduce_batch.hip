@@ -203,3 +203,11 @@ extern "C" int rdst_reduce_batch_end(void* stream) {
   rbatch::g_fins.clear();
   return rc;
 }
+
+extern "C" int rdst_reduce_batch_abort(void) {
+  // drop whatever is queued WITHOUT running it (the workspaces and outputs of a failed backward may be gone)
+  rbatch::g_active = false;
+  rbatch::g_sums.clear();
+  rbatch::g_fins.clear();
+  return 0;
+}

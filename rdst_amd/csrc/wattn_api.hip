@@ -5,7 +5,7 @@
 
 thread_local char g_rdst_err[256] = {0};
 
-extern "C" int rdst_abi_version(void) { return 6; }
+extern "C" int rdst_abi_version(void) { return 7; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {

@@ -384,7 +384,13 @@ class _UNetLoss(torch.autograd.Function):
         ctx.mod, ctx.save, ctx.kind = mod, save, None
         if "encoder" in mode:
             layers = mod.loss_layers
-            depth = max([l for l in layers] + [1])
+            # The reference's encoder always runs all five stages (loss/seg_unet.py:84: `self.encoder(x)`), whatever layers
+            # the loss reads.  The stages beyond max(layers) feed nothing but the running statistics of their own
+            # BatchNorms, which nothing ever reads (the UNet is never put in eval(): every pass normalises with batch
+            # statistics).  By default they are skipped — those BatchNorms' buffers (running_mean / running_var /
+            # num_batches_tracked under checkpoint['loss']) then stay where they were, a stated divergence from the
+            # reference's saved state; `mod.full_encoder_stats = True` runs them for a bit-faithful state at their cost.
+            depth = 5 if mod.full_encoder_stats else max([l for l in layers] + [1])
             fs = r.encoder(sr, depth, save)
             fh = r.encoder(hr, depth, None)
             n = len(layers)
@@ -440,7 +446,9 @@ class _UNetLoss(torch.autograd.Function):
                 if mod.keep_debug:
                     mod.debug_last = {"sr_logits": lg_s, "hr_logits": lg_h}
                 ctx.kind = "label"
-        mod._count_batches(1 if mode == "label-gt" else 2)
+        # only the BatchNorms that ran count a batch (nn.BatchNorm2d.forward in training mode): the encoder stages up to
+        # `depth` twice in the 'encoder' modes and never the decoder's; everything once ('label-gt') or twice otherwise
+        mod._count_batches(1 if mode == "label-gt" else 2, depth if "encoder" in mode else None)
         return loss
 
     @staticmethod
@@ -526,6 +534,7 @@ class SegUNet_F(nn.Module):
         self.loss_names = ["SegUNet({})".format(self.loss_mode)]
         self.use_mse = "L1" in self.loss_mode         # loss/seg_unet.py:73-78: 'L1' -> MSELoss, everything else L1Loss
         self.compute_dtype, self.compute_code = torch.float32, F32X3
+        self.full_encoder_stats = False               # see _UNetLoss.forward ('encoder' modes)
         self.keep_debug = False                       # tests: keep the logits of the last 'label' call in self.debug_last
         self._pack_cache = {}
         self._scratch_buf = None
@@ -573,7 +582,14 @@ class SegUNet_F(nn.Module):
             self._pack_cache = {"sig": sig, "packs": packs}
         return self._pack_cache["packs"]
 
-    def _count_batches(self, n):
+    def _bns_up_to(self, depth):
+        """The BatchNorms `_Runner.encoder(img, depth)` runs: the stem's and those of layer1 .. layer{depth-1}."""
+        ran = {id(self.encoder.bn1)}
+        for li in range(1, depth):
+            ran.update(id(m) for m in getattr(self.encoder, f"layer{li}").modules() if isinstance(m, nn.BatchNorm2d))
+        return ran
+
+    def _count_batches(self, n, encoder_depth=None):
         bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
         flat = getattr(self, "_nbt_flat", None)
         ok = flat is not None and flat.device == bns[0].num_batches_tracked.device and all(
@@ -583,7 +599,16 @@ class SegUNet_F(nn.Module):
             for i, m in enumerate(bns):
                 m.num_batches_tracked = flat[i]
             object.__setattr__(self, "_nbt_flat", flat)
-        flat += n
+            object.__setattr__(self, "_nbt_masks", {})
+        if encoder_depth is None:
+            flat += n
+            return
+        mask = self._nbt_masks.get(encoder_depth)
+        if mask is None or mask.device != flat.device:
+            ran = self._bns_up_to(encoder_depth)
+            mask = torch.tensor([1 if id(m) in ran else 0 for m in bns], dtype=flat.dtype, device=flat.device)
+            self._nbt_masks[encoder_depth] = mask
+        flat.add_(mask, alpha=n)
 
     # ---- loss/seg_unet.py:94-127 ----------------------------------------------------------------------------------------
     def forward(self, sr, hr, gt_label=None):

@@ -88,7 +88,14 @@ def _grad_like(param: torch.Tensor) -> torch.Tensor:
     v = dp.take_grad_view(param)
     if v is not None and v.shape == param.shape and v.dtype == param.dtype and v.device == param.device:
         return v
-    return torch.empty_like(param)
+    return _fresh_grad(torch.empty_like(param))
+
+
+def _fresh_grad(t: torch.Tensor) -> torch.Tensor:
+    """A parameter-gradient destination that is NOT a bucket view: autograd may read it (``p.grad += t``) as soon as the
+    node that returns it has returned, so its deferred reduction must have run by then (_ReduceBatch.settle)."""
+    _ReduceBatch.fresh += 1
+    return t
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -291,9 +298,12 @@ class _WindowAttention(torch.autograd.Function):
         dtable = _grad_like(tab)
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, qkv.device)
+        if _ReduceBatch.depth > 0:   # an outer batch is open: the d(table) slabs are summed when it ends
+            _ReduceBatch.keep.append(wsp)
         _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
                                       dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
                                       C, heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
+        _ReduceBatch.settle(lib)
         return dqkv, dtable, None, None, None, None, None, None, None
 
 
@@ -403,10 +413,11 @@ class _LnLinear(torch.autograd.Function):
         dlw = _grad_like(lw) if (lw is not None and need[1]) else None
         dlb = _grad_like(lb) if (lb is not None and need[2]) else None
         dw = _grad_like(w) if (w is not None and need[3]) else None
-        db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(N, dtype=torch.float32, device=dev)) \
-            if (has_bias and need[4]) else None
+        db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None
+              else _fresh_grad(torch.empty(N, dtype=torch.float32, device=dev))) if (has_bias and need[4]) else None
         _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy_r, lddy, dx, K, None, 0, dw, db, dlw, dlb, M, K, N,
                          out_scale, _dtype_code(x), dev, keep=_ReduceBatch.keep if _ReduceBatch.depth > 0 else None)
+        _ReduceBatch.settle(lib)
         dres = dy if (has_res and need[5]) else None
         return dx, dlw, dlb, dw, db, dres, None, None, None
 
@@ -444,9 +455,17 @@ class _ReduceBatch:
     DenseSTLayer (dense join with a GradSink) opens an OUTER one in the join's backward — the first node of the layer's
     backward — which the layer's first Swin block closes at the end of its own — the last node — so the slab sums and
     LayerNorm finishes of the whole layer (two blocks + the tail Linear) run as 2 launches instead of 6.  `keep` holds
-    the ops' workspaces (the slabs) until the batch has run."""
+    the ops' workspaces (the slabs) until the batch has run.
+
+    A batch that spans autograd nodes defers WRITES of parameter gradients past the node that returns them.  That is
+    only sound for destinations nobody reads before the batch ends: the flat-bucket views a detach_grads() bracket
+    offers (rdst_amd.dp: p.grad is None, AccumulateGrad keeps the tensor without looking at it).  Any other destination
+    (`fresh`: p.grad already defined -> autograd runs ``p.grad += g`` right after the node — bucket.zero() + backward,
+    gradient accumulation, zero_grad(set_to_none=False) —, or a parameter used twice) makes the node `settle` before
+    it returns: the queued reductions run at once and the outer batch goes on empty."""
     depth = 0
     keep: list = []
+    fresh = 0
 
     @staticmethod
     def begin(lib):
@@ -464,13 +483,31 @@ class _ReduceBatch:
                 _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
             finally:
                 _ReduceBatch.keep = []
+                _ReduceBatch.fresh = 0
+
+    @staticmethod
+    def settle(lib):
+        """Last statement of a node's backward: if a batch is still open around this node and the node handed out a
+        gradient destination that autograd may read on return, run what is queued now (and keep the batch open)."""
+        if _ReduceBatch.depth > 0 and _ReduceBatch.fresh:
+            try:
+                _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
+            finally:
+                _ReduceBatch.keep = []
+                _ReduceBatch.fresh = 0
+            _lib.check(lib.rdst_reduce_batch_begin(), "rdst_reduce_batch_begin")
+        elif _ReduceBatch.depth == 0:
+            _ReduceBatch.fresh = 0
 
     @staticmethod
     def abandon(lib):
-        """Close whatever a failed / partial backward left open (its queued reductions are run, not dropped)."""
+        """Forget whatever a failed / partial backward left open: its queued reductions are DROPPED — the slabs and the
+        outputs they name belonged to that backward and may be freed (rdst_reduce_batch_abort)."""
         if _ReduceBatch.depth > 0:
-            _ReduceBatch.depth = 1
-            _ReduceBatch.end(lib)
+            _lib.check(lib.rdst_reduce_batch_abort(), "rdst_reduce_batch_abort")
+        _ReduceBatch.depth = 0
+        _ReduceBatch.keep = []
+        _ReduceBatch.fresh = 0
 
 
 class GradSink:
@@ -644,6 +681,7 @@ class _SwinBlock(torch.autograd.Function):
                 _ReduceBatch.end(lib, keep)
             if outer:
                 _ReduceBatch.end(lib)
+            _ReduceBatch.settle(lib)   # (a later block of a DenseSTLayer: the layer's batch is still open around it)
 
     @staticmethod
     def _backward_body(ctx, lib, dy_r, lddy, need, keep, dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b,
@@ -662,7 +700,9 @@ class _SwinBlock(torch.autograd.Function):
             def out(t, like, n=None):
                 if t is not None:
                     return t
-                return torch.empty_like(like) if like is not None else torch.empty(n, dtype=torch.float32, device=dev)
+                t = torch.empty_like(like) if like is not None else torch.empty(n, dtype=torch.float32, device=dev)
+                keep.append(t)   # scratch destination of a deferred reduction: alive until the batch has run
+                return t
             o = [out(dfc1w, fc1w), out(dfc1b, fc1b, hid), out(dfc2w, fc2w), out(dfc2b, fc2b, C), out(dn2w, n2w),
                  out(dn2b, n2b)]
             nb = lib.rdst_mlp_bwd_workspace(M, C, hid)

@@ -37,6 +37,8 @@ class DPTrainStep:
     keeps its own streams); other shapes, and steps under an active loss-threshold guard, run eagerly.  This is the
     step ``bench.py`` times."""
 
+    RECORD_FLUSH = 4096   # parked device scalars before they are converted in one batch (bounds the memory they hold)
+
     def __init__(self, net: torch.nn.Module, lr: float = 1e-4, betas=(0.9, 0.99), eps: float = 1e-8,
                  weight_decay: float = 0.0, milestones: Optional[Sequence[int]] = None, gamma: float = 0.5,
                  loss_threshold: float = GUARD_OFF, loss_fn: Optional[Callable] = None, group=None,
@@ -65,6 +67,7 @@ class DPTrainStep:
         # training state carried by the reference's checkpoints
         self.training_loss_names = ["L1"] if loss_fn is None else list(getattr(loss_fn, "loss_components", ["loss"]))
         self.training_loss_records: Dict[str, list] = {n: [] for n in self.training_loss_names}
+        self._pending: Dict[str, list] = {}      # device scalars of the steps since the last flush (see _record)
         self.quick_validation_reports: list = []
         self.current_training_state_id = 0
         self.current_epoch = 0
@@ -85,6 +88,31 @@ class DPTrainStep:
             self.last_report = r[1]
             return r[0]
         return r
+
+    def _record(self, loss: torch.Tensor) -> None:
+        """trans_sr_trainer.py:165-167 appends ``report[name]`` (a Python float: one host sync per component and step).
+        Here the DEVICE scalars of the step are parked (a clone each: the graph step overwrites its buffers) and become
+        floats only when a checkpoint is written (`_flush_records`), so a step never leaves the device."""
+        rep = self.last_report
+        if isinstance(rep, dict) and rep:
+            for n in self.training_loss_names:
+                if n in rep:
+                    v = rep.raw(n) if hasattr(rep, "raw") else dict.__getitem__(rep, n)
+                    self._pending.setdefault(n, []).append(v.detach().clone() if torch.is_tensor(v) else float(v))
+        elif len(self.training_loss_names) == 1:
+            self._pending.setdefault(self.training_loss_names[0], []).append(loss.detach().clone())
+        if sum(len(v) for v in self._pending.values()) >= self.RECORD_FLUSH:
+            self._flush_records()
+
+    def _flush_records(self) -> None:
+        for n, vals in self._pending.items():
+            if not vals:
+                continue
+            ts = [v for v in vals if torch.is_tensor(v)]
+            host = torch.stack([t.reshape(()).float() for t in ts]).cpu().tolist() if ts else []
+            it = iter(host)
+            self.training_loss_records.setdefault(n, []).extend(next(it) if torch.is_tensor(v) else v for v in vals)
+        self._pending = {}
 
     def fwd_bwd(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         """forward + loss + backward with the gradients written straight into the flat bucket (no host sync inside:
@@ -114,6 +142,12 @@ class DPTrainStep:
             import warnings
             warnings.warn(f"rdst_amd.trainer: HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly")
             torch.cuda.synchronize()
+            # a backward that died half way leaves a reduction batch open and bucket views on offer: drop both (the
+            # queued reductions name workspaces of the failed capture; running them later would write through freed memory)
+            from . import _lib, ops
+            ops._ReduceBatch.abandon(_lib.load())
+            dp._OFFERED = {}
+            self.bucket.gather()
             self.use_graph, self.graph, self._static = False, None, None
             return False
         if not self.bucket.check_views():
@@ -138,6 +172,7 @@ class DPTrainStep:
             out = self.net(inputs)
             loss = self._loss(out, targets)
             if self._keep_step(loss):                  # :162
+                self._record(loss)                     # :165-167
                 loss.backward()
                 self.bucket.gather()
                 self._finish_step()
@@ -157,6 +192,7 @@ class DPTrainStep:
         else:
             loss = self.fwd_bwd(inputs, targets)
             self._eager_seen += 1
+        self._record(loss)                             # :165-167 (lazy: no host sync)
         self._finish_step()
         self.training_epoch_costs.append(time.time() - t0)   # :176-178 (host-side enqueue time: nothing synced)
         return loss
@@ -169,6 +205,7 @@ class DPTrainStep:
 
     # ---- models/basic_trainer.py:164-208 -----------------------------------------------------------
     def checkpoint(self) -> dict:
+        self._flush_records()
         ck = {"Time": time.strftime("%Y-%m-%d %H:%M:%S"),
               "model_g": self.net.state_dict(),
               "optimizer_g": self.optimizer.state_dict(),
