@@ -59,6 +59,8 @@ int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out,
                      float scale, hipStream_t st);
 int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
                      int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
+int wattn_bwd_pair(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv, int64_t ldq,
+                   float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
 int wattn_bwd_mfma_hd(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
                       int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
 int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,

@@ -525,6 +525,18 @@ int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* 
   if (dtype == RDST_F32)
     return launch_bwd<float>((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
                              scale, nslab, st);
+#ifndef RDST_K2_DMA
+#define RDST_K2_DMA 0   // 1: the round-4 re-cut (wattn_bwd_pair.hip: LDS-DMA ring, passes T / N without the P / dS images).  Measured
+                        // on MI355X it hides the row traffic (memory skeleton 53 us -> 16 us exposed) but its recomputed key-tile
+                        // pass makes it VALU-bound: 79 / 82 / 79 us cold at C = 60 / 90 / 120 against 77 / 81 / 82 for the kernel
+                        // below, 76.9 against 73.7 us inside the step — so it is not the default
+#endif
+#if RDST_K2_DMA
+  {
+    const int rc = wattn_bwd_pair(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
+    if (rc != RDST_ENOTSUP) return rc;
+  }
+#endif
   {  // the compile-time-specialised kernel (6 heads of dim 10/15/20) where it applies
     const int rc = wattn_bwd_mfma_hd(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
     if (rc != RDST_ENOTSUP) return rc;

@@ -1,8 +1,14 @@
 // K2 (window attention backward) specialised at compile time like the forward (wattn_mfma_hd.hip):
 // bf16, 8x8 windows, HEADS = 6 heads of dim D (C = 60 / 90 / 120).
 //
-// One 12-wave workgroup per window, wave w = (tile t = w & 1, head hd = w >> 1): every head of the
-// window is processed at the same time and each wave's head is a compile-time constant.
+// Work item = (window, group of NH heads); a workgroup of 2 NH waves, wave w = (tile t = w & 1, local head hd = w >> 1),
+// each wave's head a compile-time constant.  NH = 2 (round 4): a 4-wave workgroup owns one head PAIR of a window — 40 / 60 /
+// 80 bytes of every q / k / v / dOut row — needs 49-53 KB of LDS, and THREE of them share a CU.  They run independently:
+// while one waits for its rows or drains its gradient rows, the other two compute.  (NH = 6, rounds 1-3: one 12-wave
+// workgroup per CU did a whole window behind six barriers, the no-compute skeleton of that kernel alone took 46-62 us of
+// its 73-82: one window of loads in flight per CU, issued less than a load latency ahead.)  The three pair workgroups of
+// a window walk the same windows in the same order on the same XCD (blockIdx -> (group, pair) below), so the 128-byte
+// lines their row pieces share meet in that XCD's L2.
 //   phase A  (t = query tile; keys in the accumulator registers, query on the lane, as in the forward)
 //     S^T = K.Q^T (+ bias/scale as initial accumulator) -> softmax ONCE -> P^T;  dP^T = V.dO^T;
 //     delta = rowsum(P dP);  dS^T = P^T (dP^T - delta)
@@ -23,9 +29,8 @@
 namespace {
 using namespace wahd;
 
-constexpr int NW2 = 12;          // waves per workgroup: 2 tiles x 6 heads
-constexpr int NT2 = 64 * NW2;
-constexpr int MAXR2 = 6;         // token rows staged per wave (rows w, w+12, ...)
+constexpr int HEADS_ALL = 6;     // heads of the layer (the kernel covers 6 heads of dim 10 / 15 / 20)
+constexpr int MAXR2 = 6;         // row chunks staged per lane (12 rows per pass of the workgroup, 64 rows)
 
 struct BwArgs {
   const bf16* qkv; int64_t ld;
@@ -33,6 +38,7 @@ struct BwArgs {
   const bf16* dout; int64_t ldd;
   bf16* dqkv; int64_t ldq;
   float* slab;
+  int G;                       // window groups: workgroup (group, head group) walks windows group, group + G, ...
   WinGeom g;
   float scale;
   unsigned long long* stamps;  // RDST_K2_STAMPS=n: [grid][16] s_memtime stamps of thread 0 (debug only), else NULL
@@ -239,14 +245,34 @@ __device__ __forceinline__ void bw_phase_b(const BwCtx& c, f32x16& dv, f32x16& d
 }
 
 template <int D, int HEADS, int GRAN>
-__global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
+__global__ void __launch_bounds__(128 * HEADS, 3) wattn_bwd_hd_kernel(const BwArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CF = HdB<D, HEADS>;
   using CH = typename Chunk<GRAN>::type;
+  constexpr int NW2 = 2 * HEADS, NT2 = 64 * NW2;      // waves / threads per workgroup
+  constexpr int NG = HEADS_ALL / HEADS;               // head groups per window
+  constexpr int CFULL = HEADS_ALL * D;                // channels of a q / k / v third of a qkv row
   constexpr int ldt = CF::LDT, secb = CF::SEC;
   constexpr int cps = secb / GRAN;  // chunks per section
-  static_assert(4 * cps <= 64, "one token row (qkv + dOut) per wave instruction");
+  constexpr int LPR = 4 * cps;      // lanes that move one token row (q, k, v, dOut pieces)
+  constexpr int RPI = 64 / LPR;     // token rows per wave instruction
+  static_assert(LPR <= 64 && NW2 * RPI * MAXR2 >= 64, "copy plan");
   const WinGeom g = p.g;
+  // blockIdx -> (window group, head group): the NG workgroups of a group sit on ONE XCD (blocks b and b + 8 share one)
+  // in neighbouring dispatch slots; placement is for L2 locality only, any mapping is correct
+  int group, hg;
+  {
+    const int b = blockIdx.x;
+    if ((p.G & 7) == 0) {
+      const int slot = b >> 3;
+      hg = slot % NG;
+      group = (slot / NG) * 8 + (b & 7);
+    } else {
+      hg = b % NG;
+      group = b / NG;
+    }
+  }
+  const int ch0 = hg * HEADS * D;   // first channel of this workgroup's heads inside each third / inside a dOut row
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = wv & 1, hd = wv >> 1;   // tile (queries in phase A, keys in phase B) and head of this wave
@@ -311,12 +337,17 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
             (r == k0 ? 0x00003f80u : 0u) | (r == k1 ? 0x3f800000u : 0u);
       }
   }
-  // copy plan: wave w moves token rows w, w+12, ...; lanes < 3*cps move qkv chunks, the next cps lanes dOut chunks
-  const int sec = (lane >= cps) + (lane >= 2 * cps) + (lane >= 3 * cps);   // 0 Q, 1 K, 2 V, 3 dOut
-  const int chk = lane - sec * cps;
+  // copy plan: a wave instruction moves RPI token rows (LPR lanes each: 3 cps lanes the q / k / v chunks, cps lanes the
+  // dOut chunks); pass k of the workgroup covers rows NW2 * RPI * k + wave * RPI + rsub
+  const int rsub = lane / LPR, l2 = lane - rsub * LPR;
+  const int sec = (l2 >= cps) + (l2 >= 2 * cps) + (l2 >= 3 * cps);   // 0 Q, 1 K, 2 V, 3 dOut
+  const int chk = l2 - sec * cps;
   const int sec_off = sec == 0 ? CF::OFF_Q : sec == 1 ? CF::OFF_K : sec == 2 ? CF::OFF_V : CF::OFF_DO;
   char* my_lds = smem + sec_off + chk * GRAN;
-  const bool ld_act = lane < 4 * cps, st_act = lane < 3 * cps;
+  const bool ld_act = rsub < RPI, st_act = ld_act && sec < 3;
+  const int row0 = wv * RPI + (ld_act ? rsub : 0);
+  // byte offset of the lane's chunk inside a qkv / dOut / dqkv row
+  const int goff = ((sec < 3 ? sec * CFULL : 0) + ch0) * 2 + (ld_act ? chk : 0) * GRAN;
 
   struct WinPos { int b, wr, wc; };
   auto locate = [&](int win) {
@@ -327,7 +358,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     w.wc = wi - w.wr * g.nWw;
     return w;
   };
-  auto token = [&](const WinPos& w, int ri) {  // global token row of window row ri (wave uniform)
+  auto token = [&](const WinPos& w, int ri) {  // global token row of window row ri
     int rr = w.wr * 8 + (ri >> 3) + g.shift;
     if (rr >= g.H) rr -= g.H;
     int cc = w.wc * 8 + (ri & 7) + g.shift;
@@ -341,10 +372,9 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
   auto fetch = [&](const WinPos& w) {
 #pragma unroll
     for (int k = 0; k < MAXR2; ++k) {
-      const int ri = wv + NW2 * k < 64 ? wv + NW2 * k : wv;
+      const int ri = row0 + NW2 * RPI * k < 64 ? row0 + NW2 * RPI * k : row0;
       const int64_t t = token(w, ri);
-      const char* src = sec < 3 ? reinterpret_cast<const char*>(p.qkv + t * p.ld) + (size_t)(lane < 3 * cps ? lane : 0) * GRAN
-                                : reinterpret_cast<const char*>(p.dout + t * p.ldd) + (size_t)(ld_act ? chk : 0) * GRAN;
+      const char* src = (sec < 3 ? reinterpret_cast<const char*>(p.qkv + t * p.ld) : reinterpret_cast<const char*>(p.dout + t * p.ldd)) + goff;
       regs[k] = *reinterpret_cast<const CH*>(src);
     }
   };
@@ -354,7 +384,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) Dsum[kt][v] = 0.f;
 
-  int win = blockIdx.x;
+  int win = group;
   WinPos cur = locate(win < nwin ? win : 0);
   fetch(cur);   // in flight while the table is staged
   {  // relative-position table / scale, x-reversed, two copies (see wattn_mfma_hd.hip)
@@ -362,8 +392,8 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     float tv[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-      const int j = tid + NT2 * k;
-      tv[k] = p.table[j < NT_SRC ? j : NT_SRC - 1];
+      const int j0 = tid + NT2 * k, j = j0 < NT_SRC ? j0 : NT_SRC - 1;
+      tv[k] = p.table[(j / HEADS) * HEADS_ALL + hg * HEADS + (j % HEADS)];
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -377,11 +407,11 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
       }
     }
   }
-  for (; win < nwin; win += gridDim.x) {
+  for (; win < nwin; win += p.G) {
     __syncthreads();  // b0: the previous window's rows have left the sections
 #pragma unroll
     for (int k = 0; k < MAXR2; ++k) {
-      const int ri = wv + NW2 * k;
+      const int ri = row0 + NW2 * RPI * k;
       if (ri < 64 && ld_act) chunk_to_lds<CH>(my_lds + ri * ldt, regs[k]);
     }
     if (tid < 4 * 64) {  // pad columns [SEC, ldt) of the four sections: padded k-steps must read finite zeros
@@ -405,10 +435,11 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
 
     Pack16 pP[2][2], pdS[2][2];
     f32x16 dq, dv, dk;
-#define RDST_BW_HEADS(CALL) \
-    switch (hd) {           \
-      case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; \
-      case 3: CALL(3); break; case 4: CALL(4); break; default: CALL(5); break; \
+#define RDST_BW_HEADS(CALL)                                                                    \
+    if constexpr (HEADS == 2) { if (hd == 0) { CALL(0); } else { CALL(1); } }                   \
+    else switch (hd) {                                                                          \
+      case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2 % HEADS); break;           \
+      case 3: CALL(3 % HEADS); break; case 4: CALL(4 % HEADS); break; default: CALL(5 % HEADS); break; \
     }
 #define RDST_BW_A(HD) bw_phase_a<D, HEADS, HD>(c, pP, pdS, dq, Dsum)
 #ifndef K2_ABL
@@ -435,7 +466,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     // (12-byte chunks) spilled that way (80 -> 91 us) until the context was rebuilt per window: now 80.4 -> 78.0 us.
     constexpr bool EARLY_FETCH = true;
     if constexpr (EARLY_FETCH) {
-      const int nxt = win + gridDim.x;
+      const int nxt = win + p.G;
       cur = locate(nxt < nwin ? nxt : win);
       fetch(cur);
     }
@@ -451,7 +482,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     __syncthreads();  // b4: Q, dOut, P, dS are dead: the gradient tiles go where Q / K / V were
     stamp();  // 4 + 6k: phase B done
     if constexpr (!EARLY_FETCH) {
-      const int nxt = win + gridDim.x;
+      const int nxt = win + p.G;
       cur = locate(nxt < nwin ? nxt : win);
       fetch(cur);
     }
@@ -470,10 +501,10 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
     stamp();  // 5 + 6k: tiles stored
 #pragma unroll
     for (int k = 0; k < MAXR2; ++k) {
-      const int ri = wv + NW2 * k;
+      const int ri = row0 + NW2 * RPI * k;
       if (ri < 64 && st_act && !(K2_ABL & 8)) {
         const int64_t t = token(w, ri);
-        char* dst = reinterpret_cast<char*>(p.dqkv + t * p.ldq) + (size_t)lane * GRAN;
+        char* dst = reinterpret_cast<char*>(p.dqkv + t * p.ldq) + goff;
         *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(my_lds + ri * ldt);
       }
     }
@@ -495,7 +526,7 @@ __global__ void __launch_bounds__(NT2) wattn_bwd_hd_kernel(const BwArgs p) {
       ds[(hd * 64 + yi * 8 + xi) * 65 + yj * 8 + xj] = Dsum[kt][v];
     }
   __syncthreads();
-  float* my = p.slab + (int64_t)blockIdx.x * HEADS * 225;
+  float* my = p.slab + ((int64_t)group * HEADS_ALL + hg * HEADS) * 225;   // slab row [group][6][225]
   for (int e = tid; e < HEADS * 225; e += NT2) {
     const int hd2 = e / 225, rem = e - hd2 * 225, dy = rem / 15 - 7, dx = rem - (rem / 15) * 15 - 7;
     const float* base = ds + hd2 * 64 * 65;
@@ -526,18 +557,22 @@ int launch_bw(const BwArgs& p, int slab_rows, int* nslab, hipStream_t st) {
   auto kern = wattn_bwd_hd_kernel<D, HEADS, GRAN>;
   if (CF::SMEM > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF::SMEM);
+  constexpr int NT2 = 128 * HEADS, NG = HEADS_ALL / HEADS;
   const int64_t nwin = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
-  int64_t grid = 256;   // one 12-wave workgroup per CU
-  if (grid > nwin) grid = nwin;
-  if (grid > slab_rows) grid = slab_rows;
-  *nslab = (int)grid;
+  int64_t G = 256;      // window groups: NG workgroups each, 256 x NG workgroups = 12 waves per CU
+  if (G > nwin) G = nwin;
+  if (G > slab_rows) G = slab_rows;
+  *nslab = (int)G;
+  BwArgs pg = p;
+  pg.G = (int)G;
+  const int64_t grid = G * NG;
   static int want_stamps = -1;
   if (want_stamps < 0) {
     const char* e = rdst_dbg_getenv("RDST_K2_STAMPS");
     want_stamps = e ? atoi(e) : 0;
   }
   if (want_stamps > 0) {  // debug: in-kernel phase stamps of every workgroup, summarised on stderr
-    BwArgs q = p;
+    BwArgs q = pg;
     const size_t n = (size_t)grid * 16;
     (void)hipMalloc((void**)&q.stamps, n * 8);
     (void)hipMemsetAsync(q.stamps, 0, n * 8, st);
@@ -562,7 +597,7 @@ int launch_bw(const BwArgs& p, int slab_rows, int* nslab, hipStream_t st) {
     free(hst);
     return rdst_launch_status("wattn_bwd_hd");
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT2), CF::SMEM, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT2), CF::SMEM, st, pg);
   return rdst_launch_status("wattn_bwd_hd");
 }
 
@@ -589,8 +624,11 @@ int wattn_bwd_mfma_hd(const void* qkv, int64_t ld, const float* table, const voi
   p.ldq = ldq; p.slab = slab; p.g = g; p.scale = scale;
   const int d = g.C / 6;
   const int64_t a = ld * 2, b = ldd * 2, cc = ldq * 2;
-  if (d == 10 && aligned_to(qkv, dout, dqkv, a, b, cc, 8)) return launch_bw<10, 6, 8>(p, slab_rows, nslab, st);
-  if (d == 15 && aligned_to(qkv, dout, dqkv, a, b, cc, 4)) return launch_bw<15, 6, 12>(p, slab_rows, nslab, st);
-  if (d == 20 && aligned_to(qkv, dout, dqkv, a, b, cc, 16)) return launch_bw<20, 6, 16>(p, slab_rows, nslab, st);
+#ifndef K2_NH
+#define K2_NH 6    // heads per workgroup: 6 = one 12-wave workgroup per window (rounds 1-3; now the fallback for strided rows); 2 = (window, head pair) items with register-staged rows, three workgroups per CU (measured round 4: no faster, see wattn_bwd_pair.hip)
+#endif
+  if (d == 10 && aligned_to(qkv, dout, dqkv, a, b, cc, 8)) return launch_bw<10, K2_NH, 8>(p, slab_rows, nslab, st);
+  if (d == 15 && aligned_to(qkv, dout, dqkv, a, b, cc, 4)) return launch_bw<15, K2_NH, 12>(p, slab_rows, nslab, st);
+  if (d == 20 && aligned_to(qkv, dout, dqkv, a, b, cc, 16)) return launch_bw<20, K2_NH, 16>(p, slab_rows, nslab, st);
   return RDST_ENOTSUP;
 }
