@@ -30,6 +30,12 @@ Extra objects on the line (N = 1, rank 0):
   fp32_mode    — throughput of the fp32 parity mode (the mode that carries the 4-decimal PSNR claim).
   cpu_baseline — the CPU oracle (oracle/rdst_oracle.py, a port) timed on the host cores on a bounded
                  sample (batch 4) of the same workload.
+  configs      — (default run only: --config e1, N = 1) the OTHER BASELINE.json configurations on the same line, 5 timed
+                 graph steps each after capture: ws16 (configs[3]: value, ms_per_step, K1 / K2 roofline fractions),
+                 e1_unetf and e1_hrl (configs[4]: value, ms_per_step, the loss network's share of the step), each with its
+                 own cpu_baseline (oracle + oracle/segunet_oracle.py at batch 1).  `--no-configs` skips them.
+On N > 1 the line also carries world_size_seen, backend, bucket_bytes and the measured all-reduce time (HIP events around 5
+calls of FlatGradBucket.all_reduce_mean) so that a scaling record explains itself.
 """
 from __future__ import annotations
 
@@ -215,8 +221,14 @@ def _cpu_baseline_worker(threads, sample_batch, timed, which="e1"):
     """Runs in a child process: the oracle (a CPU port of the reference algorithm), fwd + L1 + bwd."""
     torch.set_num_threads(threads)
     from oracle import rdst_oracle as O
-    cfg, cin, lr, sr = {"e1": (O.CFG_E1, 1, 64, 4), "tiny": (O.CFG_TINY, 1, 64, 4),
+    cfg, cin, lr, sr = {"e1": (O.CFG_E1, 1, 64, 4), "tiny": (O.CFG_TINY, 1, 64, 4), "e1_unetf": (O.CFG_E1, 1, 64, 4),
+                        "e1_hrl": (O.CFG_E1, 1, 64, 4),
                         "ws16": (O.make_cfg(**{**O.CFG_WS16, "img_size": 128}), 3, 128, 2)}[which]
+    unet = None
+    if which in LOSS_MODES:     # 0.1 L1 + 1 SegUNet_F (oracle/segunet_oracle.py: the restated smp resnet34-UNet, seeded weights)
+        from oracle import segunet_oracle as SO
+        (mode, layers), = LOSS_MODES[which].items()
+        unet = (SO, {k: v.clone() for k, v in SO.make_unet_weights(1, 4, seed=1).items()}, mode, layers)
     sd = O.make_weights(cfg, 0)
     lay = O.state_dict_layout(cfg)
     sd = {k: (v.clone().requires_grad_(True) if lay[k][2] not in ("index", "mask", "shift_w", "shift_b") else v)
@@ -228,7 +240,11 @@ def _cpu_baseline_worker(threads, sample_batch, timed, which="e1"):
     for it in range(1 + timed):
         t0 = time.perf_counter()
         y = O.rdstsr_forward(x, sd, cfg)
-        F.l1_loss(y, tgt).backward()
+        loss = F.l1_loss(y, tgt)
+        if unet is not None:
+            SO, usd, mode, layers = unet
+            loss = 0.1 * loss + SO.segunet_loss(y, tgt, usd, mode, layers)
+        loss.backward()
         dt = time.perf_counter() - t0
         if it > 0:
             best = dt if best is None else min(best, dt)
@@ -262,7 +278,7 @@ def _host_cpu():
     return model, (len(cores) or (os.cpu_count() or 1)), (logical or (os.cpu_count() or 1))
 
 
-def cpu_baseline(which="e1", threads=16, sample_batch=4, timed=3, timeout_s=150):
+def cpu_baseline(which="e1", threads=16, sample_batch=4, timed=3, timeout_s=150, start_only=False):
     """Bounded CPU baseline next to the GPU number.  16 threads: on the 256-CPU GPU-box host the
     oracle is FASTEST there (measured 1.7 s/step at 16 threads, 2.9 s at 32, 5.7 s at 64: the ops are
     small and OpenMP fork/join dominates beyond that), so this is the best CPU figure, not a handicap."""
@@ -270,8 +286,13 @@ def cpu_baseline(which="e1", threads=16, sample_batch=4, timed=3, timeout_s=150)
     threads = max(1, min(threads, os.cpu_count() or 1))
     model, phys, logical = _host_cpu()
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), str(sample_batch), str(timed), which]
-    names = {"e1": "RDST-E1 x4, 1x64x64", "tiny": "RDST-E tiny x4 (BASELINE configs[0]), 1x64x64", "ws16": "RDST x2 window 16, 3x128x128"}
+    names = {"e1": "RDST-E1 x4, 1x64x64", "tiny": "RDST-E tiny x4 (BASELINE configs[0]), 1x64x64", "ws16": "RDST x2 window 16, 3x128x128",
+             "e1_unetf": "RDST-E1 x4 + 0.1 L1 + SegUNet_F encoder-L1 [1] (oracle/segunet_oracle.py), 1x64x64",
+             "e1_hrl": "RDST-E1 x4 + 0.1 L1 + SegUNet_F label-hr (oracle/segunet_oracle.py: resnet34-UNet x 2 forward + backward + Dice), 1x64x64"}
     host = {"cores": threads, "host_cpu": model, "host_physical_cores": phys, "host_logical_cpus": logical}
+    if start_only:    # the caller collects later (cpu_baseline_collect): the CPU sample runs while the GPU is being measured
+        return (subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT), host, names[which], threads,
+                sample_batch, timed, timeout_s, time.time())
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         best = json.loads(r.stdout.strip().splitlines()[-1])["best_s"]
@@ -281,6 +302,23 @@ def cpu_baseline(which="e1", threads=16, sample_batch=4, timed=3, timeout_s=150)
     return {"value": round(sample_batch / best, 3), "unit": "patches/s", **host, "kind": "port",
             "sample": f"oracle/rdst_oracle.py fwd+L1+bwd, {names[which]}, batch {sample_batch} fp32, "
                       f"best of {timed} after 1 warm-up, torch CPU, {threads} threads (the oracle's fastest thread count on this host)"}
+
+
+def cpu_baseline_collect(h):
+    """Result of a cpu_baseline(..., start_only=True) child."""
+    proc, host, name, threads, sample_batch, timed, timeout_s, t0 = h
+    try:
+        so, _ = proc.communicate(timeout=max(1.0, timeout_s - (time.time() - t0)))
+        best = json.loads(so.strip().splitlines()[-1])["best_s"]
+    except Exception as e:  # noqa: BLE001
+        try:
+            proc.kill()
+        except Exception:  # noqa: BLE001
+            pass
+        return {"value": None, "unit": "patches/s", **host, "kind": "port", "sample": f"failed or exceeded {timeout_s}s: {type(e).__name__}"}
+    return {"value": round(sample_batch / best, 3), "unit": "patches/s", **host, "kind": "port",
+            "sample": f"oracle fwd+loss+bwd, {name}, batch {sample_batch} fp32, best of {timed} after 1 warm-up, torch CPU, {threads} threads, "
+                      f"the three configs[3] / configs[4] samples timed side by side (16 threads each of {host['host_logical_cpus']} CPUs)"}
 
 
 def main():
@@ -303,6 +341,7 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=3, help="replay passes over the recorded launches")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-op measurements (clean per-step kernel profiles)")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the fp32 parity-mode measurement (field fp32_mode)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (field configs) of the default run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -348,6 +387,9 @@ def main():
 
     lib = _lib.load()
     rec = Recorder(lib)
+    # the other BASELINE configurations ride on the default run's line
+    want_configs = (rank == 0 and world == 1 and args.config == "e1" and args.dtype == "bf16" and not args.no_configs
+                    and not args.no_roofline)
     if args.graph:
         for _ in range(2):          # eager steps: every lazy initialisation (weight-image plans, workspaces) happens here
             tr.step(x, tgt)
@@ -388,6 +430,21 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         param_sync = bool(lo.item() == hi.item())
     loss_val = float(loss_t.item())
+    comm = None
+    if world > 1:   # what the collective costs on this fabric: HIP events around 5 all-reduces of the flat bucket
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        bucket.all_reduce_mean(tr.group)
+        sync()
+        e0.record()
+        for _ in range(5):
+            bucket.all_reduce_mean(tr.group)
+        e1.record()
+        sync()
+        tms = torch.tensor([e0.elapsed_time(e1) / 5], device=device, dtype=torch.float64)
+        dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+        comm = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(), "bucket_bytes": bucket.nbytes,
+                "all_reduce_ms": round(tms.item(), 4),
+                "all_reduce_how": "HIP events around 5 x FlatGradBucket.all_reduce_mean (one collective over the flat fp32 bucket), max over ranks"}
 
     metric = {"e1": "SR patches/sec fwd+bwd, RDST-E1 x4 64->256",
               "ws16": "SR patches/sec fwd+bwd, RDST x2 window-16 128->256 (BASELINE configs[3])",
@@ -411,6 +468,17 @@ def main():
     }
     if param_sync is not None:
         out["param_sync"] = param_sync
+    if comm is not None:
+        out.update(comm)
+    if loss_obj is not None and "UNet-F" in loss_obj.loss_functions:
+        # the frozen loss network is replicated: its train-mode BatchNorm statistics are per rank, and
+        # every rank must have run it the same number of times
+        nb = loss_obj.loss_functions["UNet-F"].encoder.bn1.num_batches_tracked.detach().to(device).double().reshape(1)
+        lo, hi = nb.clone(), nb.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out["unet_bn_batches_tracked"] = [int(lo.item()), int(hi.item())]
 
     if rank == 0 and world == 1 and not args.no_roofline and tr.graph is not None and recorded:
         elt = 2 if args.dtype == "bf16" else 4
@@ -420,10 +488,22 @@ def main():
         if args.dtype == "bf16" and not args.no_fp32_line and args.config == "e1":
             # the parity mode (fp32 activations, exact-fp32 MFMA): the only mode with the 4-decimal PSNR claim
             del tr
+            tr = None
             try:
                 out["fp32_mode"] = fp32_line(device, x, tgt, B, lib)
             except Exception as e:  # noqa: BLE001
                 out["fp32_mode"] = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
+        if want_configs:
+            tr = net = bucket = loss_obj = None
+            rec.calls = recorded = []
+            torch.cuda.empty_cache()
+            out["configs"] = {}
+            for name in ("ws16", "e1_unetf", "e1_hrl"):
+                try:
+                    line = extra_config(name, device, lib, out["ms_per_step"])
+                except Exception as e:  # noqa: BLE001
+                    line = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
+                out["configs"][name] = line
         if not args.no_cpu_baseline:
             if args.config == "ws16":
                 out["cpu_baseline"] = cpu_baseline("ws16", sample_batch=1, timed=1, timeout_s=200)
@@ -432,10 +512,66 @@ def main():
                 if args.config == "e1":
                     c1 = cpu_baseline("tiny", timeout_s=60)
                     out["cpu_baseline"]["cfg1"] = {"value": c1["value"], "unit": "patches/s", "sample": c1["sample"]}
+            if want_configs and "configs" in out:
+                # the three samples run side by side (16 threads each), after every GPU measurement of this run is over: a CPU
+                # child next to a timed GPU region slowed the headline step by 25 % (measured, round 4)
+                hs = {n: cpu_baseline(n, sample_batch=1, timed=1, timeout_s=240, start_only=True) for n in out["configs"]}
+                for n, h in hs.items():
+                    out["configs"][n]["cpu_baseline"] = cpu_baseline_collect(h)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def extra_config(name, device, lib, e1_ms, steps=5):
+    """One of the other BASELINE configurations, measured the way the headline is (DPTrainStep, forward + loss + backward
+    replayed from one HIP graph, flat-bucket Adam), `steps` timed steps after 2 eager steps + capture + 1 replay."""
+    from rdst_amd.trainer import DPTrainStep
+    cfg, lr_size, in_ch, sr, cfg_name = CONFIGS[name]
+    B = 8 if name == "ws16" else 32
+    net = build_net(device, torch.bfloat16, cfg)
+    loss_obj = build_loss(name, device)
+    if loss_obj is not None:
+        loss_obj.loss_functions["UNet-F"].set_compute_dtype("fp32x3")
+    tr = DPTrainStep(net, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, loss_fn=loss_obj, graph=False)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(B, in_ch, lr_size, lr_size, generator=g).to(device)
+    tgt = torch.rand(B, in_ch, lr_size * sr, lr_size * sr, generator=g).to(device)
+    for _ in range(2):
+        tr.step(x, tgt)
+    torch.cuda.synchronize()
+    rec = Recorder(lib)
+    tr.use_graph = True
+    tr.capture_hook = lambda: rec
+    ok = tr.capture(x, tgt)
+    tr.capture_hook = None
+    xs, ts = tr._static if ok else (x, tgt)
+    tr.step(xs, ts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(xs, ts)
+    torch.cuda.synchronize()
+    d = (time.perf_counter() - t0) / steps
+    line = {"value": round(B / d, 3), "unit": "patches/s", "ms_per_step": round(1e3 * d, 3), "steps": steps, "per_gpu_batch": B,
+            "hip_graph": bool(ok), "dtype": "bf16", "loss": round(float(tr._loss_buf.item()), 6), "workload": cfg_name}
+    if loss_obj is not None:
+        line["unet_dtype"] = "fp32x3"
+        line["loss_network_ms"] = round(1e3 * d - e1_ms, 3)
+        line["loss_network_how"] = "this step minus the headline step of the same run (same network, same batch, L1 only)"
+        line["data"] = "synthetic (seg-UNet: seeded random init, the reference's loss/unet_oasis.pt is not in the repository)"
+    if name == "ws16" and ok and rec.calls:
+        for key, op in (("roofline", "rdst_wattn_fwd"), ("roofline_bwd", "rdst_wattn_bwd")):
+            calls = [(n, a) for n, a in rec.calls if n == op]
+            ms = _replay_calls(lib, calls, 2)
+            nbytes = sum(_alg(n, a, 2)[0] for n, a in calls) / len(calls)
+            ach = nbytes / (ms * 1e-3) / 1e9
+            line[key] = {"kernel": op + " (window 16)", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * ms, 2), "launches": len(calls)}
+    del tr, net, rec
+    torch.cuda.empty_cache()
+    return line
 
 
 def fp32_line(device, x, tgt, B, lib):

@@ -47,6 +47,44 @@ def test_bench_two_ranks_gloo_prints_one_line():
     assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) <= 0.01 * d["value"]
 
 
+def _torchrun_bench(extra, timeout=800):
+    """The DOCUMENTED command (bench.py:4-6), through the launcher: a fresh child of the pytest process, two ranks on the one
+    GPU of this box over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RDST_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+           "--warmup", "1", "--no-roofline", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_through_torch_distributed_run():
+    d = _torchrun_bench([])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["param_sync"] is True and d["config"]["hip_graph"] is True
+    # a scaling record explains itself: what the process group really was and what the collective cost
+    assert d["world_size_seen"] == 2 and d["backend"] == "gloo" and d["bucket_bytes"] == 4 * 4464961
+    assert d["all_reduce_ms"] > 0.0
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) <= 0.01 * d["value"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_config5_two_ranks_through_torch_distributed_run():
+    """BASELINE configs[4] (RDST-HRL: the seg-UNet label-hr loss in the backward path) on two ranks: equal parameters after the
+    steps, one all-reduced loss, and the replicated loss network ran the same number of BatchNorm batches on every rank."""
+    d = _torchrun_bench(["--config", "e1_hrl", "--batch", "2"])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["param_sync"] is True
+    assert d["config"]["unet_dtype"] == "fp32x3" and d["config"]["hip_graph"] is True
+    lo, hi = d["unet_bn_batches_tracked"]
+    assert lo == hi == 2 * (2 + 1 + 3)      # SR + HR pass per step: 2 eager steps, 1 warm-up and 3 timed replays (a capture executes nothing)
+    assert d["loss"] == d["loss"] and 0.0 < d["loss"] < 10.0
+
+
 def test_bench_refuses_mismatched_world_size():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
