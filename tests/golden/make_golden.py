@@ -246,6 +246,8 @@ def run_model_case(rv, st, name):
         keys = sorted(grads)
         out.update(y=y.detach().numpy(), target=tgt.numpy(), loss=np.float64(loss.item()), grad_keys=np.array(keys),
                    grad_l2=np.array([grads[k].double().norm().item() for k in keys]))
+        for k in keys:          # EVERY gradient elementwise (a permuted or sign-flipped gradient of equal norm must not pass)
+            out["grad::" + k] = grads[k].numpy()
     else:
         net.eval()
         with torch.no_grad():

@@ -91,6 +91,41 @@ def test_config5_train_step_all_gradients_vs_oracle_fp32(mode, layers):
     assert worst[0] <= (5e-3 if mode == "encoder-L1" else 8e-2), worst
 
 
+@pytest.mark.timeout(1800)
+def test_config5_label_hr_fp32_is_no_further_from_float64_than_the_fp32_oracle():
+    """The 4e-2 gate above, adjudicated: oracle(RDSTSR) -> oracle(SegUNet_F 'label-hr') evaluated in float64 is the truth; over
+    all 750 parameter gradients the HIP fp32 step must be no further from it than the fp32 oracles are (factor 2)."""
+    from util import build_net
+    cfg = O.CFG_E1
+    B, mode, layers = 2, "label-hr", []
+    sd = O.make_weights(cfg, 21)
+    net = build_net(cfg)
+    net.load_state_dict(sd, strict=True)
+    net.to(DEV).train()
+    sl, usd = _loss(mode, layers, "fp32")
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(B, 1, 64, 64, generator=g)
+    tgt = torch.rand(B, 1, 256, 256, generator=g)
+    loss, _ = sl(net(x.to(DEV)), tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    params = {k: p for k, p in net.named_parameters() if p.requires_grad}
+    ref = {}
+    for name, dt in (("o32", torch.float32), ("f64", torch.float64)):
+        osd = {k: ((v.to(dt) if v.dtype.is_floating_point else v).clone().requires_grad_(k in params)) if v.dtype.is_floating_point else v
+               for k, v in sd.items()}
+        uu = {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in usd.items()}
+        oy = O.rdstsr_forward(x.to(dt), osd, cfg)
+        (0.1 * F.l1_loss(oy, tgt.to(dt)) + S.segunet_loss(oy, tgt.to(dt), uu, mode, layers)).backward()
+        ref[name] = {k: osd[k].grad.double() for k in params}
+    d_hip = sum((params[k].grad.double().cpu() - ref["f64"][k]).norm().item() ** 2 for k in params) ** 0.5
+    d_o32 = sum((ref["o32"][k] - ref["f64"][k]).norm().item() ** 2 for k in params) ** 0.5
+    n64 = sum(ref["f64"][k].norm().item() ** 2 for k in params) ** 0.5
+    print(f"\nconfig 5 label-hr adjudicator: |hip32 - f64| = {d_hip / n64:.3e}, |oracle32 - f64| = {d_o32 / n64:.3e} (750 gradients, relative to |f64|)")
+    assert len(params) == 750
+    assert d_hip <= 2.0 * d_o32 + 1e-6 * n64, (d_hip / n64, d_o32 / n64)
+
+
 @pytest.mark.parametrize("mode,layers", [("encoder-L1", [1]), ("label-hr", [])])
 def test_config5_train_step_bf16_network_x3_loss(mode, layers):
     """What bench.py --config e1_unetf / e1_hrl runs: bf16 network + 'fp32x3' loss network.  d(loss)/d(SR) of a randomly

@@ -170,8 +170,19 @@ def test_next_row_models_vs_reference_fixture(name):
     assert np.abs(y.detach().cpu().numpy() - g["y"]).max() <= 1e-4
     assert abs(loss.item() - float(g["loss"])) <= 1e-6
     params = dict(net.named_parameters())
-    for k, l2 in zip([str(k) for k in g["grad_keys"]], g["grad_l2"]):
+    keys = [str(k) for k in g["grad_keys"]]
+    for k, l2 in zip(keys, g["grad_l2"]):
         assert abs(params[k].grad.double().norm().item() - l2) <= 1e-3 * max(l2, 1e-9), k
+    # every gradient of the reference, elementwise (relative L2 per tensor; the fixture stores all of them)
+    assert sum(1 for k in g if k.startswith("grad::")) == len(keys) > 10
+    for k in keys:
+        ref = g["grad::" + k]
+        got = params[k].grad.cpu().numpy()
+        assert got.shape == ref.shape, k
+        assert np.linalg.norm(got - ref) <= 1e-3 * max(np.linalg.norm(ref), 1e-12), k
+    for k, p in params.items():     # parameters the reference leaves without a gradient have none here either
+        if p.requires_grad and k not in keys:
+            assert p.grad is None, k
 
 
 def test_full_size_batch_independence_properties():
