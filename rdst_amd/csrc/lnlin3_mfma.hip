@@ -18,6 +18,12 @@
 #include "wattn_hd.h"
 #include <stdlib.h>
 
+#ifndef LB3_ABL
+#define LB3_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no weight-gradient MFMAs, 2 no data-gradient MFMAs (the wide chain), 4 no W gather, 8 no slab dump, 16 no LDS zeroing.
+                    // Round 4: with BOTH removed the K = 120, N = 360 launch goes from 53.7 to 50.9 us: the kernel is bound by its
+                    // load -> stash -> barrier skeleton (one tile of loads in flight per workgroup), not by its arithmetic
+#endif
+
 namespace {
 using namespace wahd;
 using MM = Mma<bf16>;
@@ -66,7 +72,10 @@ struct LB3 {
   // workgroups per CU: at most 2 (measured: up to 4 for the 3-5-wave shapes changes the tails by -1.0 / +2.3 / 0 us and
   // proj 60 by +1.2 us — more slabs and prologues, no more bandwidth)
   static constexpr int PERCU0 = 12 / NWV < 1 ? 1 : 12 / NWV;
-  static constexpr int PERCU1 = PERCU0 > 2 ? 2 : PERCU0;
+  // round 4: ONE workgroup per CU for the wide shapes: K = 60, N = 180 with two (6 waves each) 38.6 us, with one 33.1 us — the
+  // steady-state tile loop already streams at 4-5 TB/s (1.5-2.4 us per 32-token tile, measured by the slope over M), what a
+  // launch loses is its fixed part (W fragment gather, slab dump, first tile), and that is paid per workgroup
+  static constexpr int PERCU1 = WIDE ? 1 : PERCU0 > 2 ? 2 : PERCU0;
   static constexpr int PERCU = PERCU1 * SMEM > 160 * 1024 ? 1 : PERCU1;
   static constexpr int WPS = (NWV * PERCU + 3) / 4;                          // waves per SIMD (the launch bound)
 };
@@ -166,7 +175,7 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
   const bool has_acc = p.Acc != nullptr || p.Acc2 != nullptr;
 
   // ---- prologue: zero both tile buffers (pads, absent dX_add), ones column of x-hat ----
-  lds_zero16(smem, CF::SMEM, tid, NT);
+  if (!(LB3_ABL & 16)) lds_zero16(smem, CF::SMEM, tid, NT);
   __syncthreads();
   if (tid < 64) *reinterpret_cast<uint16_t*>(smem + (tid >> 5) * CF::BUF + (tid & 31) * LDX + K * 2) = 0x3f80;
 
@@ -218,7 +227,13 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int j = 0; j < TC; ++j) MM::mma(G[i][j], ya[i], xb[j]);   // rows = output features n, columns = channels (column K = d(bias))
+          for (int j = 0; j < TC; ++j) {
+#if !(LB3_ABL & 1)
+            MM::mma(G[i][j], ya[i], xb[j]);   // rows = output features n, columns = channels (column K = d(bias))
+#else
+            G[i][j][0] += __uint_as_float(ya[i].w[0] ^ xb[j].w[0]);
+#endif
+          }
       }
     }
     if (LN) __syncthreads();
@@ -232,7 +247,7 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int n0 = 32 * (gn * TN + i) + 8 * g4 + 4 * hh;
-          if (n0 < N && c <= K)
+          if (n0 < N && c <= K && !(LB3_ABL & 8))
             my[(int64_t)(n0 >> 2) * (K + 1) + c] =
                 make_uint2(pack_bf16x2(G[i][j][4 * g4], G[i][j][4 * g4 + 1]), pack_bf16x2(G[i][j][4 * g4 + 2], G[i][j][4 * g4 + 3]));
         }
@@ -255,7 +270,11 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int n = 16 * ks + 8 * hh + e;
+#if LB3_ABL & 4
+        const float w = 0.01f * (float)(n + cc);
+#else
         const float w = p.W[(size_t)(n < N ? n : N - 1) * K + cc];
+#endif
         f[e] = n < N ? w * gm : 0.f;
       }
       wf[ks] = MM::pack(f);
@@ -323,7 +342,13 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
     for (int v = 0; v < 16; ++v) dx[v] = 0.f;
     if constexpr (KN > 12) {   // one accumulation chain: the W fragments leave no room for a second accumulator
 #pragma unroll
-      for (int ks = 0; ks < KN; ++ks) MM::mma(dx, wf[ks], lds_pack(yrow + 32 * ks));   // rows = channels, columns = tokens
+      for (int ks = 0; ks < KN; ++ks) {
+#if !(LB3_ABL & 2)
+        MM::mma(dx, wf[ks], lds_pack(yrow + 32 * ks));   // rows = channels, columns = tokens
+#else
+        dx[0] += __uint_as_float(lds_pack(yrow + 32 * ks).w[0]);
+#endif
+      }
     } else {
       f32x16 d2;
 #pragma unroll

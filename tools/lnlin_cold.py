@@ -8,7 +8,8 @@ from rdst_amd import _lib
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-M, NBUF = 131072, 6
+import os
+M, NBUF = int(os.environ.get("LNM", "131072")), 6
 SHAPES = [(60, 180, 1), (90, 270, 1), (120, 360, 1), (60, 60, 0), (90, 90, 0), (120, 120, 0), (60, 30, 1), (90, 30, 1), (120, 30, 1)]
 a = [int(v) for v in sys.argv[1:]]
 if a:
