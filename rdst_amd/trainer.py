@@ -123,7 +123,9 @@ class DPTrainStep:
         if self._loss_buf is None:
             self._loss_buf = torch.zeros((), dtype=torch.float32, device=inputs.device)
         self._loss_buf.copy_(loss.detach())
-        loss.backward()
+        from . import ops
+        with ops.reduce_scope():         # every slab sum of the pass in a few launches at its end (bucket views: nobody reads them before)
+            loss.backward()
         self.bucket.gather()             # whatever was not written in place is flattened into the bucket
         return self._loss_buf
 
