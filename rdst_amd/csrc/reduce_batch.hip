@@ -5,8 +5,7 @@
 namespace rbatch {
 namespace {
 
-constexpr int MAXJ = 32;   // jobs per launch (2.9 KB of kernel arguments): a DenseSTLayer's backward queues 11 sums and 5 finishes, a whole
-                           // RDST-E1 backward under rdst_amd.trainer's step-wide batch ~170 and ~72 (6 + 3 launches instead of 24 + 24)
+constexpr int MAXJ = 16;   // jobs per launch: a DenseSTLayer's backward (2 Swin blocks + its tail Linear) queues 11 sums and 5 finishes
 struct SumBatch { SumJob j[MAXJ]; int first[MAXJ + 1]; int n; };   // first[k] = first block of job k
 struct FinBatch { FinJob j[MAXJ]; int first[MAXJ + 1]; int n; };
 

@@ -466,7 +466,6 @@ class _ReduceBatch:
     depth = 0
     keep: list = []
     fresh = 0
-    scoped = False    # a caller-owned batch around a whole backward pass is open (reduce_scope)
 
     @staticmethod
     def begin(lib):
@@ -511,35 +510,6 @@ class _ReduceBatch:
         _ReduceBatch.fresh = 0
 
 
-class reduce_scope:
-    """``with ops.reduce_scope():`` around ``loss.backward()``: ONE reduction batch for the whole backward pass — every slab
-    sum and LayerNorm finish of the step runs in a handful of launches at its end (RDST-E1: 6 + 3 instead of 24 + 24), the
-    slabs (~1.7 GB for E1 at batch 32) stay allocated until then.  Only sound when no gradient destination is read before
-    the pass ends, i.e. inside a ``FlatGradBucket.detach_grads()`` bracket (rdst_amd.trainer.DPTrainStep.fwd_bwd); any other
-    destination still settles at once (_ReduceBatch.settle), so the scope is never wrong, only less effective."""
-
-    def __enter__(self):
-        if TWO_STREAM_BACKWARD or _ReduceBatch.depth > 0:
-            self.mine = False
-            return self
-        self.mine = True
-        _ReduceBatch.scoped = True
-        _ReduceBatch.begin(_lib.load())
-        return self
-
-    def __exit__(self, et, ev, tb):
-        if not self.mine:
-            return False
-        _ReduceBatch.scoped = False
-        lib = _lib.load()
-        if et is None:
-            _ReduceBatch.depth = 1           # (a node that failed to close its own level cannot leave the scope open)
-            _ReduceBatch.end(lib)
-        else:
-            _ReduceBatch.abandon(lib)        # the pass died: its queued reductions name tensors that may be gone
-        return False
-
-
 class GradSink:
     """Carries the prefix slice of a dense join's gradient to the Swin block that consumed the prefix: `prefix` feeds
     the DenseSTLayer's body AND the join, so autograd would add the body's dX and this strided slice in a separate
@@ -574,8 +544,7 @@ class _DenseJoin(torch.autograd.Function):
             ctx.sink.extra = g[..., :ctx.c]
             if g.is_cuda and not TWO_STREAM_BACKWARD:
                 lib = _lib.load()
-                if not _ReduceBatch.scoped:
-                    _ReduceBatch.abandon(lib)   # (only after a backward that did not run to its end)
+                _ReduceBatch.abandon(lib)   # (only after a backward that did not run to its end)
                 _ReduceBatch.begin(lib)
                 ctx.sink.batch_open = True
             return None, g[..., ctx.c:], None, None

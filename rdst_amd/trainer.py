@@ -123,9 +123,11 @@ class DPTrainStep:
         if self._loss_buf is None:
             self._loss_buf = torch.zeros((), dtype=torch.float32, device=inputs.device)
         self._loss_buf.copy_(loss.detach())
-        from . import ops
-        with ops.reduce_scope():         # every slab sum of the pass in a few launches at its end (bucket views: nobody reads them before)
-            loss.backward()
+        # (One reduction batch around the WHOLE backward — 6 + 3 slab-sum launches instead of 24 + 24 — was measured in round 4:
+        # 17.6 -> 20.0 ms/step.  The ~1.7 GB of slabs then stay allocated until the end of the pass; per DenseSTLayer they are
+        # 22-30 MB buffers that the caching allocator hands out again and again, written and summed while still in the 256 MiB
+        # Infinity Cache.)
+        loss.backward()
         self.bucket.gather()             # whatever was not written in place is flattened into the bucket
         return self._loss_buf
 
