@@ -526,17 +526,19 @@ int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* 
     return launch_bwd<float>((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
                              scale, nslab, st);
 #ifndef RDST_K2_DMA
-#define RDST_K2_DMA 0   // 1: the round-4 re-cut (wattn_bwd_pair.hip: LDS-DMA ring, passes T / N without the P / dS images).  Measured
-                        // on MI355X it hides the row traffic (memory skeleton 53 us -> 16 us exposed) but its recomputed key-tile
-                        // pass makes it VALU-bound: 79 / 82 / 79 us cold at C = 60 / 90 / 120 against 77 / 81 / 82 for the kernel
-                        // below, 76.9 against 73.7 us inside the step — so it is not the default
+#define RDST_K2_DMA 4   // bit mask over the head dims 10 / 15 / 20 (1 / 2 / 4): which widths take the round-4 re-cut (wattn_bwd_pair.hip:
+                        // LDS-DMA ring of section sets, loader / storer waves, passes T / N without the P / dS images).  It hides the row
+                        // traffic but is VALU-bound by its recomputed key-tile pass; inside the step (rocprofv3, profiles/r04f_*) it
+                        // takes 65.7 / 69.9 / 69.1 us at C = 60 / 90 / 120 against 64.6 / 70.0 / 72.7 for the kernel below: C = 120 only
 #endif
-#if RDST_K2_DMA
-  {
-    const int rc = wattn_bwd_pair(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
-    if (rc != RDST_ENOTSUP) return rc;
+  if (g.heads == 6 && g.C % 6 == 0) {
+    const int d6 = g.C / 6;
+    const int bit = d6 == 10 ? 1 : d6 == 15 ? 2 : d6 == 20 ? 4 : 0;
+    if (RDST_K2_DMA & bit) {
+      const int rc = wattn_bwd_pair(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
+      if (rc != RDST_ENOTSUP) return rc;
+    }
   }
-#endif
   {  // the compile-time-specialised kernel (6 heads of dim 10/15/20) where it applies
     const int rc = wattn_bwd_mfma_hd(qkv, ld, table, dout, ldd, dqkv, ldq, slab, slab_rows, g, scale, nslab, st);
     if (rc != RDST_ENOTSUP) return rc;
