@@ -526,10 +526,12 @@ int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* 
     return launch_bwd<float>((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
                              scale, nslab, st);
 #ifndef RDST_K2_DMA
-#define RDST_K2_DMA 4   // bit mask over the head dims 10 / 15 / 20 (1 / 2 / 4): which widths take the round-4 re-cut (wattn_bwd_pair.hip:
+#define RDST_K2_DMA 6   // bit mask over the head dims 10 / 15 / 20 (1 / 2 / 4): which widths take the round-4 re-cut (wattn_bwd_pair.hip:
                         // LDS-DMA ring of section sets, loader / storer waves, passes T / N without the P / dS images).  It hides the row
-                        // traffic but is VALU-bound by its recomputed key-tile pass; inside the step (rocprofv3, profiles/r04f_*) it
-                        // takes 65.7 / 69.9 / 69.1 us at C = 60 / 90 / 120 against 64.6 / 70.0 / 72.7 for the kernel below: C = 120 only
+                        // traffic but is VALU-bound by its recomputed key-tile pass.  Same box, cold, "K2 + table reduce" per call at
+                        // C = 60 / 90 / 120: 77.6-80.7 / 78.9 / 78.8 us against 76.0 / 80.5 / 82.5 for the kernel below; inside the step
+                        // (rocprofv3, profiles/r04f_*, before the loaders' cheaper issue code) 65.7 / 69.9 / 69.1 against 64.6 / 70.0 / 72.7:
+                        // C = 90 and C = 120 take it, C = 60 (where the old kernel's arithmetic is the cheaper one) does not
 #endif
   if (g.heads == 6 && g.C % 6 == 0) {
     const int d6 = g.C / 6;

@@ -188,8 +188,10 @@ __device__ __forceinline__ void pass_t(const Ctx& c, f32x16& dq, f32x16 (&Dsum)[
     const_cast<LDS_AS float*>(c.st)[tok] = __builtin_amdgcn_logf(l) - nm;
     const_cast<LDS_AS float*>(c.st)[NH * 64 + tok] = -delta;
   }
-  // dS = P (dP - delta) = e ((dP - delta) / l)
-  const float ndi = -delta * inv;
+  // dS = P (dP - delta) = e ((dP - delta) / l), times `scale` (dQ = scale K^T dS^T: the factor rides on the two per-row
+  // constants instead of on the 16 values of the dQ tile; the d(table) sums take it out again in the epilogue)
+  const float invs = inv * c.scale;
+  const float ndi = -delta * invs;
   Pack16 pdS[2][2];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
@@ -198,7 +200,7 @@ __device__ __forceinline__ void pass_t(const Ctx& c, f32x16& dq, f32x16 (&Dsum)[
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int v0 = 8 * s + 2 * e;
-        pdS[kt][s].w[e] = pack_bf16x2(X[kt][v0] * __builtin_fmaf(Y[kt][v0], inv, ndi), X[kt][v0 + 1] * __builtin_fmaf(Y[kt][v0 + 1], inv, ndi));
+        pdS[kt][s].w[e] = pack_bf16x2(X[kt][v0] * __builtin_fmaf(Y[kt][v0], invs, ndi), X[kt][v0 + 1] * __builtin_fmaf(Y[kt][v0 + 1], invs, ndi));
       }
   // dQ^T (rows = channels OG .. OG+31, cols = queries) = K^T . dS^T;  d(table) partial sums += I . dS^T
 #pragma unroll
@@ -370,6 +372,34 @@ __global__ void __launch_bounds__(NTH, 3) wattn_bwd_pair_kernel(const PArgs p) {
   // 63) are switched off, pad slots read out of range (zeros).  Loader wave w issues pieces w, w + NLW, ...
   auto issue = [&](const WinPos& w, int buf, int lane) {
     const int rl = lane / S, sl = lane - rl * S;
+    if constexpr (CF::RPP == 4 && NH == HEADS_ALL) {
+      // four rows per piece = half a window row: the row base is wave-uniform (scalar unit), a lane only adds its column —
+      // ~4 vector instructions per piece instead of ~14 (the loader waves' issue code sits in front of pass T, on the path to
+      // the first barrier of the window)
+      int colv[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        int cc = w.wc * 8 + 4 * hf + (rl & 3) + g.shift;
+        if (cc >= g.W) cc -= g.W;
+        colv[hf] = cc;
+      }
+      const bool on = rl < 4, data = sl < SD;
+      const uint32_t sloff = (uint32_t)(sl * 16);
+#pragma unroll
+      for (int i = 0; i < CF::PPW; ++i) {
+        const int pc = wv + NLW * i;                     // wave-uniform
+        const int sec = pc / CF::PPS, pl = pc - sec * CF::PPS;
+        const bool is_do = sec == 3;
+        int rr = w.wr * 8 + (pl >> 1) + g.shift;         // window row pl / 2 (scalar)
+        if (rr >= g.H) rr -= g.H;
+        const int rb = (w.b * g.H + rr) * g.W;
+        const uint32_t t = (uint32_t)(rb + colv[pl & 1]);
+        const uint32_t off = data ? t * (is_do ? lddb : ldb) + (uint32_t)((is_do ? 0 : sec * CF::CFULL) * 2) + sloff : 0xffffffffu;
+        if (on)
+          dma(is_do ? rs_do : rs_qkv, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(buf * CF::BUFB + sec * CF::SECB + pl * 4 * ldt)), off);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < CF::PPW; ++i) {
       const int pc = wv + NLW * i;                     // wave-uniform
@@ -508,7 +538,7 @@ __global__ void __launch_bounds__(NTH, 3) wattn_bwd_pair_kernel(const PArgs p) {
 #if !(K2P_ABL & 4)
 #define K2P_ST(HD)                                                                               \
     {                                                                                            \
-      store_tile_rows<CF::og(HD), HD * D, HD * D + D>(c.own + CF::OFF_Q, dq, c.scale, c.h);      \
+      store_tile_rows<CF::og(HD), HD * D, HD * D + D>(c.own + CF::OFF_Q, dq, 1.0f, c.h);         \
       store_tile_rows<CF::og(HD), HD * D, HD * D + D>(c.own + CF::OFF_K, dk, c.scale, c.h);      \
       store_tile_rows<CF::og(HD), HD * D, HD * D + D>(c.own + CF::OFF_V, dv, 1.0f, c.h);         \
     }
@@ -610,7 +640,7 @@ __global__ void __launch_bounds__(NTH, 3) wattn_bwd_pair_kernel(const PArgs p) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int yj = kt * 4 + (v >> 2), xj = (v & 3) + 4 * h;
-        ds[(hd * 64 + yi * 8 + xi) * 65 + yj * 8 + xj] = Dsum[kt][v];
+        ds[(hd * 64 + yi * 8 + xi) * 65 + yj * 8 + xj] = Dsum[kt][v] * rscale;   // (pass T accumulated scale * dS)
       }
   }
   __syncthreads();

@@ -32,6 +32,7 @@ PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_B
 KERNELS = {
     "wattn_fwd_hd_kernel": ("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"]),
     "wattn_bwd_hd_kernel": ("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"]),
+    "wattn_bwd_pair_kernel": ("wattn_bwd_pair_kernel", ["wattn_bwd_pair.hip", "wattn_hd.h"]),
     "conv3_kernel": ("conv3_kernel", ["conv3_mfma.hip"]),
     "conv3_wgrad_kernel": ("conv3_wgrad_kernel", ["conv3_wgrad.hip"]),
     "lin_mfma_kernel": ("lin_mfma_kernel", ["linear_mfma.hip"]),
