@@ -292,17 +292,31 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
   };
 
   // ---- per-lane LDS positions (loop invariant) ------------------------------------------------------------
+  // Bank rules (tools/lds_banks.py; rows are an odd number of 16-B slots long for the b128 row reads): a transposed read
+  // takes four rows FOUR APART (c, c+4, c+8, c+12: their 64-byte segments tile the 256-byte bank row exactly; four
+  // consecutive rows overlap, 2-way), so
+  //   * row i of the phase-1 MFMAs (lane r = i) is the tile's LDS row sg = sigma(i), sigma(16s + 8x + 4h + q) =
+  //     16s + 4q + 2x + h: the accumulator registers of a lane half then hold LDS rows {4q + hh} and {4q + hh + 2}
+  //     (+ 16s), which is what the phase-2 reads fetch; phase 3's token of lane r is sigma(r) as well;
+  //   * the contraction order of phase 3 over a 16-block of hidden units is 4q + hh + 2x for W1^T, and the dHp image
+  //     keeps hidden unit 16k + 4q + y at row 16k + 4y + q (consecutive rows of a 64-byte-row image ARE the exact
+  //     tiling), its 8-byte pieces XOR-swizzled by (row >> 1) & 7 so that the 16 lanes of a ds_write_b64 group land on
+  //     32 different banks (unswizzled: 8-way).
   const int q = (lane & 15) >> 2, pp = lane & 3, gq1 = (lane >> 4) & 1;
-  const lds_cp xrow = (lds_cp)(smem + CF::OFF_XH + r * LDX + hh * 16);
-  const lds_cp yrow = (lds_cp)(smem + CF::OFF_DY + r * LDX + hh * 16);
+  const int sg = (r & 16) + 4 * (r & 3) + ((r >> 2) & 1) + 2 * ((r >> 3) & 1);
+  const lds_cp xrow = (lds_cp)(smem + CF::OFF_XH + sg * LDX + hh * 16);
+  const lds_cp yrow = (lds_cp)(smem + CF::OFF_DY + sg * LDX + hh * 16);
   const lds_cp wrow = (lds_cp)(smem + CF::OFF_W1 + j * LDW + hh * 16);
-  const lds_cp dhw = (lds_cp)(smem + CF::OFF_DH + j * CF::LDH + 8 * hh);
-  // transposed reads: token order of the accumulator registers (rows 4hh+q, then +8) for the weight gradients,
-  // natural k order (rows 8hh+q, then +4) for the data gradient
-  const lds_cp xtr = (lds_cp)(smem + CF::OFF_XH + (4 * hh + q) * LDX + (16 * gq1 + 4 * pp) * 2);
-  const lds_cp ytr = (lds_cp)(smem + CF::OFF_DY + (4 * hh + q) * LDX + (16 * gq1 + 4 * pp) * 2);
-  const lds_cp wtr = (lds_cp)(smem + CF::OFF_W1 + (8 * hh + q) * LDW + (16 * gq1 + 4 * pp) * 2 + wave * 64);
-  const lds_cp dtr = (lds_cp)(smem + CF::OFF_DH + (8 * hh + q) * CF::LDH + (16 * gq1 + 4 * pp) * 2);
+  const int dhpos = 32 * wave + (r & 16) + 4 * (r & 3) + ((r >> 2) & 3);          // image row of hidden unit j
+  const uint32_t dho = (uint32_t)dhpos * CF::LDH + 8u * ((dhpos >> 1) & 7);        // piece P of it: dho ^ (8 P)
+  const lds_cp dhb = (lds_cp)(smem + CF::OFF_DH);
+  // transposed reads: rows 4q + hh (then + 2) of the tiles and of W1; rows 4hh + q (then + 8) of the dHp image
+  const lds_cp xtr = (lds_cp)(smem + CF::OFF_XH + (4 * q + hh) * LDX + (16 * gq1 + 4 * pp) * 2);
+  const lds_cp ytr = (lds_cp)(smem + CF::OFF_DY + (4 * q + hh) * LDX + (16 * gq1 + 4 * pp) * 2);
+  const lds_cp wtr = (lds_cp)(smem + CF::OFF_W1 + (4 * q + hh) * LDW + (16 * gq1 + 4 * pp) * 2 + wave * 64);
+  const lds_cp dtr0 = dhb + (4 * hh + q) * CF::LDH + 8 * ((4 * gq1 + pp) ^ ((2 * hh + (q >> 1)) & 7));
+  const lds_cp dtr1 = dhb + (4 * hh + 8 + q) * CF::LDH + 8 * ((4 * gq1 + pp) ^ ((2 * hh + 4 + (q >> 1)) & 7));
+  static_assert(CF::LDH == 64 && CF::OFF_DH % 64 == 0, "dHp image: 64-byte rows, XOR swizzle of the 8-byte pieces");
 
   f32x16 G1[NCT], W2g[NCT];
 #pragma unroll
@@ -376,8 +390,8 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
         // dHp -> [hidden][token] image: registers 8s..8s+3 are tokens 16s+4hh.., 8s+4..8s+7 tokens 16s+8+4hh..
         u32x2_t lo, hi;
         lo.x = dA[s].w[0]; lo.y = dA[s].w[1]; hi.x = dA[s].w[2]; hi.y = dA[s].w[3];
-        *reinterpret_cast<LDS_AS u32x2_t*>(dhw + 32 * s) = lo;
-        *reinterpret_cast<LDS_AS u32x2_t*>(dhw + 32 * s + 16) = hi;
+        *reinterpret_cast<LDS_AS u32x2_t*>(dhb + (dho ^ (uint32_t)(8 * (4 * s + hh)))) = lo;
+        *reinterpret_cast<LDS_AS u32x2_t*>(dhb + (dho ^ (uint32_t)(8 * (4 * s + 2 + hh)))) = hi;
       }
     }
     __syncthreads();   // B2: dHp image complete
@@ -388,8 +402,8 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const Pack16 xb = lds_tr_pack(xtr + 16 * s * LDX + ct * 64, xtr + (16 * s + 8) * LDX + ct * 64);
-        const Pack16 yb = lds_tr_pack(ytr + 16 * s * LDX + ct * 64, ytr + (16 * s + 8) * LDX + ct * 64);
+        const Pack16 xb = lds_tr_pack(xtr + 16 * s * LDX + ct * 64, xtr + (16 * s + 2) * LDX + ct * 64);
+        const Pack16 yb = lds_tr_pack(ytr + 16 * s * LDX + ct * 64, ytr + (16 * s + 2) * LDX + ct * 64);
         MM::mma(G1[ct], dA[s], xb);    // rows = hidden units, columns = channels (column C = d(bias))
         MM::mma(W2g[ct], hA[s], yb);
       }
@@ -403,20 +417,20 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
       if (!(MLP_DBG(p) & 8))
 #pragma unroll
       for (int kk = 0; kk < CF::KJ; kk += 2) {
-        const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 4) * LDW);
-        const Pack16 db = lds_tr_pack(dtr + 16 * kk * CF::LDH, dtr + (16 * kk + 4) * CF::LDH);
-        const Pack16 wa2 = lds_tr_pack(wtr + 16 * (kk + 1) * LDW, wtr + (16 * (kk + 1) + 4) * LDW);
-        const Pack16 db2 = lds_tr_pack(dtr + 16 * (kk + 1) * CF::LDH, dtr + (16 * (kk + 1) + 4) * CF::LDH);
+        const Pack16 wa = lds_tr_pack(wtr + 16 * kk * LDW, wtr + (16 * kk + 2) * LDW);
+        const Pack16 db = lds_tr_pack(dtr0 + 16 * kk * CF::LDH, dtr1 + 16 * kk * CF::LDH);
+        const Pack16 wa2 = lds_tr_pack(wtr + 16 * (kk + 1) * LDW, wtr + (16 * (kk + 1) + 2) * LDW);
+        const Pack16 db2 = lds_tr_pack(dtr0 + 16 * (kk + 1) * CF::LDH, dtr1 + 16 * (kk + 1) * CF::LDH);
         MM::mma(dx, wa, db);   // rows = channels, columns = tokens
         MM::mma(dx2, wa2, db2);
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) dx[v] += dx2[v];
-      rstd = sm[r];
+      rstd = sm[sg];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_XH + r * LDX) + (32 * wave + 8 * g4 + 4 * hh) * 2);
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_XH + sg * LDX) + (32 * wave + 8 * g4 + 4 * hh) * 2);
         const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -442,14 +456,14 @@ __global__ void __launch_bounds__(128 * NCT, 2) mlp_bwd_kernel(const MlpArgs p) 
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int cb = (32 * wave + 8 * g4 + 4 * hh) * 2;
-        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_XH + r * LDX) + cb);
-        const u32x2_t yv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_DY + r * LDX) + cb);
+        const u32x2_t xv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_XH + sg * LDX) + cb);
+        const u32x2_t yv = *reinterpret_cast<const LDS_AS u32x2_t*>((lds_cp)(smem + CF::OFF_DY + sg * LDX) + cb);
         const float xh[4] = {bf16lo(xv.x), bf16hi(xv.x), bf16lo(xv.y), bf16hi(xv.y)};
         const float dy[4] = {bf16lo(yv.x), bf16hi(yv.x), bf16lo(yv.y), bf16hi(yv.y)};
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[4 * g4 + e] = fmaf(rstd, dx[4 * g4 + e] - s1 - xh[e] * s2, dy[e]);
       }
-      const int64_t row = tile * 32 + r;
+      const int64_t row = tile * 32 + sg;   // the lane's token
       if (row < p.M) {
         bf16* drow = p.dX + row * p.lddx;
 #pragma unroll
