@@ -99,7 +99,7 @@ __device__ __forceinline__ void bw_phase_a(const BwCtx& c, Pack16 (&pP)[2][2], P
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int v = 0; v < 16; v += 2) {
-      const f32x2 b2 = tbh[((7 - (kt * 4 + (v >> 2))) * TSX + (v & 3)) / 2];
+      const f32x2 b2 = lds_read_f32x2(tbh + ((7 - (kt * 4 + (v >> 2))) * TSX + (v & 3)) / 2);
       X[kt][v] = b2.x;
       X[kt][v + 1] = b2.y;
       Y[kt][v] = 0.f;

@@ -134,7 +134,7 @@ __device__ __forceinline__ void pass_t(const Ctx& c, f32x16& dq, f32x16 (&Dsum)[
     for (int v = 0; v < 16; v += 2) {
       // bias of (query on the lane, key kt*4 + (v >> 2), 4 h + (v & 3)): natural column xi + 7 - 4 h - (v & 3) — the pair
       // (v, v + 1) lies at descending columns, so the aligned 8-byte read returns it swapped
-      const f32x2 b2 = tbh[((7 - (kt * 4 + (v >> 2))) * TSX + (2 - (v & 3))) / 2];
+      const f32x2 b2 = lds_read_f32x2(tbh + ((7 - (kt * 4 + (v >> 2))) * TSX + (2 - (v & 3))) / 2);
       X[kt][v] = b2.y;
       X[kt][v + 1] = b2.x;
       Y[kt][v] = 0.f;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void pass_n(const Ctx& c, f32x16& dv, f32x16& dk) {
       const f32x4 nd = st4[(NH * 64) / 4 + qt * 8 + 2 * g4];
 #pragma unroll
       for (int e = 0; e < 4; e += 2) {
-        const f32x2 b2 = tnh[((qt * 4 + g4) * TSX + e) / 2];
+        const f32x2 b2 = lds_read_f32x2(tnh + ((qt * 4 + g4) * TSX + e) / 2);
         X[qt][4 * g4 + e] = b2.x;
         X[qt][4 * g4 + e + 1] = b2.y;
       }
