@@ -59,6 +59,11 @@ int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out,
                      float scale, hipStream_t st);
 int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
                      int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
+// 16x16 windows in exact fp32 on the matrix cores (wattn16_f32.hip); RDST_ENOTSUP otherwise
+int wattn16_fwd_f32(const float* qkv, int64_t ld, const float* table, float* out, int64_t ldo, const WinGeom& g, float scale,
+                    hipStream_t st);
+int wattn16_bwd_f32(const float* qkv, int64_t ld, const float* table, const float* dout, int64_t ldd, float* dqkv, int64_t ldq,
+                    float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
 int wattn_bwd_pair(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv, int64_t ldq,
                    float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
 int wattn_bwd_mfma_hd(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,

@@ -15,9 +15,11 @@
 //     (every lane reads aligned 8-byte pairs).
 // The kernel is bound by the softmax on the vector ALUs (256 x 256 x 6 exponentials per window), not by HBM.
 #include "wattn_hd.h"
+#include "wattn16.h"
 
 namespace {
 using namespace wahd;
+using namespace w16c;
 
 struct W16Args {
   const bf16* qkv; int64_t ld;
@@ -48,14 +50,6 @@ struct W16 {
   static constexpr int TABF = 31 * TROW + 16;
   static constexpr int NKS = (GC + 15) / 16;         // k-steps over the pair's channels
 };
-
-__device__ __forceinline__ int64_t win_token16(int b, int wr, int wc, int t, const WinGeom& g) {
-  int r = wr * 16 + (t >> 4) + g.shift;
-  if (r >= g.H) r -= g.H;
-  int c = wc * 16 + (t & 15) + g.shift;
-  if (c >= g.W) c -= g.W;
-  return ((int64_t)b * g.H + r) * g.W + c;
-}
 
 // workgroup -> (window, head pair): the three pairs of a window run on the same XCD (blockIdx round-robins over 8 XCDs)
 __device__ __forceinline__ void w16_locate(int nwin, int& win, int& grp) {
@@ -354,18 +348,6 @@ struct W16BCtx {
 
 __device__ __forceinline__ Pack16 tr_pack(lds_cp p, int ldt) { return lds_tr_pack(p, p + 8 * ldt); }
 
-// lane i of every 16-lane row reads lane i - N (shr) / i + N (shl) of its row, 0 outside
-template <int N> __device__ __forceinline__ float dpp_row_shr(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xf, 0xf, true));
-}
-template <int N> __device__ __forceinline__ float dpp_row_shl(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x100 + N, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float other_half(float x, int h) {   // the value of lane ^ 32
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(h ? r[0] : r[1]);
-}
-
 template <int D, int HL>
 __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
   using CF = W16<D>;
@@ -473,20 +455,6 @@ __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
       for (int e = 0; e < 4; ++e) pb.w[e] = pack_bf16x2(dp[8 * s + 2 * e], dp[8 * s + 2 * e + 1]);
       Mma<bf16>::mma(dq, tr_pack(c.Ktr + RL * 2 + (kt * 32 + 16 * s) * ldt, ldt), pb);   // rows = channels (K^T), cols = queries
     }
-  }
-}
-
-// fixed-order sum of the row sums of one head: entry (dy, dx) <- sum over yi - yj = dy - 15 of part[yi][yj][dx]
-template <int D>
-__device__ __forceinline__ void w16_dtable_out(const float* part, float* slab_row, int tid) {
-  for (int idx = tid; idx < 961; idx += 512) {
-    const int ry = idx / 31, rx = idx - ry * 31;
-    float sum = 0.f;
-    for (int yi = 0; yi < 16; ++yi) {
-      const int yj = yi + 15 - ry;
-      if (yj >= 0 && yj < 16) sum += part[(yi * 16 + yj) * 32 + rx];
-    }
-    slab_row[idx] = sum;
   }
 }
 
@@ -708,13 +676,13 @@ __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
   w16_bwd_p1<D, 0>(c, dq0);
 #endif
   __syncthreads();
-  if (!(W16_ABL & 4)) w16_dtable_out<D>(part, slab_row, tid);
+  if (!(W16_ABL & 4)) w16_dtable_out(part, slab_row, tid);
   __syncthreads();
 #if !(W16_ABL & 1)
   w16_bwd_p1<D, 1>(c, dq1);
 #endif
   __syncthreads();
-  if (!(W16_ABL & 4)) w16_dtable_out<D>(part, slab_row + 961, tid);
+  if (!(W16_ABL & 4)) w16_dtable_out(part, slab_row + 961, tid);
   {  // pass 2: wave = key tile wv
     c.kt = wv;
     c.QA = (lds_cp)(Qs + r * ldt + h * 16);

@@ -522,9 +522,13 @@ int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* 
                    int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int dtype, int* nslab,
                    hipStream_t st) {
   if (mfma_disabled()) return RDST_ENOTSUP;
-  if (dtype == RDST_F32)
+  if (dtype == RDST_F32) {
+    const int rc = wattn16_bwd_f32((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
+                                   scale, nslab, st);   // 16x16 windows
+    if (rc != RDST_ENOTSUP) return rc;
     return launch_bwd<float>((const float*)qkv, ld, table, (const float*)dout, ldd, (float*)dqkv, ldq, slab, slab_rows, g,
                              scale, nslab, st);
+  }
 #ifndef RDST_K2_DMA
 #define RDST_K2_DMA 6   // bit mask over the head dims 10 / 15 / 20 (1 / 2 / 4): which widths take the round-4 re-cut (wattn_bwd_pair.hip:
                         // LDS-DMA ring of section sets, loader / storer waves, passes T / N without the P / dS images).  It hides the row

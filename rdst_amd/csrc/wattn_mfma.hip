@@ -374,7 +374,11 @@ int launch_fwd(const T* qkv, int64_t ld, const float* table, T* out, int64_t ldo
 int wattn_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
                    float scale, int dtype, hipStream_t st) {
   if (mfma_disabled()) return RDST_ENOTSUP;
-  if (dtype == RDST_F32) return launch_fwd<float>((const float*)qkv, ld, table, (float*)out, ldo, g, scale, st);
+  if (dtype == RDST_F32) {
+    const int rc = wattn16_fwd_f32((const float*)qkv, ld, table, (float*)out, ldo, g, scale, st);   // 16x16 windows
+    if (rc != RDST_ENOTSUP) return rc;
+    return launch_fwd<float>((const float*)qkv, ld, table, (float*)out, ldo, g, scale, st);
+  }
   {  // the compile-time-specialised kernel (6 heads of dim 10/15/20) where it applies
     const int rc = wattn_fwd_mfma_hd(qkv, ld, table, out, ldo, g, scale, st);
     if (rc != RDST_ENOTSUP) return rc;

@@ -142,3 +142,41 @@ def test_wattn16_bf16(B, H, W, C, shift):
     assert (q.grad.float().cpu() - q_ref.grad).norm().item() <= 2e-2 * q_ref.grad.norm().item()
     rel = (t.grad.cpu() - t_ref.grad).norm().item() / t_ref.grad.norm().item()
     assert rel <= 2e-2, rel
+
+
+@pytest.mark.parametrize("B,H,W,C,shift", WS16_CASES)
+def test_wattn16_fp32_mfma_vs_oracle(B, H, W, C, shift):
+    """16 x 16 windows in the reference's own arithmetic (exact-fp32 matrix-core kernels, wattn16_f32.hip: BASELINE
+    configs[3] without bf16) vs the oracle, forward and backward: relative L2 <= 2e-6 on the output and on every gradient
+    (fp32 sums in a different order, expf vs the CPU's exp)."""
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    heads, ws = 6, 16
+    scale = (C // heads) ** -0.5
+    qkv = _rand((B, H, W, 3 * C), 21)
+    table = _rand(((2 * ws - 1) ** 2, heads), 22, 0.5)
+    gout = _rand((B, H, W, C), 23)
+
+    q_ref = qkv.clone().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout)
+
+    q = qkv.to(dev).requires_grad_(True)
+    t = table.to(dev).requires_grad_(True)
+    o = ops.window_attention(q, t, H, W, heads, ws, shift, scale)
+    o.backward(gout.to(dev))
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return (a.cpu().double() - b.double()).norm().item() / b.double().norm().item()
+
+    assert rel(o, o_ref) <= 2e-6, rel(o, o_ref)
+    assert rel(q.grad, q_ref.grad) <= 2e-6, rel(q.grad, q_ref.grad)
+    assert rel(t.grad, t_ref.grad) <= 2e-6, rel(t.grad, t_ref.grad)
+    assert (o.cpu() - o_ref).abs().max().item() <= 2e-5
+    assert (q.grad.cpu() - q_ref.grad).abs().max().item() <= 5e-5
+    # the three sections separately (a wrong dK / dV of small norm must not hide behind dQ)
+    for s3, name in enumerate(("dq", "dk", "dv")):
+        a, b_ = q.grad[..., s3 * C:(s3 + 1) * C], q_ref.grad[..., s3 * C:(s3 + 1) * C]
+        assert rel(a, b_) <= 3e-6, (name, rel(a, b_))
