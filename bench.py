@@ -571,7 +571,34 @@ def extra_config(name, device, lib, e1_ms, steps=5):
                          "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * ms, 2), "launches": len(calls)}
     del tr, net, rec
     torch.cuda.empty_cache()
+    if name == "ws16":   # the same configuration in the reference's own arithmetic (exact-fp32 matrix-core kernels, wattn16_f32.hip)
+        try:
+            line["fp32_mode"] = _fp32_step_line(device, cfg, x, tgt, B, steps=3)
+        except Exception as e:  # noqa: BLE001
+            line["fp32_mode"] = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     return line
+
+
+def _fp32_step_line(device, cfg, x, tgt, B, steps):
+    from rdst_amd.trainer import DPTrainStep
+    net32 = build_net(device, torch.float32, cfg)
+    t32 = DPTrainStep(net32, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, graph=False)
+    for _ in range(2):
+        t32.step(x, tgt)
+    torch.cuda.synchronize()
+    t32.use_graph = True
+    ok = t32.capture(x, tgt)
+    xs, ts = t32._static if ok else (x, tgt)
+    t32.step(xs, ts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t32.step(xs, ts)
+    torch.cuda.synchronize()
+    d = (time.perf_counter() - t0) / steps
+    return {"value": round(B / d, 3), "unit": "patches/s", "ms_per_step": round(1e3 * d, 3), "steps": steps, "per_gpu_batch": B,
+            "hip_graph": bool(ok), "dtype": "fp32", "loss": round(float(t32._loss_buf.item()), 6)}
 
 
 def fp32_line(device, x, tgt, B, lib):
