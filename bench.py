@@ -701,7 +701,17 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         kname, bound_note = "rdst_wattn_fwd (K1, window 16: wattn16_fwd_kernel)", "vector ALU (256 x 256 x 6 exponentials per window); priced against HBM as north_star asks"
     else:
         traffic, tsrc = _pmc_traffic("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"])
-        t2, t2src = _pmc_traffic("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"])
+        # K2 is two kernels since round 4 (wattn_bwd_mfma.hip, RDST_K2_DMA = 6): C = 60 on wattn_bwd_hd_kernel, C = 90 / 120 on
+        # wattn_bwd_pair_kernel; the per-launch traffic of the family is the launch-weighted mean of the two collections
+        ta, tasrc = _pmc_traffic("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"])
+        tb, tbsrc = _pmc_traffic("wattn_bwd_pair_kernel", ["wattn_bwd_pair.hip", "wattn_hd.h"])
+        n60 = sum(1 for _, a in groups["rdst_wattn_bwd"] if a[15] == 60)
+        nall = len(groups["rdst_wattn_bwd"])
+        if ta is not None and tb is not None and nall:
+            t2 = int((n60 * ta + (nall - n60) * tb) / nall)
+            t2src = f"{n60} launches x wattn_bwd_hd_kernel ({ta} B) + {nall - n60} x wattn_bwd_pair_kernel ({tb} B): {tasrc}"
+        else:
+            t2, t2src = None, (tasrc if ta is None else tbsrc)
         kname, bound_note = "rdst_wattn_fwd (K1, window attention forward)", None
     ach = k1_bytes / (k1_ms * 1e-3) / 1e9
     out["roofline"] = {"kernel": kname, "bound": "hbm",

@@ -17,9 +17,11 @@ cd $R
 f=$(find $O/trace -name '*kernel_trace.csv' | head -1)
 python3 tools/cold_from_trace.py $f wattn_fwd_hd_kernel > $O/k1_cold_vs_step.txt
 python3 tools/cold_from_trace.py $f wattn_bwd_hd_kernel > $O/k2_cold_vs_step.txt
+python3 tools/cold_from_trace.py $f wattn_bwd_pair_kernel >> $O/k2_cold_vs_step.txt
 rm -rf $O/trace
 python3 tools/pmc_collect.py $T/pmc_e1 e1 > $O/pmc_e1.log 2>&1
 python3 tools/pmc_collect.py $T/pmc_ws16 ws16 gpurun_out/$T/pmc_e1_pmc.json > $O/pmc_ws16.log 2>&1
 python3 tools/pmc_collect.py $T/pmc_all e1_hrl gpurun_out/$T/pmc_ws16_pmc.json > $O/pmc_hrl.log 2>&1
 rm -rf $O/pmc_e1 $O/pmc_ws16 $O/pmc_all
+bash tools/prof_tool.sh $T/w16f32 tools/wattn16_bench.py 8 fp32 > /dev/null 2>&1   # the exact-fp32 window-16 kernels at the bench shape
 ls -la $O
