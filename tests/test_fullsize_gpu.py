@@ -381,19 +381,13 @@ def test_e1_bf16_train_step_all_gradients_vs_oracle_bench_batch():
     _e1_all_gradients(32)
 
 
-def test_ws16_bf16_train_step_all_gradients_vs_oracle():
-    """BASELINE configs[3] (3-channel x2, 128x128 -> 256x256, window 16, the E1 widths) in the bf16 mode: every trainable
-    tensor's gradient against the fp32 oracle, batch 2 (128 windows per layer: wattn16_mfma.hip forward and backward in all
-    48 Swin blocks, shifted and not, with the region masks of the last window row / column).  Same stated tolerances as the
-    E1 test except per tensor: rel L2 <= 4.5e-2 (B = 2 is 8192 tokens, a sixteenth of the E1 test's: the 961-entry bias tables
-    sit at 3.0e-2..3.7e-2, measured), total <= 1.2e-2 (measured 4.8e-3), |dPSNR| < 0.05 dB."""
+def _ws16_all_gradients(dtype, B, tol_tensor, tol_total, tol_dpsnr, tol_loss):
     from util import build_net
     cfg = O.CFG_WS16
-    B = 2
     sd = O.make_weights(cfg, 12)
     net = build_net(cfg)
     net.load_state_dict(sd, strict=True)
-    net.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    net.to(DEV).train().set_compute_dtype(dtype)
     g = torch.Generator().manual_seed(4321)
     x = torch.rand(B, 3, 128, 128, generator=g)
     tgt = torch.rand(B, 3, 256, 256, generator=g)
@@ -424,13 +418,31 @@ def test_ws16_bf16_train_step_all_gradients_vs_oracle():
         rel = d / max(rn, 1e-12)
         if rel > worst[0]:
             worst = (rel, k)
-        if rel > 4.5e-2:
+        if rel > tol_tensor:
             bad.append((k, rel))
     total = (tot_d / tot_r) ** 0.5
-    print(f"\nws16 bf16 B={B}: |dPSNR| {dpsnr:.2e} dB  out max|d| {(yc - oy.detach()).abs().max().item():.2e}  "
+    print(f"\nws16 {str(dtype).split('.')[-1]} B={B}: |dPSNR| {dpsnr:.2e} dB  out max|d| {(yc - oy.detach()).abs().max().item():.2e}  "
           f"loss {loss.item():.6f} vs {oloss.item():.6f}  {n} gradients: total rel L2 {total:.2e}, worst {worst[0]:.2e} "
           f"({worst[1]})")
     assert n == sum(1 for v in osd.values() if v.requires_grad) == 748   # one PixelShuffle stage (x2): two tensors fewer than E1
-    assert dpsnr < 0.05 and abs(loss.item() - oloss.item()) <= 2e-3
-    assert total <= 1.2e-2
+    assert dpsnr < tol_dpsnr and abs(loss.item() - oloss.item()) <= tol_loss
+    assert total <= tol_total
     assert not bad, bad[:10]
+
+
+def test_ws16_bf16_train_step_all_gradients_vs_oracle():
+    """BASELINE configs[3] (3-channel x2, 128x128 -> 256x256, window 16, the E1 widths) in the bf16 mode: every trainable
+    tensor's gradient against the fp32 oracle, batch 2 (128 windows per layer: wattn16_mfma.hip forward and backward in all
+    48 Swin blocks, shifted and not, with the region masks of the last window row / column).  Same stated tolerances as the
+    E1 test except per tensor: rel L2 <= 4.5e-2 (B = 2 is 8192 tokens, a sixteenth of the E1 test's: the 961-entry bias tables
+    sit at 3.0e-2..3.7e-2, measured), total <= 1.2e-2 (measured 4.8e-3), |dPSNR| < 0.05 dB."""
+    _ws16_all_gradients(torch.bfloat16, 2, 4.5e-2, 1.2e-2, 0.05, 2e-3)
+
+
+def test_ws16_fp32_train_step_all_gradients_vs_oracle():
+    """BASELINE configs[3] in the reference's own arithmetic: the full window-16 network (48 Swin blocks on the exact-fp32
+    matrix-core kernels of wattn16_f32.hip, every mask case of the shifted blocks) in fp32, forward + L1 + backward at the
+    configuration's own patch size (B = 1: 64 windows per layer), every trainable tensor's gradient against the oracle:
+    rel L2 <= 1e-4 per tensor (measured worst 3.4e-6), <= 1e-5 in total (2.5e-7), |dPSNR| < 5e-6 dB (5.1e-8; the claim is four
+    decimals), loss to 1e-6."""
+    _ws16_all_gradients(torch.float32, 1, 1e-4, 1e-5, 5e-6, 1e-6)
