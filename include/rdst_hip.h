@@ -77,6 +77,25 @@ int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* table, const fl
                    size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift,
                    float scale, int dtype, void* stream);
 
+/* ---- K1 / K2 with attention dropout (ABI 8) -----------------------------------------------------------
+ * WindowAttention(attn_drop > 0) in training (reference: networks/swin_transformer_sr.py:102, :136 — nn.Dropout on the
+ * softmax output): out = (softmax(S) * M / (1 - attn_drop)) @ v with M ~ Bernoulli(1 - attn_drop).  The mask is a pure
+ * function of (*seed, window, head, query, key) — a counter-based generator — so nothing is stored between forward and
+ * backward; `seed` is a DEVICE pointer (the host draws the value on the stream, e.g. from torch's generator, so a HIP
+ * graph replay gets a fresh mask), and rdst_wattn_bwd_drop must be given the attn_drop and *seed of its forward.
+ * attn_drop = 0 is rdst_wattn_fwd / _bwd on the shape-generic kernels.  rdst_wattn_drop_mask writes the multipliers
+ * (0 or 1 / (1 - attn_drop)) as out[(window * heads + head)][N][N] floats, for inspection and tests. */
+int rdst_wattn_fwd_drop(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
+                        void* out, int64_t ld_out, int B, int H, int W, int C, int heads, int ws, int shift,
+                        float scale, int dtype, float attn_drop, const unsigned long long* seed, void* stream);
+int rdst_wattn_bwd_drop(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
+                        const void* dout, int64_t ld_dout, void* dqkv, int64_t ld_dqkv, float* dtable,
+                        void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
+                        int shift, float scale, int dtype, float attn_drop, const unsigned long long* seed,
+                        void* stream);
+int rdst_wattn_drop_mask(float* out, int B, int H, int W, int heads, int ws, float attn_drop,
+                         const unsigned long long* seed, void* stream);
+
 /* ---- K3: (LayerNorm | activation ->) Linear (-> *scale + residual), forward and backward ---------
  * Y[M,N] = ( f(X)[M,K] @ Wt[N,K]^T + bias ) * out_scale + R
  * with f = LayerNorm (ln_w != NULL), or the activation `in_act` applied to X on the fly, or identity.

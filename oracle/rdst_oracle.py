@@ -95,7 +95,7 @@ def effective_window(input_resolution: Sequence[int], ws: int, shift: int) -> Tu
 # attention core (what the fused HIP kernel K1/K2 replaces)
 # --------------------------------------------------------------------------------------
 def window_attention_core(qkv: Tensor, table: Tensor, heads: int, ws: int, shift: int,
-                          scale: float) -> Tensor:
+                          scale: float, drop_mult: Optional[Tensor] = None) -> Tensor:
     """qkv (B,H,W,3C) token-major, inner order [3][heads][d] -> out (B,H,W,C).
 
     Restates roll -> window_partition -> (q*scale)@k^T + bias (+mask) -> softmax -> @v ->
@@ -124,6 +124,10 @@ def window_attention_core(qkv: Tensor, table: Tensor, heads: int, ws: int, shift
         attn = attn.reshape(-1, nW, heads, N, N) + mask[None, :, None]
         attn = attn.reshape(-1, heads, N, N)
     attn = torch.softmax(attn, dim=-1)
+    if drop_mult is not None:
+        # self.attn_drop(attn) (:136) with the mask made explicit: nn.Dropout multiplies by 0 or 1 / (1 - p); the random
+        # stream itself is not part of the restatement (the tests export the HIP path's mask and pass it here)
+        attn = attn * drop_mult.reshape(attn.shape)
     out = (attn @ v).transpose(1, 2).reshape(-1, ws, ws, C)
     out = window_reverse(out, ws, H, W)
     if shift > 0:

@@ -48,6 +48,9 @@ SIGNATURES = {
     "rdst_reduce_batch_begin": (_i, []),
     "rdst_reduce_batch_end": (_i, [_p]),
     "rdst_reduce_batch_abort": (_i, []),
+    "rdst_wattn_fwd_drop": (_i, [_p, _l, _p, _p, _i, _p, _l, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _p, _p]),
+    "rdst_wattn_bwd_drop": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _f, _p, _p]),
+    "rdst_wattn_drop_mask": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "rdst_nchw_to_rows": (_i, [_p, _p, _l, _i, _i, _i, _i, _i, _p]),
     "rdst_rows_to_nchw": (_i, [_p, _l, _p, _i, _i, _i, _i, _i, _p]),
     "rdst_upsample2_fwd": (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _i, _p]),
@@ -72,7 +75,7 @@ SIGNATURES = {
     "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
-ABI_VERSION = 7             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
+ABI_VERSION = 8             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 

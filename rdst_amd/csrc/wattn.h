@@ -9,7 +9,24 @@ struct WinGeom {
   int T;         // relative-position table rows = (2ws-1)^2
   const float* mask;  // optional explicit additive mask (mask_nw, N, N), else NULL
   int mask_nw;
+  // attention dropout (swin_transformer_sr.py:136, training only): probability and the DEVICE address of the 64-bit seed
+  // of this call; 0 / NULL everywhere but in rdst_wattn_{fwd,bwd}_drop (the generic kernels of wattn_v0.hip apply it)
+  float pdrop;
+  const unsigned long long* seed;
 };
+
+// Multiplier of attention weight (query i, key j) of workgroup `blk` = (window, head) under dropout: 0 with probability
+// pdrop, else 1 / (1 - pdrop); a pure function of (seed, blk, i, j) (splitmix64 of a counter), so the forward, both passes of
+// the backward and rdst_wattn_drop_mask see the same mask without storing it.
+__device__ __forceinline__ float wattn_drop_mul(unsigned long long seed, unsigned blk, int i, int j, int N, float pdrop,
+                                                float rkeep) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)blk * N + i) * N + j + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);   // 24 uniform bits
+  return u >= pdrop ? rkeep : 0.f;
+}
 
 // Row (token) index in the (B*H*W) activation of token t of window (wr,wc) of image b.
 // The cyclic shift of networks/swin_transformer_sr.py:244-247 / :264-267 is folded in here:
@@ -43,6 +60,7 @@ __device__ __forceinline__ int win_region(int wr, int wc, int t, const WinGeom& 
   return rr * 3 + cr;
 }
 
+int wattn_drop_mask(float* out, int64_t nblk, int N, float pdrop, const unsigned long long* seed, hipStream_t st);
 int wattn_fwd_generic(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
                       float scale, int dtype, hipStream_t st);
 int wattn_bwd_generic(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,

@@ -5,7 +5,7 @@
 
 thread_local char g_rdst_err[256] = {0};
 
-extern "C" int rdst_abi_version(void) { return 7; }
+extern "C" int rdst_abi_version(void) { return 8; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {
@@ -22,6 +22,7 @@ int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shi
   g.nWh = H / ws; g.nWw = W / ws; g.N = ws * ws; g.T = (2 * ws - 1) * (2 * ws - 1);
   if (mask && mask_nw <= 0) return rdst_fail(RDST_EINVAL, "%s: mask given with mask_nw=%d", who, mask_nw);
   g.mask = mask; g.mask_nw = mask ? mask_nw : 1;
+  g.pdrop = 0.f; g.seed = nullptr;
   return 0;
 }
 
@@ -76,4 +77,64 @@ extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* tabl
   sj.slab = slab; sj.nwg = nwin; sj.stride = (int64_t)heads * g.T; sj.tot = heads * g.T; sj.map = rbatch::MAP_DTABLE;
   sj.out = dtable; sj.a = heads; sj.b = g.T;
   return rbatch::sum(sj, st);
+}
+
+// ---- attention dropout (WindowAttention.attn_drop > 0 in training, swin_transformer_sr.py:102,136): the generic kernels with
+// a counter-based mask; `seed` is a DEVICE pointer to the call's 64-bit seed (drawn by the host from its generator: a HIP graph
+// replay then sees a new seed without re-capturing); the backward must get the same attn_drop and seed as its forward.
+namespace {
+int drop_args(WinGeom& g, float attn_drop, const unsigned long long* seed, const char* who) {
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return rdst_fail(RDST_EINVAL, "%s: attn_drop=%g must be in [0, 1)", who, (double)attn_drop);
+  if (attn_drop > 0.f && !seed) return rdst_fail(RDST_EINVAL, "%s: attn_drop > 0 needs a seed", who);
+  g.pdrop = attn_drop;
+  g.seed = attn_drop > 0.f ? seed : nullptr;
+  return 0;
+}
+}  // namespace
+
+extern "C" int rdst_wattn_fwd_drop(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
+                                   void* out, int64_t ld_out, int B, int H, int W, int C, int heads, int ws, int shift,
+                                   float scale, int dtype, float attn_drop, const unsigned long long* seed, void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_fwd_drop")) return rc;
+  if (!qkv || !table || !out) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_drop: null pointer");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_drop: bad dtype %d", dtype);
+  if (ld_qkv < 3 * C || ld_out < C) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_drop: leading dimension too small");
+  if (int rc = drop_args(g, attn_drop, seed, "rdst_wattn_fwd_drop")) return rc;
+  return wattn_fwd_generic(qkv, ld_qkv, table, out, ld_out, g, scale, dtype, (hipStream_t)stream);
+}
+
+extern "C" int rdst_wattn_bwd_drop(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
+                                   const void* dout, int64_t ld_dout, void* dqkv, int64_t ld_dqkv, float* dtable,
+                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
+                                   int shift, float scale, int dtype, float attn_drop, const unsigned long long* seed,
+                                   void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_bwd_drop")) return rc;
+  if (!qkv || !table || !dout || !dqkv || !dtable || !workspace)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_drop: null pointer");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_drop: bad dtype %d", dtype);
+  if (ld_qkv < 3 * C || ld_dqkv < 3 * C || ld_dout < C)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_drop: leading dimension too small");
+  if (workspace_bytes < rdst_wattn_bwd_workspace(B, H, W, C, heads, ws))
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_drop: workspace too small");
+  if (int rc = drop_args(g, attn_drop, seed, "rdst_wattn_bwd_drop")) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)workspace;
+  const int nwin = B * g.nWh * g.nWw;
+  if (int rc = wattn_bwd_generic(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, g, scale, dtype, st)) return rc;
+  rbatch::SumJob sj{};   // one slab row per (window, head) workgroup: [nwin][heads][T]
+  sj.slab = slab; sj.nwg = nwin; sj.stride = (int64_t)heads * g.T; sj.tot = heads * g.T; sj.map = rbatch::MAP_DTABLE;
+  sj.out = dtable; sj.a = heads; sj.b = g.T;
+  return rbatch::sum(sj, st);
+}
+
+// The multipliers (0 or 1 / (1 - attn_drop)) the two entry points above apply: out[(window * heads + head)][N][N] floats
+// (inspection and tests: the kernels never store the mask).
+extern "C" int rdst_wattn_drop_mask(float* out, int B, int H, int W, int heads, int ws, float attn_drop,
+                                    const unsigned long long* seed, void* stream) {
+  if (!out || !seed || B <= 0 || H <= 0 || W <= 0 || heads <= 0 || ws <= 0 || H % ws || W % ws)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_drop_mask: bad argument");
+  if (!(attn_drop > 0.f && attn_drop < 1.f)) return rdst_fail(RDST_EINVAL, "rdst_wattn_drop_mask: attn_drop must be in (0, 1)");
+  return wattn_drop_mask(out, (int64_t)B * (H / ws) * (W / ws) * heads, ws * ws, attn_drop, seed, (hipStream_t)stream);
 }

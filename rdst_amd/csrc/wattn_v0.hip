@@ -44,6 +44,9 @@ wattn_fwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
   __syncthreads();
 
   const int tw = 2 * ws - 1;
+  const bool drop = g.pdrop > 0.f;
+  const unsigned long long seed = drop ? *g.seed : 0ull;
+  const float rkeep = drop ? 1.0f / (1.0f - g.pdrop) : 1.0f;
   for (int i = tid; i < N; i += bd) {
     float q[D];
     const T* qrow = qkv + (int64_t)trow[i] * ld + head * D;
@@ -73,9 +76,10 @@ wattn_fwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
         s += tab[base - yj * tw - xj];
         if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         const float p = expf(s - m);
-        l += p;
+        l += p;   // the softmax is normalised over ALL keys; dropout acts on the normalised weights
+        const float pm = drop ? p * wattn_drop_mul(seed, blockIdx.x, i, j, N, g.pdrop, rkeep) : p;
 #pragma unroll
-        for (int e = 0; e < D; ++e) acc[e] = fmaf(p, Vs[j * D + e], acc[e]);
+        for (int e = 0; e < D; ++e) acc[e] = fmaf(pm, Vs[j * D + e], acc[e]);
       }
     const float inv = 1.0f / l;
     T* orow = out + (int64_t)trow[i] * ldo + head * D;
@@ -130,6 +134,11 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
   __syncthreads();
 
   const int tw = 2 * ws - 1;
+  // attention dropout: out_i = sum_j a_ij m_ij v_j with a = softmax, m = 0 or 1 / (1 - p).  Then dV_j = sum_i a_ij m_ij dO_i,
+  // dS_ij = a_ij (m_ij dP_ij - delta_i) with dP = dO.V^T and delta_i = sum_k a_ik m_ik dP_ik = dO_i . out_i as without dropout
+  const bool drop = g.pdrop > 0.f;
+  const unsigned long long seed = drop ? *g.seed : 0ull;
+  const float rkeep = drop ? 1.0f / (1.0f - g.pdrop) : 1.0f;
   // ---- pass A: one lane per query row: lse, delta, dQ, d(table) -------------------------------
   for (int i = tid; i < N; i += bd) {
     float q[D], dO[D];
@@ -160,8 +169,9 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
         if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         const float p = expf(s - m);
         l += p;
+        const float pm = drop ? p * wattn_drop_mul(seed, blockIdx.x, i, j, N, g.pdrop, rkeep) : p;
 #pragma unroll
-        for (int e = 0; e < D; ++e) acc[e] = fmaf(p, Vs[j * D + e], acc[e]);
+        for (int e = 0; e < D; ++e) acc[e] = fmaf(pm, Vs[j * D + e], acc[e]);
       }
     float dl = 0.f;
 #pragma unroll
@@ -185,6 +195,7 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
         s += tab[ti];
         if (mrow) s += mrow[j]; else if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         const float p = expf(s - ls);
+        if (drop) dp *= wattn_drop_mul(seed, blockIdx.x, i, j, N, g.pdrop, rkeep);
         const float ds = p * (dp - dl);
 #pragma unroll
         for (int e = 0; e < D; ++e) dq[e] = fmaf(ds, Ks[j * D + e], dq[e]);
@@ -214,10 +225,12 @@ wattn_bwd_v0(const T* __restrict__ qkv, int64_t ld, const float* __restrict__ ta
         s += tab[base + yi * tw + xi];
         if (mcol) s += mcol[(int64_t)i * N]; else if (g.shift > 0 && reg[i] != rj) s += -100.0f;
         const float p = expf(s - lse[i]);
-        const float ds = p * (dp - delta[i]);
+        const float mm = drop ? wattn_drop_mul(seed, blockIdx.x, i, j, N, g.pdrop, rkeep) : 1.0f;
+        const float ds = p * (mm * dp - delta[i]);
+        const float pm = p * mm;
 #pragma unroll
         for (int e = 0; e < D; ++e) {
-          dv[e] = fmaf(p, dOs[i * D + e], dv[e]);
+          dv[e] = fmaf(pm, dOs[i * D + e], dv[e]);
           dk[e] = fmaf(ds, Qs[i * D + e], dk[e]);  // Qs already carries `scale`
         }
       }
@@ -280,6 +293,23 @@ int launch_bwd_d(int D, const T* qkv, int64_t ld, const float* table, const T* d
 }
 
 }  // namespace
+
+namespace {
+__global__ void wattn_drop_mask_kernel(float* out, int N, float pdrop, const unsigned long long* seedp) {
+  const unsigned long long seed = *seedp;
+  const float rkeep = 1.0f / (1.0f - pdrop);
+  float* my = out + (size_t)blockIdx.x * N * N;
+  for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+    const int i = idx / N, j = idx - i * N;
+    my[idx] = wattn_drop_mul(seed, blockIdx.x, i, j, N, pdrop, rkeep);
+  }
+}
+}  // namespace
+
+int wattn_drop_mask(float* out, int64_t nblk, int N, float pdrop, const unsigned long long* seed, hipStream_t st) {
+  hipLaunchKernelGGL(wattn_drop_mask_kernel, dim3((unsigned)nblk), dim3(256), 0, st, out, N, pdrop, seed);
+  return rdst_launch_status("wattn_drop_mask");
+}
 
 int wattn_fwd_generic(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
                       float scale, int dtype, hipStream_t st) {

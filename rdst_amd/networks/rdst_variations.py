@@ -19,7 +19,7 @@ import torch.nn as nn
 from .. import ops
 from .common import Conv2d, MeanShift, UpSampler, default_conv
 from .swin_transformer_sr import (BasicLayer, Mlp, PatchEmbed, PatchUnEmbed, SwinTransformerBlock,  # noqa: F401
-                                  WindowAttention, _ln_params, _norm_only, trunc_normal_, window_partition,
+                                  WindowAttention, _drop_p, _ln_params, _norm_only, trunc_normal_, window_partition,
                                   window_reverse)
 
 
@@ -289,9 +289,7 @@ class RDSTSR(nn.Module):
         if self.ape:
             self.absolute_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
             trunc_normal_(self.absolute_pos_embed, std=.02)
-        if drop_rate and drop_rate > 0.:
-            raise NotImplementedError("rdst_amd RDSTSR: drop_rate > 0 is not on the hot path")
-        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.pos_drop = nn.Dropout(p=_drop_p(drop_rate, "drop_rate"))
 
         self.body = nn.ModuleList()
         for i_block in range(self.num_blocks):
@@ -356,11 +354,14 @@ class RDSTSR(nn.Module):
         chain = t.is_cuda and len(blocks) > 0 and all(isinstance(b, RDSTB) and len(b.body) > 0 and hasattr(b, "conv")
                                                       and b.input_dim == E for b in blocks)
         bufs = [b.make_buffer(B, H * W, t.dtype, t.device) for b in blocks] if chain else [None] * len(blocks)
+        pos_drop = self.training and self.pos_drop.p > 0.
         if self.patch_embed.norm is not None:
-            first = (bufs[0], 0) if (chain and not self.ape and isinstance(self.patch_embed.norm, nn.LayerNorm)) else None
+            first = (bufs[0], 0) if (chain and not self.ape and not pos_drop and isinstance(self.patch_embed.norm, nn.LayerNorm)) else None
             t = _norm_only(t, self.patch_embed.norm, out_slot=first)
         if self.ape:
             t = t + self.absolute_pos_embed.to(t.dtype)
+        if pos_drop:
+            t = self.pos_drop(t)   # rdst_variations.py:1332
         for i, blk in enumerate(blocks):
             if chain:
                 t = blk(t, x_size, buf=bufs[i], out_slot=(bufs[i + 1], 0) if i + 1 < len(blocks) else None)
@@ -471,6 +472,7 @@ class RDSTSR_N(RDSTSR):
             t = _norm_only(t, self.patch_embed.norm)
         if self.ape:
             t = t + self.absolute_pos_embed.to(t.dtype)
+        t = self.pos_drop(t)   # rdst_variations.py:1068
         gs = self.global_res_scale
         if self.do_global_bottleneck:
             maps = []

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 
@@ -25,11 +26,12 @@ def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
     return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
 
 
-def _no_dropout(p, what):
-    if p and p > 0.:
-        raise NotImplementedError(
-            f"rdst_amd: {what}={p} > 0 is not on the RDST hot path (every shipped config uses 0; "
-            "the reference's RDSTSR never forwards drop_path_rate to its blocks)")
+def _drop_p(p, what):
+    """A dropout probability as the reference's nn.Dropout takes it ([0, 1]; 1 would divide by zero in the kernels)."""
+    p = float(p or 0.)
+    if not (0. <= p < 1.):
+        raise ValueError(f"rdst_amd: {what}={p} must be in [0, 1)")
+    return p
 
 
 class DropPath(nn.Module):
@@ -92,15 +94,20 @@ class Mlp(nn.Module):
         hidden_features = hidden_features or in_features
         if act_layer is not nn.GELU:
             raise NotImplementedError("rdst_amd Mlp: only nn.GELU (exact erf form)")
-        _no_dropout(drop, "drop")
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features, out_features)
-        self.drop = nn.Dropout(drop)
+        self.drop = nn.Dropout(_drop_p(drop, "drop"))
 
     def forward(self, x, norm=None, residual=None):
         w, b = _ln_params(norm)
         h = ops.ln_linear(x, w, b, self.fc1.weight, self.fc1.bias)
+        if self.training and self.drop.p > 0.:
+            # swin_transformer_sr.py:24-28 with drop > 0: the activation is materialised so that the mask can sit between it
+            # and fc2 (and behind fc2); elementwise torch ops on the device tensors, the Linears stay on the HIP kernels
+            h = self.drop(F.gelu(h))
+            y = self.drop(ops.ln_linear(h, None, None, self.fc2.weight, self.fc2.bias))
+            return y if residual is None else y + residual
         return ops.ln_linear(h, None, None, self.fc2.weight, self.fc2.bias, in_act=ops.ACT_GELU, residual=residual)
 
 
@@ -137,15 +144,13 @@ class WindowAttention(nn.Module):
         self.scale = qk_scale or head_dim ** -0.5
         if window_size[0] != window_size[1]:
             raise NotImplementedError("rdst_amd WindowAttention: square windows only")
-        _no_dropout(attn_drop, "attn_drop")
-        _no_dropout(proj_drop, "proj_drop")
         self.relative_position_bias_table = nn.Parameter(
             torch.zeros((2 * window_size[0] - 1) * (2 * window_size[1] - 1), num_heads))
         self.register_buffer("relative_position_index", _relative_position_index(window_size[0], window_size[1]))
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
-        self.attn_drop = nn.Dropout(attn_drop)
+        self.attn_drop = nn.Dropout(_drop_p(attn_drop, "attn_drop"))
         self.proj = nn.Linear(dim, dim)
-        self.proj_drop = nn.Dropout(proj_drop)
+        self.proj_drop = nn.Dropout(_drop_p(proj_drop, "proj_drop"))
         trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)
 
@@ -156,8 +161,12 @@ class WindowAttention(nn.Module):
         ws = self.window_size[0]
         qkv = ops.ln_linear(x, None, None, self.qkv.weight, self.qkv.bias)
         a = ops.window_attention(qkv.view(B_, ws, ws, 3 * C), self.relative_position_bias_table, ws, ws,
-                                 self.num_heads, ws, 0, self.scale, mask=mask)
-        return ops.ln_linear(a.view(B_, N, C), None, None, self.proj.weight, self.proj.bias)
+                                 self.num_heads, ws, 0, self.scale, mask=mask, attn_drop=self.active_attn_drop())
+        return self.proj_drop(ops.ln_linear(a.view(B_, N, C), None, None, self.proj.weight, self.proj.bias))
+
+    def active_attn_drop(self):
+        """attn_drop as it acts now: nn.Dropout is the identity in eval()."""
+        return self.attn_drop.p if self.training else 0.
 
     def extra_repr(self) -> str:
         return f'dim={self.dim}, window_size={self.window_size}, num_heads={self.num_heads}'
@@ -209,22 +218,30 @@ class SwinTransformerBlock(nn.Module):
     def fuses_input_gradient(self):
         """True when forward() runs as the single autograd node that can add a dense join's gradient slice inside its
         backward (ops.GradSink): no stochastic depth in training, qkv bias present."""
-        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.:
+        if self._stochastic():
             return False
         return self.attn.qkv.bias is not None
+
+    def _stochastic(self):
+        """True when a random mask (stochastic depth or any dropout) acts in this call: training only."""
+        if not self.training:
+            return False
+        dp = isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.
+        return dp or self.attn.attn_drop.p > 0. or self.attn.proj_drop.p > 0. or self.mlp.drop.p > 0.
 
     def forward(self, x, x_size, sink=None):
         H, W = x_size
         n1w, n1b = _ln_params(self.norm1)
         n2w, n2b = _ln_params(self.norm2)
         at, mlp = self.attn, self.mlp
-        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.:
-            # stochastic depth (swin_transformer_sr.py:268, :272): the per-sample mask sits between each branch and its
-            # residual add, so the block runs as its op-level chain and the two adds are plain tensor ops
+        if self._stochastic():
+            # stochastic depth (swin_transformer_sr.py:268, :272) and the dropouts (:136 on the attention weights, :140 behind
+            # proj, :26 / :28 inside the Mlp): the masks sit between the pieces of the block, so it runs as its op-level
+            # chain and the two residual adds are plain tensor ops
             qkv = ops.ln_linear(x, n1w, n1b, at.qkv.weight, at.qkv.bias)
             a = ops.window_attention(qkv, at.relative_position_bias_table, H, W, self.num_heads, self.window_size,
-                                     self.shift_size, at.scale)
-            x = x + self.drop_path(ops.ln_linear(a, None, None, at.proj.weight, at.proj.bias))
+                                     self.shift_size, at.scale, attn_drop=at.active_attn_drop())
+            x = x + self.drop_path(at.proj_drop(ops.ln_linear(a, None, None, at.proj.weight, at.proj.bias)))
             return x + self.drop_path(self.mlp(x, norm=self.norm2))
         if at.qkv.bias is None:  # qkv_bias=False: fall back to the op-level chain
             qkv = ops.ln_linear(x, n1w, n1b, at.qkv.weight, None)
@@ -462,8 +479,7 @@ class SwinIR(nn.Module):
         if self.ape:
             self.absolute_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
             trunc_normal_(self.absolute_pos_embed, std=.02)
-        _no_dropout(drop_rate, "drop_rate")
-        self.pos_drop = nn.Dropout(p=drop_rate)
+        self.pos_drop = nn.Dropout(p=_drop_p(drop_rate, "drop_rate"))
         dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]   # stochastic depth decay rule
         self.layers = nn.ModuleList()
         for i_layer in range(self.num_layers):
@@ -526,6 +542,7 @@ class SwinIR(nn.Module):
             t = _norm_only(t, self.patch_embed.norm)
         if self.ape:
             t = t + self.absolute_pos_embed.to(t.dtype)
+        t = self.pos_drop(t)   # swin_transformer_sr.py:774 (identity unless drop_rate > 0 in training)
         for layer in self.layers:
             t = layer(t, (H, W))
         return _norm_only(t, self.norm).view(B, H, W, E)

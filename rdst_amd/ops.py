@@ -271,7 +271,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # ------------------------------------------------------------------------------------------------
 class _WindowAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, table, mask, H, W, heads, ws, shift, scale):
+    def forward(ctx, qkv, table, mask, H, W, heads, ws, shift, scale, attn_drop=0.0, seed=None):
         _need_gpu(qkv, table, mask)
         lib = _lib.load()
         C = qkv.shape[-1] // 3
@@ -281,17 +281,22 @@ class _WindowAttention(torch.autograd.Function):
         msk = _param(mask)
         nw = 0 if msk is None else msk.shape[0]
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
-        _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
-                                      W, C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()),
-                   "rdst_wattn_fwd")
-        ctx.save_for_backward(qkv_r, tab, msk)
-        ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw)
+        if attn_drop > 0.0:   # training-mode attention dropout: the shape-generic kernels with a counter-based mask
+            _lib.check(lib.rdst_wattn_fwd_drop(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
+                                               W, C, heads, ws, shift, float(scale), _dtype_code(qkv), float(attn_drop),
+                                               seed.data_ptr(), _stream()), "rdst_wattn_fwd_drop")
+        else:
+            _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
+                                          W, C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()),
+                       "rdst_wattn_fwd")
+        ctx.save_for_backward(qkv_r, tab, msk, seed)
+        ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw, float(attn_drop))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, tab, msk = ctx.saved_tensors
-        B, H, W, C, heads, ws, shift, scale, ld, nw = ctx.geom
+        qkv, tab, msk, seed = ctx.saved_tensors
+        B, H, W, C, heads, ws, shift, scale, ld, nw, attn_drop = ctx.geom
         lib = _lib.load()
         dout_r, ldd = _rows(dout)
         dqkv = torch.empty(qkv.shape[:-1] + (3 * C,), dtype=qkv.dtype, device=qkv.device)
@@ -300,19 +305,40 @@ class _WindowAttention(torch.autograd.Function):
         wsp = _workspace(nbytes, qkv.device)
         if _ReduceBatch.depth > 0:   # an outer batch is open: the d(table) slabs are summed when it ends
             _ReduceBatch.keep.append(wsp)
-        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
-                                      dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
-                                      C, heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
+        if attn_drop > 0.0:
+            _lib.check(lib.rdst_wattn_bwd_drop(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
+                                               dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
+                                               C, heads, ws, shift, scale, _dtype_code(qkv), attn_drop, seed.data_ptr(),
+                                               _stream()), "rdst_wattn_bwd_drop")
+        else:
+            _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
+                                          dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
+                                          C, heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
         _ReduceBatch.settle(lib)
-        return dqkv, dtable, None, None, None, None, None, None, None
+        return dqkv, dtable, None, None, None, None, None, None, None, None, None
+
+
+def draw_seed(device) -> torch.Tensor:
+    """One 64-bit seed on `device` from torch's generator (so torch.manual_seed governs it and a HIP-graph replay of the
+    call draws a new one): the seed argument of the attention-dropout entry points."""
+    return torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device)
 
 
 def window_attention(qkv: torch.Tensor, table: torch.Tensor, H: int, W: int, heads: int, ws: int, shift: int,
-                     scale: float, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     scale: float, mask: Optional[torch.Tensor] = None, attn_drop: float = 0.0,
+                     seed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused roll + window partition + (q*scale)k^T + relative-position bias + shift mask + softmax
     + @v + window reverse + un-roll on token-major qkv (..., 3C) -> (..., C).
     Replaces networks/swin_transformer_sr.py:244-267 with :117-138 inside (minus the Linears).
-    ``mask`` (nW,N,N) overrides the analytic shifted-window mask (standalone WindowAttention API)."""
+    ``mask`` (nW,N,N) overrides the analytic shifted-window mask (standalone WindowAttention API).
+    ``attn_drop`` > 0 (the caller passes it in training only): nn.Dropout on the softmax output (:136) with a counter-based
+    mask keyed by ``seed`` (a 1-element int64 tensor on the device; drawn from torch's generator when not given)."""
+    if attn_drop and attn_drop > 0.0:
+        if not (0.0 < attn_drop < 1.0):
+            raise ValueError(f"window_attention: attn_drop={attn_drop} must be in [0, 1)")
+        if seed is None:
+            seed = draw_seed(qkv.device)
+        return _WindowAttention.apply(qkv, table, mask, H, W, heads, ws, shift, scale, float(attn_drop), seed)
     return _WindowAttention.apply(qkv, table, mask, H, W, heads, ws, shift, scale)
 
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().rdst_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.load().rdst_abi_version() == _lib.ABI_VERSION == 8
 
 
 @pytest.mark.parametrize("name", sorted(NET_CASES))
@@ -274,3 +274,21 @@ def test_segunet_f_state_dict_is_smp_layout_and_loads_smp_checkpoint(tmp_path):
         SegUNet_F({"label-hr": []}, "OASIS", unet_path=str(tmp_path / "missing.pt"))
     with pytest.raises(ValueError):
         SegUNet_F({"label-hr": []}, "MARS", allow_random_init=True)
+
+
+def test_dropout_probabilities_are_validated_like_nn_dropout():
+    """Dropout p > 0 is accepted by the constructors (reference: swin_transformer_sr.py:21, :102, :105); p outside [0, 1) is
+    refused at construction time (1.0 would divide by zero in the attention kernels' 1 / (1 - p))."""
+    import pytest
+    from rdst_amd.networks.swin_transformer_sr import Mlp, SwinTransformerBlock, WindowAttention
+    assert Mlp(60, 120, drop=0.1).drop.p == 0.1
+    assert WindowAttention(60, (8, 8), 6, attn_drop=0.2, proj_drop=0.3).active_attn_drop() == 0.2
+    blk = SwinTransformerBlock(60, (16, 16), 6, window_size=8, shift_size=4, drop=0.1, attn_drop=0.1)
+    assert blk._stochastic() and not blk.fuses_input_gradient()
+    blk.eval()
+    assert not blk._stochastic() and blk.attn.active_attn_drop() == 0.0
+    for bad in (1.0, -0.1, 1.5):
+        with pytest.raises(ValueError):
+            Mlp(60, 120, drop=bad)
+        with pytest.raises(ValueError):
+            WindowAttention(60, (8, 8), 6, attn_drop=bad)

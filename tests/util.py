@@ -31,8 +31,9 @@ def rand(shape, seed, scale=1.0):
     return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32))
 
 
-def build_net(cfg, mean=None, std=None):
-    """The HIP-backed RDSTSR for an oracle cfg dict (same kwargs the golden generator gave the reference)."""
+def build_net(cfg, mean=None, std=None, **extra):
+    """The HIP-backed RDSTSR for an oracle cfg dict (same kwargs the golden generator gave the reference); `extra`: further
+    constructor arguments (drop_rate, attn_drop ...)."""
     import torch.nn as nn
     from rdst_amd.networks.rdst_variations import RDSTSR
     return RDSTSR(
@@ -43,7 +44,7 @@ def build_net(cfg, mean=None, std=None):
         patch_norm=cfg["patch_norm"], resi_connection=cfg["resi_connection"], growth_rate=cfg["growth_rate"],
         dense_scale=cfg["dense_scale"], rdb_residual_scale=cfg["rdb_residual_scale"],
         global_res_scale=cfg["global_res_scale"], mean=mean, std=std, pre_norm=cfg["pre_norm"],
-        feature_last_operation=cfg["feature_last_operation"])
+        feature_last_operation=cfg["feature_last_operation"], **extra)
 
 
 def seeded_fill(state_dict, seed):
