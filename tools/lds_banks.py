@@ -5,8 +5,6 @@ the kernels' index arithmetic; the file:line of each is in the table it prints).
 A wave64 access is served in fixed lane groups, one LDS cycle per group when conflict free; inside a group every extra
 DISTINCT dword on a busy bank costs one more cycle.  Banks: (a / 4) mod 64 for ds_read_b64 / b128 / b64_tr_b16, mod 32 for
 ds_read_b32 and every ds_write."""
-import sys
-
 G32 = [list(range(0, 32)), list(range(32, 64))]
 G128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
 G128 = G128 + [[l + 32 for l in g] for g in G128]
@@ -90,8 +88,7 @@ def mlp_bwd(nct):
         def st(l, wave=wave):
             idx = 64 * wave + l
             row, chk = (idx // PK) & 31, idx % PK
-            o = min(chk * 16, 2 * (CP - (8 if nct != 2 else 4)) - 16) if False else chk * 16
-            return OFF_XH + row * LDX + o
+            return OFF_XH + row * LDX + chk * 16
         rows.append((f"stash x-hat (wave {wave})", "write_b128", st, "2 per thread"))
     return rows
 
