@@ -180,3 +180,24 @@ def test_wattn16_fp32_mfma_vs_oracle(B, H, W, C, shift):
     for s3, name in enumerate(("dq", "dk", "dv")):
         a, b_ = q.grad[..., s3 * C:(s3 + 1) * C], q_ref.grad[..., s3 * C:(s3 + 1) * C]
         assert rel(a, b_) <= 3e-6, (name, rel(a, b_))
+
+
+def test_wattn16_fp32_is_bit_deterministic():
+    """The exact-fp32 window-16 kernels sum d(table) in a fixed order (lane-shift diagonal sums, then one thread per entry, then
+    the batched slab sum): two runs give the same bits for the output and every gradient."""
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, W, C, shift = 2, 64, 64, 90, 8
+    qkv = _rand((B, H, W, 3 * C), 31).to(dev)
+    table = _rand((961, 6), 32, 0.5).to(dev)
+    gout = _rand((B, H, W, C), 33).to(dev)
+    res = []
+    for _ in range(2):
+        q = qkv.clone().requires_grad_(True)
+        t = table.clone().requires_grad_(True)
+        o = ops.window_attention(q, t, H, W, 6, 16, shift, 15 ** -0.5)
+        o.backward(gout)
+        torch.cuda.synchronize()
+        res.append((o.detach().clone(), q.grad.clone(), t.grad.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
