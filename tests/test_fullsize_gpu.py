@@ -142,6 +142,35 @@ def test_wattn16_bf16_bench_size_vs_oracle(C, shift):
     assert torch.equal(t.grad, t2.grad) and torch.equal(q.grad, q2.grad)
 
 
+@pytest.mark.parametrize("C,shift", [(60, 8), (120, 0)])
+def test_wattn16_fp32_bench_size_vs_oracle(C, shift):
+    """The exact-fp32 window-16 kernels (wattn16_f32.hip) at the size of `bench.py --config ws16` (8 x 128 x 128 tokens = 512
+    windows = 3072 workgroups, the XCD-aware block mapping): rel L2 <= 2e-6 (3e-6 on d(table)), per-window bounds 5e-6."""
+    from rdst_amd import ops
+    heads, ws, B, HW16 = 6, 16, 8, 128
+    scale = (C // heads) ** -0.5
+    qkv = rand((B, HW16, HW16, 3 * C), 400 + C)
+    table = rand(((2 * ws - 1) ** 2, heads), 2, 0.5)
+    gout = rand((B, HW16, HW16, C), 3)
+    q_ref = qkv.clone().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout)
+    q = qkv.to(DEV).requires_grad_(True)
+    t = table.to(DEV).requires_grad_(True)
+    o = ops.window_attention(q, t, HW16, HW16, heads, ws, shift, scale)
+    o.backward(gout.to(DEV))
+    torch.cuda.synchronize()
+    ro, rq, rt = _rel(o, o_ref.detach()), _rel(q.grad, q_ref.grad), _rel(t.grad, t_ref.grad)
+    print(f"\nwattn16 fp32 C={C} shift={shift}: rel L2 out {ro:.2e}  dqkv {rq:.2e}  dtable {rt:.2e}")
+    assert ro <= 2e-6 and rq <= 2e-6 and rt <= 3e-6
+    nw = HW16 // ws
+    for got, want, width in ((o, o_ref.detach(), C), (q.grad, q_ref.grad, 3 * C)):
+        d = (got.float().cpu() - want).view(B, nw, ws, nw, ws, width)
+        per_win = d.pow(2).sum(dim=(2, 4, 5)).sqrt() / want.view(B, nw, ws, nw, ws, width).pow(2).sum(dim=(2, 4, 5)).sqrt()
+        assert per_win.max().item() <= 5e-6
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # K7 (mlp_mfma.hip): 4096 tiles, resident dW accumulators
 # ------------------------------------------------------------------------------------------------------------------
