@@ -11,6 +11,7 @@ Parameters are always fp32; activations are fp32 (parity mode) or bf16 (throughp
 from __future__ import annotations
 
 import os
+import threading
 import weakref
 
 from typing import Optional
@@ -476,7 +477,28 @@ class _IntoDense(torch.autograd.Function):
         return g, None
 
 
-class _ReduceBatch:
+class _ReduceBatchState(type):
+    """``_ReduceBatch.depth / .keep / .fresh`` live PER THREAD, like the C side's queues (csrc/reduce_batch.hip keeps
+    them ``thread_local``): autograd runs each device's backward on its own thread, so two devices in one process (or two
+    backward passes on two Python threads) never share a counter while their C queues are separate."""
+    _tls = threading.local()
+
+    def _state(cls):
+        st = cls._tls.__dict__
+        if "depth" not in st:
+            st.update(depth=0, keep=[], fresh=0, owner=-1, mixed=False)
+        return st
+
+    depth = property(lambda cls: cls._state()["depth"], lambda cls, v: cls._state().__setitem__("depth", v))
+    keep = property(lambda cls: cls._state()["keep"], lambda cls, v: cls._state().__setitem__("keep", v))
+    fresh = property(lambda cls: cls._state()["fresh"], lambda cls, v: cls._state().__setitem__("fresh", v))
+    # the autograd graph task that opened the batch, and whether a node of ANOTHER task ran while it was open: the engine's
+    # device thread serves every concurrent backward() of that device, so nodes of two passes can interleave
+    owner = property(lambda cls: cls._state()["owner"], lambda cls, v: cls._state().__setitem__("owner", v))
+    mixed = property(lambda cls: cls._state()["mixed"], lambda cls, v: cls._state().__setitem__("mixed", v))
+
+
+class _ReduceBatch(metaclass=_ReduceBatchState):
     """Nesting-aware rdst_reduce_batch_begin / _end.  A Swin block's backward opens a batch for its own four ops; a
     DenseSTLayer (dense join with a GradSink) opens an OUTER one in the join's backward — the first node of the layer's
     backward — which the layer's first Swin block closes at the end of its own — the last node — so the slab sums and
@@ -489,14 +511,26 @@ class _ReduceBatch:
     (`fresh`: p.grad already defined -> autograd runs ``p.grad += g`` right after the node — bucket.zero() + backward,
     gradient accumulation, zero_grad(set_to_none=False) —, or a parameter used twice) makes the node `settle` before
     it returns: the queued reductions run at once and the outer batch goes on empty."""
-    depth = 0
-    keep: list = []
-    fresh = 0
+
+    @staticmethod
+    def _task():
+        return torch._C._current_graph_task_id()
+
+    @staticmethod
+    def _foreign():
+        """A node of another backward pass runs inside this thread's open batch (two Python threads called backward() on
+        the same device at once): from here until the batch closes every node flushes what is queued before it returns,
+        so no pass ever returns with reductions of its own still parked in the other pass's batch."""
+        if _ReduceBatch.depth > 0 and _ReduceBatch._task() != _ReduceBatch.owner:
+            _ReduceBatch.mixed = True
+        return _ReduceBatch.mixed
 
     @staticmethod
     def begin(lib):
         if _ReduceBatch.depth == 0:
             _lib.check(lib.rdst_reduce_batch_begin(), "rdst_reduce_batch_begin")
+            _ReduceBatch.owner = _ReduceBatch._task()
+            _ReduceBatch.mixed = False
         _ReduceBatch.depth += 1
 
     @staticmethod
@@ -515,7 +549,7 @@ class _ReduceBatch:
     def settle(lib):
         """Last statement of a node's backward: if a batch is still open around this node and the node handed out a
         gradient destination that autograd may read on return, run what is queued now (and keep the batch open)."""
-        if _ReduceBatch.depth > 0 and _ReduceBatch.fresh:
+        if _ReduceBatch.depth > 0 and (_ReduceBatch.fresh or _ReduceBatch._foreign()):
             try:
                 _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
             finally:
@@ -534,6 +568,7 @@ class _ReduceBatch:
         _ReduceBatch.depth = 0
         _ReduceBatch.keep = []
         _ReduceBatch.fresh = 0
+        _ReduceBatch.mixed = False
 
 
 class GradSink:
@@ -853,8 +888,8 @@ class _ConvRows(torch.autograd.Function):
         dev = x.device
         dx = torch.empty((B, H, W, Cin), dtype=x.dtype, device=dev) if need[0] else None
         dw = _grad_like(w) if need[1] else None
-        db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None else torch.empty(Cout, dtype=torch.float32, device=dev)) \
-            if (has_bias and need[2]) else None
+        db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None
+              else _fresh_grad(torch.empty(Cout, dtype=torch.float32, device=dev))) if (has_bias and need[2]) else None
         nbytes = lib.rdst_conv_bwd_workspace(B, H, W, Cin, Cout, k)
         code = _dtype_code(x)
 
@@ -874,6 +909,7 @@ class _ConvRows(torch.autograd.Function):
             cur.wait_stream(side)
         else:
             call(dx, dw, db, _workspace(nbytes, dev))
+        _ReduceBatch.settle(lib)   # (a conv inside an open outer batch: nothing of its own is deferred, its fresh destinations settle)
         dres = dy if (has_res and need[3]) else None
         return dx, dw, db, dres, None, None, None, None
 

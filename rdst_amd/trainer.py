@@ -60,6 +60,7 @@ class DPTrainStep:
         self.use_graph = bool(graph)
         self.graph_warmup = int(graph_warmup)
         self.graph = None
+        self._graph_report = None      # the report object whose tensors the captured graph rewrites on every replay
         self._static = None            # (inputs, targets) the graph reads
         self._eager_seen = 0
         self._loss_buf = None
@@ -114,6 +115,12 @@ class DPTrainStep:
             self.training_loss_records.setdefault(n, []).extend(next(it) if torch.is_tensor(v) else v for v in vals)
         self._pending = {}
 
+    def loss_records(self) -> Dict[str, list]:
+        """``training_loss_records`` with every parked step converted (the reference reads the attribute directly,
+        basic_trainer.py:440; here the attribute lags by up to RECORD_FLUSH steps until this or checkpoint() runs)."""
+        self._flush_records()
+        return self.training_loss_records
+
     def fwd_bwd(self, inputs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         """forward + loss + backward with the gradients written straight into the flat bucket (no host sync inside:
         capturable).  Returns the loss as a device scalar that is overwritten by the next call."""
@@ -152,12 +159,15 @@ class DPTrainStep:
             ops._ReduceBatch.abandon(_lib.load())
             dp._OFFERED = {}
             self.bucket.gather()
-            self.use_graph, self.graph, self._static = False, None, None
+            self.use_graph, self.graph, self._static, self._graph_report = False, None, None, None
             return False
         if not self.bucket.check_views():
-            self.use_graph, self.graph, self._static = False, None, None
+            self.use_graph, self.graph, self._static, self._graph_report = False, None, None, None
             return False
         self.graph = g
+        # the report the capture produced: its tensors are the graph's own buffers, refreshed by every replay.  An eager
+        # step in between (another shape) rebinds last_report to ITS tensors; step() re-points it before recording a replay.
+        self._graph_report = self.last_report
         return True
 
     def _graph_fits(self, inputs, targets) -> bool:
@@ -192,6 +202,7 @@ class DPTrainStep:
             if targets.data_ptr() != self._static[1].data_ptr():
                 self._static[1].copy_(targets)
             self.graph.replay()
+            self.last_report = self._graph_report
             loss = self._loss_buf
         else:
             loss = self.fwd_bwd(inputs, targets)
@@ -239,6 +250,7 @@ class DPTrainStep:
             self.loss_module.load_state_dict(ck["loss"])
         self.training_loss_names = ck.get("training_loss_names", self.training_loss_names)
         self.training_loss_records = ck.get("training_loss_records", self.training_loss_records)
+        self._pending = {}             # steps taken before the load belong to the history that was just replaced
         self.quick_validation_reports = ck.get("quick_validation_reports", [])
         self.current_training_state_id = ck.get("current_training_state_id", 0)
         self.current_epoch = ck.get("current_epoch", 0)

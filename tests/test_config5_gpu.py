@@ -201,3 +201,32 @@ def test_unetf_state_through_graph_captured_trainer_step_equals_eager():
     assert res[False][0] == res[True][0]
     assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
     assert res[False][3] == res[True][3] == 10
+
+
+def test_graph_replay_after_an_odd_shaped_eager_step_records_its_own_components():
+    """A step whose shape does not fit the captured graph runs eagerly and rebinds ``last_report`` to ITS tensors; the
+    replays that follow must record the replayed step's components, not that stale eager report (trainer.py:_record):
+    the per-component records of a graph run equal those of an eager run over the same batches, step by step."""
+    from rdst_amd.trainer import DPTrainStep
+    from util import build_net
+    cfg = O.make_cfg(img_size=16, in_chans=1, sr_scale=4, embed_dim=60, dense_layer_depths=[2], num_heads=[6], window_size=[8],
+                     rdb_depths=[2], mlp_ratio=2.0, growth_rate=30, pre_norm=True, feature_last_operation=True)
+    g = torch.Generator().manual_seed(11)
+    mk = lambda b: (torch.rand(b, 1, 16, 16, generator=g).to(DEV), torch.rand(b, 1, 64, 64, generator=g).to(DEV))
+    data = [mk(2), mk(2), mk(2), mk(1), mk(2), mk(2)]       # 2 eager, capture + replay, odd-shaped eager, 2 replays
+    recs = {}
+    for use_graph in (False, True):
+        net = build_net(cfg)
+        net.load_state_dict(O.make_weights(cfg, 9), strict=True)
+        net.to(DEV).train().set_compute_dtype(torch.bfloat16)
+        sl, _ = _loss("label-hr", [], "fp32x3")
+        tr = DPTrainStep(net, lr=1e-3, loss_fn=sl, graph=use_graph, graph_warmup=2)
+        for x, t in data:
+            tr.step(x, t)
+        assert (tr.graph is not None) == use_graph
+        recs[use_graph] = {n: list(v) for n, v in tr.loss_records().items()}
+        assert all(len(v) == len(data) for v in recs[use_graph].values()), recs[use_graph]
+        assert tr.checkpoint()["training_loss_records"] == recs[use_graph]      # what step() records reaches the checkpoint
+    assert recs[True] == recs[False], (recs[True], recs[False])
+    for n, v in recs[True].items():     # different batches: a stale report would repeat step 3's values
+        assert v[4] != v[3] and v[5] != v[4], (n, v)

@@ -146,3 +146,41 @@ def test_dense_layer_with_stochastic_depth_in_a_later_block():
     torch.cuda.synchronize()
     for k, p in blk.named_parameters():
         assert (p.grad - 2 * first[k]).norm().item() <= 1e-5 * max(first[k].norm().item(), 1e-6), k
+
+
+def test_two_threads_backward_at_once_vs_oracle():
+    """Two Python threads call backward() on the same device at the same time (two networks, forwards done one after the
+    other): autograd's device thread serves both passes and may interleave their nodes, so a node of one pass can run
+    inside the reduction batch the other pass's dense join opened.  ``_ReduceBatch`` keeps its state per thread (as the
+    C side's queues are) and flushes at every node while two passes are mixed: both gradients equal the oracle's."""
+    import threading
+    nets, losses = [], []
+    for _ in range(2):
+        net, g, x, tgt = _tiny()
+        nets.append(net)
+        losses.append(F.l1_loss(net(x), tgt))
+    torch.cuda.synchronize()
+    errs = []
+
+    def run(l):
+        try:
+            l.backward()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    for rep in range(3):
+        if rep:
+            for net in nets:
+                net.zero_grad(set_to_none=True)
+            losses = [F.l1_loss(net(x), tgt) for net in nets]
+        ts = [threading.Thread(target=run, args=(l,)) for l in losses]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errs, errs
+        for net in nets:
+            _check(net, g, 1.0)
+    from rdst_amd import ops
+    assert ops._ReduceBatch.depth == 0

@@ -181,6 +181,9 @@ def test_trainer_checkpoint_layout_and_resume_from_reference_style_checkpoint(tm
         assert torch.equal(net2.state_dict()[k], v)
     assert net2[0].weight.data_ptr() == tr.optimizer.flat_param.data_ptr()      # still views of the flat buffer
     assert tr.current_epoch == 3 and tr.training_loss_records["L1"] == [0.3, 0.2, 0.1]
+    tr._pending = {"L1": [9.0]}            # a step taken before a (second) load belongs to the history the load replaces
+    tr.load_checkpoint(path)
+    assert tr.loss_records()["L1"] == [0.3, 0.2, 0.1] and tr._pending == {}
     assert tr.optimizer.param_groups[0]["lr"] == ref_opt.param_groups[0]["lr"] == 1e-4 * 0.5   # past milestone 2
     ck = tr.checkpoint()
     assert set(ref_ck) <= set(ck)                                                # every reference key is written
