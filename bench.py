@@ -336,6 +336,9 @@ def main():
     ap.add_argument("--unet-dtype", default=None, choices=["fp32", "fp32x3", "bf16"],
                     help="arithmetic of the seg-UNet loss network (e1_unetf / e1_hrl); default fp32x3: fp32 activations, 3-term bf16 "
                          "split on the matrix cores (the features of SR and HR are DIFFERENCED: bf16 activations are too noisy)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="initialise the process group and run its collectives (broadcast, bucket all-reduce) even with ONE rank: "
+                         "executes the RCCL path on a one-GPU box (launch through torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3, help="replay passes over the recorded launches")
@@ -358,13 +361,20 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or args.force_pg
+    if use_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
 
     from rdst_amd import _lib, dp, optim  # noqa: F401
+    if args.force_pg:
+        dp.FORCE_COLLECTIVES = True
     from rdst_amd.trainer import DPTrainStep
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     cfg, lr_size, in_ch, sr, cfg_name = CONFIGS[args.config]
@@ -403,7 +413,7 @@ def main():
     x, tgt = (tr._static if tr.graph is not None else (x, tgt))   # no per-step input copy: the step reads the static buffers
 
     def sync():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -417,7 +427,7 @@ def main():
     elapsed = time.perf_counter() - t0
     loss_t = tr._loss_buf.detach().clone().double()
     param_sync = None
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -431,7 +441,7 @@ def main():
         param_sync = bool(lo.item() == hi.item())
     loss_val = float(loss_t.item())
     comm = None
-    if world > 1:   # what the collective costs on this fabric: HIP events around 5 all-reduces of the flat bucket
+    if use_pg:   # what the collective costs on this fabric: HIP events around 5 all-reduces of the flat bucket
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         bucket.all_reduce_mean(tr.group)
         sync()
@@ -463,7 +473,7 @@ def main():
         "config": {"workload": cfg_name + f", step = fwd + {step_desc} + bwd + flat-bucket grad all-reduce + Adam",
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "hip_graph": tr.graph is not None, "grad_bucket_bytes": bucket.nbytes,
-                   "backend": (args.backend if world > 1 else None), "unet_dtype": unet_dtype},
+                   "backend": (args.backend if use_pg else None), "unet_dtype": unet_dtype},
         "loss": round(loss_val, 6),
     }
     if param_sync is not None:
@@ -475,7 +485,7 @@ def main():
         # every rank must have run it the same number of times
         nb = loss_obj.loss_functions["UNet-F"].encoder.bn1.num_batches_tracked.detach().to(device).double().reshape(1)
         lo, hi = nb.clone(), nb.clone()
-        if world > 1:
+        if use_pg:
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         out["unet_bn_batches_tracked"] = [int(lo.item()), int(hi.item())]
@@ -520,7 +530,7 @@ def main():
                     out["configs"][n]["cpu_baseline"] = cpu_baseline_collect(h)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

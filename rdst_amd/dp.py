@@ -16,6 +16,11 @@ import torch
 import torch.distributed as dist
 
 
+# A one-rank process group normally skips its collectives (nothing to exchange).  bench.py --force-pg sets this so that the
+# SAME calls the 8-GPU run makes (parameter broadcast, AVG all-reduce of the flat bucket) execute on RCCL with one rank: the
+# transport of row (e) can be exercised on a one-GPU box.
+FORCE_COLLECTIVES = False
+
 # data_ptr of a parameter -> its bucket view, while a detach_grads()/gather() bracket is open (see FlatGradBucket)
 _OFFERED: dict = {}
 
@@ -103,7 +108,7 @@ class FlatGradBucket:
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not FORCE_COLLECTIVES:
             return
         if dist.get_backend(group) == "nccl":      # RCCL averages inside the collective: one kernel fewer
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
@@ -114,7 +119,7 @@ class FlatGradBucket:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every rank start from rank `src`'s parameters and buffers (one flat broadcast each dtype)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES):
         return
     tensors = [p.data for p in module.parameters()] + [b for b in module.buffers() if b is not None]
     by_dtype = {}

@@ -90,3 +90,27 @@ def test_bench_refuses_mismatched_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_one_rank_over_rccl():
+    """The RCCL transport of row (e), executed: `bench.py --gpus 1 --backend nccl --force-pg` through the launcher (a fresh
+    child: the process group is initialised before anything else touches the GPU) — a 1-rank NCCL(=RCCL) process group bound
+    to the device, the parameter broadcast, HIP-graph capture and replays with the NCCL watchdog alive, the AVG all-reduce of
+    the 17.9 MB flat bucket, FlatAdam.  Everything the 8-GPU run does except moving bytes over xGMI."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                          "RDST_BENCH_ONE_GPU")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-pg",
+           "--steps", "3", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp1"
+    assert d["world_size_seen"] == 1 and d["backend"] == "nccl" and d["config"]["backend"] == "nccl"
+    assert d["bucket_bytes"] == 4 * 4464961 and d["all_reduce_ms"] > 0.0
+    assert d["config"]["hip_graph"] is True and d["param_sync"] is True
+    assert d["loss"] == d["loss"] and 0.0 < d["loss"] < 10.0
