@@ -201,6 +201,26 @@ int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, cons
                   float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
                   int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
+/* ---- K8: the attention half of a Swin block in ONE launch ------------------------------------------------------
+ *   x1 = X + proj(WindowAttention(qkv(LayerNorm(X))))     networks/swin_transformer_sr.py:240-271 with :110-141 inside
+ * i.e. rdst_ln_linear_fwd (norm1 + qkv) -> rdst_wattn_fwd -> rdst_ln_linear_fwd (proj + shortcut) without the two round
+ * trips through HBM in between: 6 C instead of 11 C bytes per token.  Writes everything the backward entry points above
+ * read: qkv (M, 3C), a (M, C) = the attention output, x1 (M, C), stats (M, 2) {mean, rstd} of norm1; M = B*H*W.  Results are
+ * bit-identical to the three-call sequence.  Covered: bf16, ws = 8, heads = 6, C = 60 / 90 / 120, the analytic
+ * shifted-window mask (rdst_swin_attn_fwd_supported); everything else returns RDST_ENOTSUP and the caller composes the
+ * three calls.  bqkv / bproj may be NULL.
+ *   workspace : rdst_swin_attn_fwd_workspace(C) bytes, 16-byte aligned, for the packed weight images
+ *               [RDST_PACK_LINEAR_SEC3 image of (Wqkv, ln_w, ln_b, bqkv)][RDST_PACK_LINEAR image of (Wproj, bproj)];
+ *               RDST_PREPACKED = both are already there (rdst_pack_batch, the second at
+ *               workspace + rdst_swin_attn_fwd_workspace(C) - rdst_ln_linear_fwd_workspace(C, C)). */
+int rdst_swin_attn_fwd_supported(int C, int heads, int ws, int dtype);
+size_t rdst_swin_attn_fwd_workspace(int C);
+int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* Wqkv,
+                       const float* bqkv, const float* table, const float* Wproj, const float* bproj, void* qkv,
+                       int64_t ld_qkv, void* a, int64_t ld_a, void* x1, int64_t ld_x1, float* stats, void* workspace,
+                       size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift, float scale,
+                       int dtype, void* stream);
+
 /* ---- batched weight packing ------------------------------------------------------------------------------
  * rdst_ln_linear_fwd and rdst_conv_fwd read their weights as bf16 fragment images that a small pack kernel writes into
  * the op's `workspace` on every call.  rdst_pack_batch writes the images of MANY layers in a handful of launches (e.g.
@@ -212,6 +232,8 @@ int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, cons
 #define RDST_PREPACKED ((size_t)-1)
 #define RDST_PACK_LINEAR 0
 #define RDST_PACK_CONV3_FWD 1
+#define RDST_PACK_LINEAR_SEC3 2   /* a Linear whose N = 3 C outputs are the sections q | k | v, each padded to whole 32-row tiles
+                                     (the qkv half of rdst_swin_attn_fwd's workspace; N % 3 == 0) */
 typedef struct rdst_pack_job {
   int kind;
   const float* W; const float* gamma; const float* beta; const float* bias;

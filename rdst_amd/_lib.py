@@ -37,6 +37,10 @@ SIGNATURES = {
     "rdst_mlp_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_mlp_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p, _z, _l, _i, _i, _i,
                           _p]),
+    "rdst_swin_attn_fwd_supported": (_i, [_i, _i, _i, _i]),
+    "rdst_swin_attn_fwd_workspace": (_z, [_i]),
+    "rdst_swin_attn_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i,
+                                _f, _i, _p]),
     "rdst_conv_fwd_workspace": (_z, [_i, _i, _i]),
     "rdst_conv_fwd": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _l, _p, _z, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
@@ -75,7 +79,7 @@ SIGNATURES = {
     "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
-ABI_VERSION = 8             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
+ABI_VERSION = 9             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 

@@ -57,6 +57,69 @@ __device__ __forceinline__ void lin3_pack_block(int bid, const float* __restrict
 }
 
 
+// The same image for a Linear whose N outputs are `nsec` equal SECTIONS (qkv: q | k | v, N = 3 C), each padded to whole
+// 32-row tiles of its own: tile nt = sec * spt + j holds outputs sec * Cs + 32 j + r (zero rows where 32 j + r >= Cs), so a
+// tile never straddles two sections and the consumer (swinattn_fwd.hip) writes each tile into one LDS section.
+// sb[0][32 nt + r] = S, sb[1][32 nt + r] = b' of that output (0 for the pad rows).
+__device__ __forceinline__ void lin3sec_pack_block(int bid, const float* __restrict__ W, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ bias,
+                                                   bf16* __restrict__ wp, float* __restrict__ sb, int N, int K, int nsec, float s) {
+  const int Cs = N / nsec, spt = (Cs + 31) / 32, ntiles = nsec * spt, ksteps = (K + 15) / 16;
+  const int nfr = ntiles * ksteps * 64, nb1 = (nfr + 255) / 256;
+  if (bid < nb1) {
+    const int i = bid * 256 + threadIdx.x;
+    if (i >= nfr) return;
+    const int lane = i & 63, f = i >> 6;
+    const int ks = f % ksteps, nt = f / ksteps;
+    const int sec = nt / spt, c = (nt - sec * spt) * 32 + (lane & 31);
+    const int n = sec * Cs + c, k0 = ks * 16 + (lane >> 5) * 8;
+    uint32_t w[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int e1 = 0; e1 < 2; ++e1) {
+        const int k = k0 + 2 * e2 + e1;
+        v[e1] = (c < Cs && k < K) ? W[(int64_t)n * K + k] * (gamma ? gamma[k] : 1.f) * s : 0.f;
+      }
+      w[e2] = pack_bf16x2(v[0], v[1]);
+    }
+    u32x4_a4 o;
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    *reinterpret_cast<u32x4_a4*>(wp + (int64_t)i * 8) = o;
+    return;
+  }
+  const int np = (bid - nb1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // padded output index
+  const int NP = ntiles * 32;
+  if (np >= NP) return;
+  const int nt = np >> 5, sec = nt / spt, c = (nt - sec * spt) * 32 + (np & 31), n = sec * Cs + c;
+  float S = 0.f, bb = 0.f;
+  if (c < Cs) {
+    for (int k = lane; k < K; k += 64) {
+      const float w = W[(int64_t)n * K + k];
+      S += __bfloat162float(__float2bfloat16(w * (gamma ? gamma[k] : 1.f) * s));
+      if (beta) bb = fmaf(w, beta[k], bb);
+    }
+    S = wave_sum(S);
+    bb = wave_sum(bb);
+    bb = (bb + (bias ? bias[n] : 0.f)) * s;
+  }
+  if (lane == 0) {
+    sb[np] = S;
+    sb[NP + np] = bb;
+  }
+}
+static __host__ __device__ inline int lin3sec_tiles(int K, int N, int nsec) { (void)K; return nsec * ((N / nsec + 31) / 32); }
+static inline int lin3sec_pack_blocks(int K, int N, int nsec) {
+  const int nt = lin3sec_tiles(K, N, nsec), ks = (K + 15) / 16;
+  return (nt * ks * 64 + 255) / 256 + (nt * 32 + 3) / 4;
+}
+static __host__ __device__ inline size_t lin3sec_pack_bytes(int K, int N, int nsec) {
+  const int nt = lin3sec_tiles(K, N, nsec), ks = (K + 15) / 16;
+  return (size_t)nt * ks * 1024 + (size_t)2 * nt * 32 * 4 + 256;
+}
+
+
 // packed weights: fragment (ct, tap, ks) = 64 lanes x 8 bf16; lane (r, h): output channel n = 32 ct + r,
 // contraction k = 16 ks + 8 h + e.
 //   PK_FWD          : Wc[n][k][tap]

@@ -1,0 +1,610 @@
+// K8: the attention half of a Swin block in ONE launch (bf16, 8x8 windows, 6 heads of dim D = 10 / 15 / 20):
+//     x1 = x + proj(WindowAttention(qkv(LayerNorm(x))))          networks/swin_transformer_sr.py:240-271, :110-141 inside
+// replacing lin3 (LayerNorm + qkv) -> K1 (window attention) -> lin3 (proj + shortcut): those three launches move 11 C bytes
+// per token (qkv and the attention output are written and read back); a window's 64 tokens never meet another window before
+// the Mlp, so one workgroup can take a window from x to x1: 6 C bytes per token (x in; qkv, the attention output a and x1
+// out, the three tensors the backward reads).  The arithmetic is the unfused kernels' arithmetic, operation for operation
+// (same bf16 fragments, same k order, same epilogue formulas, same softmax): the outputs are bit-identical to theirs.
+//
+// One 12-wave workgroup per CU walks windows g, g + G, ...; per window, three workgroup barriers:
+//   top   x(n) and its LayerNorm statistics are in LDS (put there during window n - 1, see below)
+//   G1    qkv = LN(x) Wqkv^T: 6 / 9 / 12 output tiles (q | k | v, each section padded to whole 32-channel tiles of its own:
+//         pack.h lin3sec_pack_block) x 2 token halves.  A wave keeps the fragments of ONE tile in registers for the whole
+//         kernel (16 / 24 / 32 registers), B operands are ds_read_b128 of the raw token rows, LayerNorm enters in the epilogue
+//         (lin3_mfma.hip); the tile goes to the Q / K / V section in LDS (16-byte stores of 8 channels of a token) AND to the
+//         qkv rows in HBM, straight from the registers
+//   B1    attention: wave = (head, query half), one of the 12.  K1's data flow (wattn_mfma_hd.hip: S^T = K Q^T with the
+//         bias / scale as initial accumulator, the shift mask as one more k-step, in-register softmax, O^T = V^T P^T) for ONE
+//         head per wave; O overwrites the wave's own Q channels (nobody else reads them)
+//   B2    waves 4-11: a (the Q section now) -> HBM by row copies; proj + bias + x (the residual is read from the x tile in
+//         LDS) -> x1 rows in HBM; its weights (8 / 18 / 32 KB of fragments) live in LDS.
+//         waves 0-3: wait for the NEXT window's rows — each of them put its own 16 rows in flight by LDS-DMA right after the
+//         top barrier, a whole window earlier — and compute their LayerNorm statistics (4 lanes per token, two passes:
+//         lin3's), so that neither the row fetch nor the statistics are ever on the critical path.
+// No vector register ever holds an input row; the only global loads of the steady state are the LDS-DMA pieces.
+#include "wattn_hd.h"
+#include "pack.h"
+#include "linear.h"
+
+namespace {
+using namespace wahd;
+
+constexpr int SA_NW = 12, SA_NTH = 64 * SA_NW, SA_NLW = 4;   // waves, threads, loader waves (0 .. 3)
+
+struct SAArgs {
+  const bf16* X; int64_t ldx; uint32_t x_bytes;
+  const bf16* Wq; const float* sbq;      // qkv image: fragments [NTQ][KS][64][8], S | b' [2][NTQ * 32]
+  const bf16* Wp; const float* sbp;      // proj image: fragments [NTS][KS][64][8], S | b' [2][NTS * 32]
+  const float* table;
+  bf16* qkv; int64_t ldq;
+  bf16* a; int64_t lda;
+  bf16* x1; int64_t ld1;
+  float* stats;
+  WinGeom g;
+  float scale;
+  int G;
+};
+
+template <int D>
+struct SA {
+  static constexpr int HEADS = 6, C = HEADS * D;
+  static constexpr int KS = (C + 15) / 16, NTS = (C + 31) / 32, NTQ = 3 * NTS;   // 4/6/8 k-steps, 2/3/4 tiles per section
+  // x tile: [64 tokens][XS bytes], odd number of 16-byte slots (b128 row reads), XD slots carry data
+  static constexpr int XS0 = KS * 32, XS = ((XS0 / 16) & 1) ? XS0 : XS0 + 16, XSLOTS = XS / 16, XD = (2 * C + 15) / 16;
+  static constexpr int XBUFB = 64 * XS;
+  static constexpr int WSLOTS = 16 * XSLOTS, WPIECES = (WSLOTS + 63) / 64;       // a loader wave's 16 rows: slots, DMA pieces
+  // Q / K / V sections: K1's row stride
+  static constexpr int SEC = C * 2, LDT0 = ((SEC + 31) / 32) * 32;
+  static constexpr int LDT = LDT0 % 256 == 0 ? LDT0 + 80 : (LDT0 / 16) % 2 == 0 ? LDT0 + 16 : LDT0;
+  static constexpr int SECB = 64 * LDT;
+  static constexpr int TABF = HEADS * 15 * TSX, TABB = TABF + 8;
+  static constexpr int OFF_X = 0;
+  static constexpr int OFF_Q = 2 * XBUFB, OFF_K = OFF_Q + SECB, OFF_V = OFF_K + SECB;
+  static constexpr int OFF_TAB = OFF_V + SECB + 256;                              // (256 zero bytes behind V)
+  static constexpr int OFF_WP = (OFF_TAB + (TABB + TABF + 8) * 4 + 1023) / 1024 * 1024;
+  static constexpr int WPB = NTS * KS * 1024;
+  static constexpr int OFF_SBQ = OFF_WP + WPB;                                    // [2][NTQ * 32] floats
+  static constexpr int SBQB = (2 * NTQ * 32 * 4 + 1023) / 1024 * 1024;
+  static constexpr int OFF_SBP = OFF_SBQ + SBQB;                                  // [2][NTS * 32] floats
+  static constexpr int SBPB = (2 * NTS * 32 * 4 + 1023) / 1024 * 1024;
+  static constexpr int OFF_ST = OFF_SBP + SBPB;                                   // [2 buffers][64][2] floats
+  static constexpr int SMEM = OFF_ST + 2 * 64 * 2 * 4;
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  // a -> HBM: 16-byte chunks of a row, rows per store instruction, rows per storer wave (waves 4 .. 11)
+  static constexpr int CPR = (SEC + 15) / 16, RPI = 64 / CPR, TAILB = SEC - 16 * (CPR - 1), RPW = 64 / (SA_NW - SA_NLW);
+  static constexpr int NAI = (RPW + RPI - 1) / RPI;
+};
+
+struct SaCtx {
+  lds_cp Qp, Kp, Vp, Op;
+  const LDS_AS f32x2* tb;
+  int h;
+  bool masked;
+  float scale2;
+  Pack16 mK[2], mQ;
+};
+
+// one head of one wave: 32 queries (lane & 31) x 64 keys; O (normalised) -> the head's channels of the wave's Q rows
+template <int D, int HD>
+__device__ __forceinline__ void sa_head(const SaCtx& c) {
+  using CF = SA<D>;
+  constexpr int ldt = CF::LDT;
+  constexpr int c_lo = HD * D, c_hi = c_lo + D;
+  constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16;
+  constexpr int r_lo = c_lo & ~3;
+  const int h = c.h;
+  f32x16 X[2];
+  const LDS_AS f32x2* tbh = c.tb + HD * (15 * TSX / 2);
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+      const f32x2 b2 = lds_read_f32x2(tbh + ((7 - (kt * 4 + (v >> 2))) * TSX + (v & 3)) / 2);
+      X[kt][v] = b2.x;
+      X[kt][v + 1] = b2.y;
+    }
+#pragma unroll
+  for (int t = t_lo; t <= t_hi; ++t) {
+    Pack16 qb = lds_pack(c.Qp + t * 32);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t mA = qmask_bits(t * 16 + 2 * e, c_lo, c_hi), mB = qmask_bits(t * 16 + 8 + 2 * e, c_lo, c_hi);
+      qb.w[e] &= h ? mB : mA;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const Pack16 ka = lds_pack(c.Kp + kt * 32 * ldt + t * 32);
+      Mma<bf16>::mma(X[kt], ka, qb);
+    }
+  }
+  if (c.masked) {   // shifted-window mask as one more k-step (wattn_mfma_hd.hip)
+    Mma<bf16>::mma(X[0], c.mK[0], c.mQ);
+    Mma<bf16>::mma(X[1], c.mK[1], c.mQ);
+  }
+  float m = X[0][0];
+#pragma unroll
+  for (int v = 1; v < 16; ++v) m = __builtin_fmaxf(m, X[0][v]);
+#pragma unroll
+  for (int v = 0; v < 16; ++v) m = __builtin_fmaxf(m, X[1][v]);
+  m = half_swap_max(m);
+  const float nm = -c.scale2 * m;
+  float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+      const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(X[kt][v], c.scale2, nm));
+      const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(X[kt][v + 1], c.scale2, nm));
+      l0 += e0;
+      l1 += e1;
+      X[kt][v] = e0;
+      X[kt][v + 1] = e1;
+    }
+  Pack16 pb[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pb[kt][s].w[e] = pack_bf16x2(X[kt][8 * s + 2 * e], X[kt][8 * s + 2 * e + 1]);
+  const float inv = __builtin_amdgcn_rcpf(half_swap_sum(l0 + l1));
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const lds_cp vb = c.Vp + r_lo * 2 + (kt * 32 + 16 * s) * ldt;
+      const Pack16 va = lds_tr_pack(vb, vb + 8 * ldt);
+      Mma<bf16>::mma(acc, va, pb[kt][s]);   // rows = channels r_lo .. r_lo + 31 (V^T), cols = queries
+    }
+  store_tile_rows<r_lo, c_lo, c_hi>(c.Op, acc, inv, h);
+}
+
+template <int D>
+__global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using CF = SA<D>;
+  constexpr int C = CF::C, KS = CF::KS, NTS = CF::NTS, NTQ = CF::NTQ, XS = CF::XS, ldt = CF::LDT;
+  const WinGeom g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wv < SA_NLW;
+  char* Qs = smem + CF::OFF_Q;
+  char* Ks = smem + CF::OFF_K;
+  char* Vs = smem + CF::OFF_V;
+  float* tabL = reinterpret_cast<float*>(smem + CF::OFF_TAB);
+  const float* sbqL = reinterpret_cast<const float*>(smem + CF::OFF_SBQ);
+  const float* sbpL = reinterpret_cast<const float*>(smem + CF::OFF_SBP);
+  float* statL = reinterpret_cast<float*>(smem + CF::OFF_ST);
+
+  typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [&](const void* ptr, uint32_t bytes) {
+    u32x4s_t q;
+    q.x = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ptr);
+    q.y = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)ptr >> 32) & 0xffffu);
+    q.z = __builtin_amdgcn_readfirstlane(bytes);
+    q.w = 0x00020000u;
+    return q;
+  };
+  const u32x4s_t rsx = make_rsrc(p.X, p.x_bytes);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma = [&](const u32x4s_t& rs, uint32_t ldst, uint32_t off) {   // inline asm: see conv3_mfma.hip
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
+  };
+
+  // ---- G1 work of this wave: tile tq, token halves [hf0, hf1) ---------------------------------------------------------
+  //   D = 20: 12 tiles, wave = tile, both halves;  D = 10: 6 tiles x 2 halves = one item per wave;
+  //   D = 15: 9 tiles: waves 0-5 a tile with both halves, waves 6-11 tiles 6-8 with one half each
+  int tq, hf0, hf1;
+  if constexpr (D == 20) { tq = wv; hf0 = 0; hf1 = 2; }
+  else if constexpr (D == 10) { tq = wv % 6; hf0 = wv / 6; hf1 = hf0 + 1; }
+  else {
+    if (wv < 6) { tq = wv; hf0 = 0; hf1 = 2; }
+    else { tq = 6 + (wv - 6) % 3; hf0 = (wv - 6) / 3; hf1 = hf0 + 1; }
+  }
+  // its weight fragments, loaded by inline asm before anything else is in flight (lin3_mfma.hip)
+  typedef uint32_t u32x4v_t __attribute__((ext_vector_type(4)));
+  u32x4v_t wfr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const char* src = reinterpret_cast<const char*>(p.Wq) + (((int64_t)tq * KS + ks) * 64 + lane) * 16;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wfr[ks]) : "v"(src) : "memory");
+  }
+  const int secq = tq / NTS, chq = (tq - secq * NTS) * 32;   // section and first channel of the tile
+
+  const int nW = g.nWh * g.nWw;
+  const int nwin = g.B * nW;
+  struct WinPos { int b, wr, wc; };
+  auto locate = [&](int win) {
+    WinPos w;
+    w.b = win / nW;
+    const int wi = win - w.b * nW;
+    w.wr = wi / g.nWw;
+    w.wc = wi - w.wr * g.nWw;
+    return w;
+  };
+  auto token = [&](const WinPos& w, int t) {   // row of token t (0 .. 63) of the window in the (B H W) activation
+    int rr = w.wr * 8 + (t >> 3) + g.shift;
+    if (rr >= g.H) rr -= g.H;
+    int cc = w.wc * 8 + (t & 7) + g.shift;
+    if (cc >= g.W) cc -= g.W;
+    return (w.b * g.H + rr) * g.W + cc;
+  };
+  // loader wave wv puts rows 16 wv .. 16 wv + 15 of a window in flight: slot s of its region = (row 16 wv + s / XSLOTS, slot)
+  const uint32_t ldxb = (uint32_t)p.ldx * 2u;
+  auto issue = [&](const WinPos& w, int buf, int ln) {
+#pragma unroll
+    for (int i = 0; i < CF::WPIECES; ++i) {
+      const int s = 64 * i + ln;
+      const int rl = s / CF::XSLOTS, sl = s - rl * CF::XSLOTS;
+      const uint32_t t = (uint32_t)token(w, (16 * wv + rl) & 63);
+      const uint32_t off = sl < CF::XD ? t * ldxb + (uint32_t)(sl * 16) : 0xffffffffu;
+      if (s < CF::WSLOTS)
+        dma(rsx, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(CF::OFF_X + buf * CF::XBUFB + 16 * wv * XS + i * 1024)), off);
+    }
+  };
+  // LayerNorm statistics of the loader wave's own 16 rows (4 lanes per token, two passes: lin3_mfma.hip) -> LDS + HBM
+  auto row_stats = [&](const WinPos& w, int buf, int ln) {
+    const int tok = 16 * wv + (ln >> 2), part = ln & 3;
+    const char* tb = smem + CF::OFF_X + buf * CF::XBUFB + tok * XS;
+    constexpr int NSL = (CF::XD + 3) / 4;
+    float xv[NSL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int sl = part + 4 * i;
+      const Pack16 q = *reinterpret_cast<const Pack16*>(tb + (sl < CF::XD ? sl : 0) * 16);
+      Mma<bf16>::unpack(q, xv[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool valid = sl < CF::XD && sl * 8 + e < C;
+        xv[i][e] = valid ? xv[i][e] : 0.f;
+        sum += xv[i][e];
+      }
+    }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float mean = sum * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      const int sl = part + 4 * i;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool valid = sl < CF::XD && sl * 8 + e < C;
+        const float d = xv[i][e] - mean;
+        sq = valid ? fmaf(d, d, sq) : sq;
+      }
+    }
+    sq += __shfl_xor(sq, 1, 64);
+    sq += __shfl_xor(sq, 2, 64);
+    const float rstd = rsqrtf(sq * (1.0f / C) + 1e-5f);
+    if (part == 0) {
+      statL[(buf * 64 + tok) * 2] = mean;
+      statL[(buf * 64 + tok) * 2 + 1] = rstd;
+      *reinterpret_cast<float2*>(p.stats + (int64_t)token(w, tok) * 2) = make_float2(mean, rstd);
+    }
+  };
+
+  int win = blockIdx.x;
+  WinPos cur = locate(win < nwin ? win : 0);
+  if (loader) issue(cur, 0, lane);
+  // ---- one-time LDS state -----------------------------------------------------------------------------------------------
+  for (int i = tid * 16; i < 3 * CF::SECB + 256; i += SA_NTH * 16) *reinterpret_cast<float4*>(Qs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  {  // proj fragments, S / b' of both Linears: plain copies (L2-resident, once per workgroup)
+    const u32x4_a4* src = reinterpret_cast<const u32x4_a4*>(p.Wp);
+    for (int i = tid; i < CF::WPB / 16; i += SA_NTH) *reinterpret_cast<u32x4_a4*>(smem + CF::OFF_WP + i * 16) = src[i];
+    for (int i = tid; i < 2 * NTQ * 32; i += SA_NTH) reinterpret_cast<float*>(smem + CF::OFF_SBQ)[i] = p.sbq[i];
+    for (int i = tid; i < 2 * NTS * 32; i += SA_NTH) reinterpret_cast<float*>(smem + CF::OFF_SBP)[i] = p.sbp[i];
+  }
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float rscale = 1.0f / p.scale;
+  {  // relative-position table / scale, x-reversed, two copies (wattn_mfma_hd.hip)
+    constexpr int NT_SRC = 225 * 6, NLD = (NT_SRC + SA_NTH - 1) / SA_NTH;
+    float tv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int j = tid + SA_NTH * k;
+      tv[k] = p.table[j < NT_SRC ? j : NT_SRC - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int j = tid + SA_NTH * k;
+      if (j < NT_SRC) {
+        const int rel = j / 6, hd = j - rel * 6;
+        const int dy = rel / 15, u = 14 - (rel - dy * 15);
+        const float v = tv[k] * rscale;
+        tabL[(hd * 15 + dy) * TSX + u] = v;
+        if (u >= 1) tabL[CF::TABB + (hd * 15 + dy) * TSX + u - 1] = v;
+      }
+    }
+  }
+  // attention role: wave = (head hd, query half qt)
+  const int qt = wv & 1, hd = wv >> 1;
+  const int yi = qt * 4 + (r >> 3), xi = r & 7;
+  const int thr = g.ws - g.shift;
+  SaCtx c;
+  c.h = h;
+  c.Qp = (lds_cp)(Qs + (qt * 32 + r) * ldt + h * 16);
+  c.Kp = (lds_cp)(Ks + r * ldt + h * 16);
+  {
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    c.Vp = (lds_cp)(Vs + (4 * h + q) * ldt + (16 * (gq & 1) + 4 * pp) * 2);
+  }
+  c.Op = (lds_cp)(Qs + (qt * 32 + r) * ldt);
+  {
+    const int u0 = 4 * h - xi + 7;
+    const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
+    c.tb = (const LDS_AS f32x2*)tb;
+  }
+  const uint32_t cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
+  c.scale2 = p.scale * LOG2E;
+
+  // every load of the prologue has landed (weights, table, proj image, the loader waves' rows of window 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wfr[ks]));
+  if (loader && win < nwin) row_stats(cur, 0, lane);
+
+  int buf = 0;
+  for (; win < nwin; win += p.G) {
+    __syncthreads();   // top: x(n) + statistics in LDS; everybody is done with window n - 1
+    const WinPos w = cur;
+    const int nxt = win + p.G;
+    const bool more = nxt < nwin;
+    cur = locate(more ? nxt : win);
+    int lnw = tid;
+    asm volatile("" : "+v"(lnw));
+    lnw &= 63;
+    if (loader && more) issue(cur, buf ^ 1, lnw);   // in flight for a whole window
+    const char* xb = smem + CF::OFF_X + buf * CF::XBUFB;
+    const float* st = statL + buf * 128;
+
+    // ---- G1: qkv tile(s) of this wave -----------------------------------------------------------------------------------
+    for (int hf = hf0; hf < hf1; ++hf) {
+      const int tok = hf * 32 + r;
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+      const char* brow = xb + tok * XS + h * 16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
+        if (C % 16 != 0 && ks == KS - 1) {   // the row's last slot ends with the next channels of the memory row: zero them
+          constexpr int c0 = C % 16 < 8 ? C % 16 : 8, c1 = C % 16 > 8 ? C % 16 - 8 : 0;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) bq.w[d] = (2 * d < (h ? c1 : c0)) ? bq.w[d] : 0u;
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfr[ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
+      }
+      const float2 mr = *reinterpret_cast<const float2*>(st + tok * 2);
+      const float rstd = mr.y, nrm = -mr.y * mr.x;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n0 = tq * 32 + 8 * g4 + 4 * h;
+        const float4 S4 = *reinterpret_cast<const float4*>(sbqL + n0);
+        const float4 B4 = *reinterpret_cast<const float4*>(sbqL + NTQ * 32 + n0);
+        acc[4 * g4] = fmaf(rstd, acc[4 * g4], fmaf(nrm, S4.x, B4.x));
+        acc[4 * g4 + 1] = fmaf(rstd, acc[4 * g4 + 1], fmaf(nrm, S4.y, B4.y));
+        acc[4 * g4 + 2] = fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4.z, B4.z));
+        acc[4 * g4 + 3] = fmaf(rstd, acc[4 * g4 + 3], fmaf(nrm, S4.w, B4.w));
+      }
+      const int64_t grow = token(w, tok);
+      char* srow = smem + CF::OFF_Q + secq * CF::SECB + tok * ldt;
+      bf16* qrow = p.qkv + grow * p.ldq + secq * C;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float c8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * gp + e]), __float_as_uint(acc[8 * gp + 4 + e]), false, false);
+          c8[e] = __uint_as_float(sw[0]);
+          c8[4 + e] = __uint_as_float(sw[1]);
+        }
+        const int ch = chq + 8 * (2 * gp + h);   // the lane's 8 consecutive channels of the section (zeros from C on)
+        u32x4_t u;
+        u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
+        u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
+        *reinterpret_cast<u32x4_t*>(srow + ch * 2) = u;
+        const int nv = C - ch;
+        if (nv >= 8) {
+          u32x4_a4 o;
+          o.x = u.x; o.y = u.y; o.z = u.z; o.w = u.w;
+          *reinterpret_cast<u32x4_a4*>(qrow + ch) = o;
+        } else if (nv > 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            if (2 * d + 2 <= nv) *reinterpret_cast<uint32_t*>(qrow + ch + 2 * d) = u[d];
+        }
+      }
+    }
+    __syncthreads();   // B1: the window's q | k | v are in LDS
+
+    // ---- attention: (head hd, query half qt) -----------------------------------------------------------------------------
+    {
+      const bool mrow = g.shift > 0 && w.wr == g.nWh - 1, mcol = g.shift > 0 && w.wc == g.nWw - 1;
+      c.masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
+      if (c.masked) {
+        auto onehot = [&](int reg, uint32_t v, Pack16& q) {
+          q.w[0] = h ? 0u : ((reg == 0 ? v : 0u) | (reg == 1 ? v << 16 : 0u));
+          q.w[1] = h ? 0u : ((reg == 2 ? v : 0u) | (reg == 3 ? v << 16 : 0u));
+          q.w[2] = 0u;
+          q.w[3] = 0u;
+        };
+        const int rx = (mcol && xi >= thr) ? 1 : 0;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) onehot(2 * ((mrow && kt * 4 + (r >> 3) >= thr) ? 1 : 0) + rx, 0x3f80u, c.mK[kt]);
+        onehot(2 * ((mrow && yi >= thr) ? 1 : 0) + rx, cbits, c.mQ);
+      }
+      switch (hd) {
+        case 0: sa_head<D, 0>(c); break;
+        case 1: sa_head<D, 1>(c); break;
+        case 2: sa_head<D, 2>(c); break;
+        case 3: sa_head<D, 3>(c); break;
+        case 4: sa_head<D, 4>(c); break;
+        default: sa_head<D, 5>(c); break;
+      }
+    }
+    __syncthreads();   // B2: a (the attention output) lies where q was
+
+    if (loader) {
+      // the next window's rows of this wave have landed (and its qkv stores, issued an attention phase ago, are done)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (more) row_stats(cur, buf ^ 1, lnw);
+    } else {
+      const int sw = wv - SA_NLW;   // 0 .. 7
+      // a rows -> HBM
+#pragma unroll
+      for (int i = 0; i < CF::NAI; ++i) {
+        const int rl = i * CF::RPI + lnw / CF::CPR, chk = lnw % CF::CPR;
+        const int row = sw * CF::RPW + rl;
+        if (lnw < CF::RPI * CF::CPR && rl < CF::RPW) {
+          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Qs + row * ldt + chk * 16);
+          char* dst = reinterpret_cast<char*>(p.a + (int64_t)token(w, row) * p.lda) + chk * 16;
+          if (CF::TAILB == 16 || chk < CF::CPR - 1) {
+            u32x4_a4 o;
+            o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+            *reinterpret_cast<u32x4_a4*>(dst) = o;
+          } else if (CF::TAILB == 8) {
+            u32x2_a4 o;
+            o.x = v.x; o.y = v.y;
+            *reinterpret_cast<u32x2_a4*>(dst) = o;
+          } else {
+            *reinterpret_cast<uint32_t*>(dst) = v.x;
+          }
+        }
+      }
+      // proj + bias + shortcut: item sw = (tile j, token half)
+      if (sw < 2 * NTS) {
+        const int j = sw % NTS, hf = sw / NTS;
+        const int tok = hf * 32 + r;
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+        const char* brow = Qs + tok * ldt + h * 16;
+        const char* wrow = smem + CF::OFF_WP + (j * KS * 64 + lnw) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const Pack16 aw = *reinterpret_cast<const Pack16*>(wrow + ks * 1024);
+          const Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
+          Mma<bf16>::mma(acc, aw, bq);
+        }
+        const char* xr = xb + tok * XS;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n0 = j * 32 + 8 * g4 + 4 * h;
+          const float4 B4 = *reinterpret_cast<const float4*>(sbpL + NTS * 32 + n0);
+          acc[4 * g4] += B4.x; acc[4 * g4 + 1] += B4.y; acc[4 * g4 + 2] += B4.z; acc[4 * g4 + 3] += B4.w;
+          const u32x2_a4 rr = *reinterpret_cast<const u32x2_a4*>(xr + n0 * 2);
+          acc[4 * g4] += bf16lo(rr.x); acc[4 * g4 + 1] += bf16hi(rr.x);
+          acc[4 * g4 + 2] += bf16lo(rr.y); acc[4 * g4 + 3] += bf16hi(rr.y);
+        }
+        bf16* yrow = p.x1 + (int64_t)token(w, tok) * p.ld1;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float c8[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * gp + e]), __float_as_uint(acc[8 * gp + 4 + e]), false, false);
+            c8[e] = __uint_as_float(sx[0]);
+            c8[4 + e] = __uint_as_float(sx[1]);
+          }
+          const int ch = j * 32 + 8 * (2 * gp + h);
+          const int nv = C - ch;
+          if (nv >= 8) {
+            u32x4_a4 o;
+            o.x = pack_bf16x2(c8[0], c8[1]); o.y = pack_bf16x2(c8[2], c8[3]);
+            o.z = pack_bf16x2(c8[4], c8[5]); o.w = pack_bf16x2(c8[6], c8[7]);
+            *reinterpret_cast<u32x4_a4*>(yrow + ch) = o;
+          } else if (nv > 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              if (2 * d + 2 <= nv) *reinterpret_cast<uint32_t*>(yrow + ch + 2 * d) = pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
+          }
+        }
+      }
+    }
+    buf ^= 1;
+  }
+}
+
+template <int D>
+int launch_sa(SAArgs& p, hipStream_t st) {
+  using CF = SA<D>;
+  auto kern = swinattn_fwd_kernel<D>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+    attr = true;
+  }
+  const int64_t nwin = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
+  int64_t G = 256;
+  if (G > nwin) G = nwin;
+  p.G = (int)G;
+  hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SA_NTH), CF::SMEM, st, p);
+  return rdst_launch_status("swinattn_fwd");
+}
+
+}  // namespace
+
+size_t swinattn_pack_bytes(int C) {
+  return lin3sec_pack_bytes(C, 3 * C, 3) + lin3_pack_bytes(C, C);
+}
+bool swinattn_supported(int C, int heads, int ws) { return ws == 8 && heads == 6 && (C == 60 || C == 90 || C == 120); }
+
+int swinattn_pack_launch(const float* ln_w, const float* ln_b, const float* Wqkv, const float* bqkv, const float* Wproj,
+                         const float* bproj, void* out, int C, hipStream_t st);
+
+// bf16, ws 8, 6 heads of dim 10 / 15 / 20, scale > 0; RDST_ENOTSUP otherwise.  wpack: swinattn_pack_bytes(C) bytes = [sectioned qkv
+// image][proj image] (pack.h), written here unless `prepacked`.
+int swinattn_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* Wqkv, const float* bqkv,
+                      const float* table, const float* Wproj, const float* bproj, bf16* qkv, int64_t ldq, bf16* a, int64_t lda,
+                      bf16* x1, int64_t ld1, float* stats, void* wpack, bool prepacked, const WinGeom& g, float scale, hipStream_t st) {
+  const int C = g.C;
+  if (!swinattn_supported(C, g.heads, g.ws) || g.mask || !(scale > 0.f) || !wpack || ((uintptr_t)wpack & 15)) return RDST_ENOTSUP;
+  if (((uintptr_t)X & 3) || (ldx & 1) || ((uintptr_t)qkv & 3) || (ldq & 1) || ((uintptr_t)a & 3) || (lda & 1) || ((uintptr_t)x1 & 3) || (ld1 & 1))
+    return RDST_ENOTSUP;
+  const int64_t M = (int64_t)g.B * g.H * g.W;
+  const int64_t xb = ((M - 1) * ldx + C) * 2;
+  if (xb >= (1ll << 31) || M * ldq * 2 >= (1ll << 31)) return RDST_ENOTSUP;
+  const int ks = (C + 15) / 16, nts = (C + 31) / 32, ntq = 3 * nts;
+  char* img = reinterpret_cast<char*>(wpack);
+  char* img2 = img + lin3sec_pack_bytes(C, 3 * C, 3);
+  if (!prepacked)
+    if (int rc = swinattn_pack_launch(ln_w, ln_b, Wqkv, bqkv, Wproj, bproj, wpack, C, st)) return rc;
+  SAArgs p{};
+  p.X = X; p.ldx = ldx; p.x_bytes = (uint32_t)xb;
+  p.Wq = reinterpret_cast<const bf16*>(img); p.sbq = reinterpret_cast<const float*>(img + (size_t)ntq * ks * 1024);
+  p.Wp = reinterpret_cast<const bf16*>(img2); p.sbp = reinterpret_cast<const float*>(img2 + (size_t)nts * ks * 1024);
+  p.table = table; p.qkv = qkv; p.ldq = ldq; p.a = a; p.lda = lda; p.x1 = x1; p.ld1 = ld1; p.stats = stats; p.g = g; p.scale = scale;
+  if (C == 60) return launch_sa<10>(p, st);
+  if (C == 90) return launch_sa<15>(p, st);
+  return launch_sa<20>(p, st);
+}
+
+namespace {
+__global__ void __launch_bounds__(256) swinattn_pack_kernel(const float* ln_w, const float* ln_b, const float* Wqkv, const float* bqkv,
+                                                            const float* Wproj, const float* bproj, char* out, int C, int nb_q) {
+  const int ks = (C + 15) / 16, nts = (C + 31) / 32, ntq = 3 * nts;
+  if ((int)blockIdx.x < nb_q) {
+    lin3sec_pack_block((int)blockIdx.x, Wqkv, ln_w, ln_b, bqkv, reinterpret_cast<bf16*>(out),
+                       reinterpret_cast<float*>(out + (size_t)ntq * ks * 1024), 3 * C, C, 3, 1.0f);
+  } else {
+    char* o2 = out + lin3sec_pack_bytes(C, 3 * C, 3);
+    lin3_pack_block((int)blockIdx.x - nb_q, Wproj, nullptr, nullptr, bproj, reinterpret_cast<bf16*>(o2),
+                    reinterpret_cast<float*>(o2 + (size_t)nts * ks * 1024), C, C, ks, nts, 1.0f);
+  }
+}
+}  // namespace
+
+int swinattn_pack_launch(const float* ln_w, const float* ln_b, const float* Wqkv, const float* bqkv, const float* Wproj,
+                         const float* bproj, void* out, int C, hipStream_t st) {
+  const int nbq = lin3sec_pack_blocks(C, 3 * C, 3), nbp = lin3_pack_blocks(C, C);
+  hipLaunchKernelGGL(swinattn_pack_kernel, dim3((unsigned)(nbq + nbp)), dim3(256), 0, st, ln_w, ln_b, Wqkv, bqkv, Wproj, bproj,
+                     reinterpret_cast<char*>(out), C, nbq);
+  return rdst_launch_status("swinattn_pack");
+}

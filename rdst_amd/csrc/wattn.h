@@ -89,3 +89,10 @@ int wattn_bwd_mfma_hd(const void* qkv, int64_t ld, const float* table, const voi
 int wattn_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
                    int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int dtype, int* nslab,
                    hipStream_t st);
+
+// K8 (swinattn_fwd.hip): LayerNorm + qkv -> window attention -> proj + shortcut in one launch (bf16, ws 8, 6 heads, C = 60 / 90 / 120)
+size_t swinattn_pack_bytes(int C);
+bool swinattn_supported(int C, int heads, int ws);
+int swinattn_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* Wqkv, const float* bqkv,
+                      const float* table, const float* Wproj, const float* bproj, bf16* qkv, int64_t ldq, bf16* a, int64_t lda,
+                      bf16* x1, int64_t ld1, float* stats, void* wpack, bool prepacked, const WinGeom& g, float scale, hipStream_t st);

@@ -5,7 +5,7 @@
 
 thread_local char g_rdst_err[256] = {0};
 
-extern "C" int rdst_abi_version(void) { return 8; }
+extern "C" int rdst_abi_version(void) { return 9; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {
@@ -77,6 +77,29 @@ extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* tabl
   sj.slab = slab; sj.nwg = nwin; sj.stride = (int64_t)heads * g.T; sj.tot = heads * g.T; sj.map = rbatch::MAP_DTABLE;
   sj.out = dtable; sj.a = heads; sj.b = g.T;
   return rbatch::sum(sj, st);
+}
+
+// ---- K8: the attention half of a Swin block in one launch (swinattn_fwd.hip) ---------------------------------------------------
+extern "C" int rdst_swin_attn_fwd_supported(int C, int heads, int ws, int dtype) {
+  return (dtype == RDST_BF16 && swinattn_supported(C, heads, ws)) ? 1 : 0;
+}
+extern "C" size_t rdst_swin_attn_fwd_workspace(int C) { return C > 0 ? swinattn_pack_bytes(C) : 0; }
+extern "C" int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* Wqkv,
+                                  const float* bqkv, const float* table, const float* Wproj, const float* bproj, void* qkv,
+                                  int64_t ld_qkv, void* a, int64_t ld_a, void* x1, int64_t ld_x1, float* stats, void* workspace,
+                                  size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift, float scale,
+                                  int dtype, void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, nullptr, 0, "rdst_swin_attn_fwd")) return rc;
+  if (!X || !ln_w || !ln_b || !Wqkv || !table || !Wproj || !qkv || !a || !x1 || !stats || !workspace)
+    return rdst_fail(RDST_EINVAL, "rdst_swin_attn_fwd: null pointer");
+  if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_swin_attn_fwd: bad dtype %d", dtype);
+  if (ld_x < C || ld_qkv < 3 * C || ld_a < C || ld_x1 < C) return rdst_fail(RDST_EINVAL, "rdst_swin_attn_fwd: leading dimension too small");
+  if (dtype != RDST_BF16) return RDST_ENOTSUP;
+  const bool prepacked = workspace_bytes == RDST_PREPACKED;
+  if (!prepacked && workspace_bytes < swinattn_pack_bytes(C)) return rdst_fail(RDST_EINVAL, "rdst_swin_attn_fwd: workspace too small");
+  return swinattn_fwd_bf16((const bf16*)X, ld_x, ln_w, ln_b, Wqkv, bqkv, table, Wproj, bproj, (bf16*)qkv, ld_qkv, (bf16*)a, ld_a,
+                           (bf16*)x1, ld_x1, stats, workspace, prepacked, g, scale, (hipStream_t)stream);
 }
 
 // ---- attention dropout (WindowAttention.attn_drop > 0 in training, swin_transformer_sr.py:102,136): the generic kernels with

@@ -148,6 +148,21 @@ class PackPlan:
             return None
         return self.arena.data_ptr() + self.offsets[i]
 
+    def record_swinattn(self, wq, lw, lb, bq, wp, bp, C, nbq, nbp):
+        """The workspace layout of rdst_swin_attn_fwd: the sectioned qkv image (norm1 folded in), then the proj image."""
+        k = ("swinattn", wq.data_ptr(), wp.data_ptr(), _ptr(lw) or 0, _ptr(lb) or 0, _ptr(bq) or 0, _ptr(bp) or 0)
+        if k not in self.keys:
+            self.record(PACK_LINEAR_SEC3, wq, lw, lb, bq, 3 * C, C, 1.0, nbq, key=k)
+            self.record(PACK_LINEAR, wp, None, None, bp, C, C, 1.0, (nbp + 255) // 256 * 256, key=k + ("proj",))
+
+    def lookup_swinattn(self, wq, lw, lb, bq, wp, bp):
+        k = ("swinattn", wq.data_ptr(), wp.data_ptr(), _ptr(lw) or 0, _ptr(lb) or 0, _ptr(bq) or 0, _ptr(bp) or 0)
+        i = self.keys.get(k)
+        if i is None:
+            self.misses += 1
+            return None
+        return self.arena.data_ptr() + self.offsets[i]
+
     @staticmethod
     def signature(owner):
         return (getattr(owner, "compute_dtype", None),) + tuple((p.data_ptr(), p.dtype) for p in owner.parameters())
@@ -195,7 +210,7 @@ _PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # owner modu
 
 def pack_plan_of(owner) -> Optional[PackPlan]:
     return _PLANS.get(owner)
-PACK_LINEAR, PACK_CONV3_FWD = 0, 1
+PACK_LINEAR, PACK_CONV3_FWD, PACK_LINEAR_SEC3 = 0, 1, 2
 
 
 class pack_scope:
@@ -256,6 +271,7 @@ def _packed_workspace(kind, w, lw, lb, b, N, K, s, nbytes, device):
 _side_streams: dict = {}
 TWO_STREAM_BACKWARD = os.environ.get("RDST_TWO_STREAM", "0") != "0"   # env switch: profiling with clean kernel durations
 MLP_FUSED = os.environ.get("RDST_MLP_FUSED", "1") != "0"   # K7 (fused Mlp kernels) on/off
+ATTN_FUSED = os.environ.get("RDST_ATTN_FUSED", "1") != "0"   # K8 (LayerNorm + qkv -> attention -> proj + shortcut in one launch) on/off
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -669,12 +685,36 @@ class _SwinBlock(torch.autograd.Function):
 
         stats1 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n1w_ is not None else None
         qkv = torch.empty(lead + (3 * C,), dtype=dt, device=dev)
-        lin(x_r.data_ptr(), ldx, n1w_, n1b_, ACT_NONE, qkvw_, qkvb_, None, 0, qkv, 3 * C, stats1, C)
         a = torch.empty(lead + (C,), dtype=dt, device=dev)
-        _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
-                                      heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
         x1 = torch.empty(lead + (C,), dtype=dt, device=dev)
-        lin(a.data_ptr(), C, None, None, ACT_NONE, projw_, projb_, x_r.data_ptr(), ldx, x1, C, None, C)
+        fused_attn = (ATTN_FUSED and n1w_ is not None and n1b_ is not None
+                      and bool(lib.rdst_swin_attn_fwd_supported(C, heads, ws, code)))
+        if fused_attn:
+            # K8: norm1 + qkv -> window attention -> proj + shortcut as ONE launch (qkv, a, x1, stats1 for the backward)
+            nbytes = lib.rdst_swin_attn_fwd_workspace(C)
+            wptr, nws, _wsp = None, 0, None
+            if _plan_active is not None:
+                wptr = _plan_active.lookup_swinattn(qkvw_, n1w_, n1b_, qkvb_, projw_, projb_)
+                nws = _lib.PREPACKED
+            if wptr is None:
+                nbp = lib.rdst_ln_linear_fwd_workspace(C, C)
+                if _plan_recording is not None:
+                    _plan_recording.record_swinattn(qkvw_, n1w_, n1b_, qkvb_, projw_, projb_, C, nbytes - nbp, nbp)
+                _wsp = _workspace(nbytes, dev)
+                wptr, nws = _wsp.data_ptr(), nbytes
+            rc = lib.rdst_swin_attn_fwd(x_r.data_ptr(), ldx, n1w_.data_ptr(), n1b_.data_ptr(), qkvw_.data_ptr(), _ptr(qkvb_),
+                                        tab_.data_ptr(), projw_.data_ptr(), _ptr(projb_), qkv.data_ptr(), 3 * C, a.data_ptr(), C,
+                                        x1.data_ptr(), C, stats1.data_ptr(), wptr, nws, B, H, W, C, heads, ws, shift,
+                                        float(scale), code, st)
+            if rc == _lib.ENOTSUP:
+                fused_attn = False
+            else:
+                _lib.check(rc, "rdst_swin_attn_fwd")
+        if not fused_attn:
+            lin(x_r.data_ptr(), ldx, n1w_, n1b_, ACT_NONE, qkvw_, qkvb_, None, 0, qkv, 3 * C, stats1, C)
+            _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
+                                          heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
+            lin(a.data_ptr(), C, None, None, ACT_NONE, projw_, projb_, x_r.data_ptr(), ldx, x1, C, None, C)
         stats2 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n2w_ is not None else None
         y = torch.empty(lead + (C,), dtype=dt, device=dev)
         h = None
