@@ -72,6 +72,10 @@ def _alg(name, a, elt):
     if name == "rdst_wattn_fwd":        # read qkv (3C) + write out (C) per token
         B, H, W, C = a[7:11]
         return B * H * W * 4 * C * elt, 4 * B * H * W * a[12] * a[12] * C
+    if name == "rdst_swin_attn_fwd":    # K8: read x (C); write qkv (3C), a (C), x1 (C) per token (+ 8 bytes of LayerNorm statistics)
+        B, H, W, C = a[18:22]
+        M, N = B * H * W, a[23] * a[23]
+        return M * (6 * C * elt + 8), 2 * M * C * 3 * C + 4 * M * N * C + 2 * M * C * C
     if name == "rdst_wattn_bwd":        # read qkv (3C) + dout (C), write dqkv (3C)
         B, H, W, C = a[12:16]
         return B * H * W * 7 * C * elt, 10 * B * H * W * a[17] * a[17] * C
@@ -104,7 +108,7 @@ def _alg(name, a, elt):
 class Recorder:
     """Wraps the C-ABI entry points of the loaded library: records (name, args) of every call and can leave the calls of
     one entry point out (`skip`), which is how an op's time INSIDE the step is measured (step with - step without)."""
-    OPS = ("rdst_wattn_fwd", "rdst_wattn_bwd", "rdst_ln_linear_fwd", "rdst_ln_linear_bwd", "rdst_ln_linear_bwd2", "rdst_mlp_fwd",
+    OPS = ("rdst_swin_attn_fwd", "rdst_wattn_fwd", "rdst_wattn_bwd", "rdst_ln_linear_fwd", "rdst_ln_linear_bwd", "rdst_ln_linear_bwd2", "rdst_mlp_fwd",
            "rdst_mlp_bwd", "rdst_conv_fwd", "rdst_conv_bwd", "rdst_nchw_to_rows", "rdst_rows_to_nchw")
     STREAM_ARG = {"rdst_ln_linear_bwd2": 24}   # position of the stream argument where it is not the last one
 
@@ -675,13 +679,16 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
                              "back from one HIP graph on the step's own operands (cold: a step's activations are GBs), HIP "
                              "events around the replays; frac_of_peak = max(alg bytes / 8 TB/s, alg FLOPs / dense MFMA peak) / time",
                       "top": table[:8]}
-    # ---- roofline of the window-attention forward kernel (K1) -------------------------------------------------
-    k1 = groups["rdst_wattn_fwd"]
-    k1_ms = next(r["avg_us"] for r in table if r["op"] == "rdst_wattn_fwd") * 1e-3
+    # ---- roofline of the window-attention forward kernel: K8 (the fused attention half of a Swin block: LayerNorm + qkv ->
+    # window attention -> proj + shortcut) where the step runs it, else K1 (window 16, fp32) -------------------------
+    fused = "rdst_swin_attn_fwd" in groups
+    fa, ci = ("rdst_swin_attn_fwd", 21) if fused else ("rdst_wattn_fwd", 10)
+    k1 = groups[fa]
+    k1_ms = next(r["avg_us"] for r in table if r["op"] == fa) * 1e-3
     k1_bytes = sum(_alg(n, a, elt)[0] for n, a in k1) / len(k1)
     per_c = {}
-    for C in sorted({a[10] for _, a in k1}):
-        sub = [(n, a) for n, a in k1 if a[10] == C]
+    for C in sorted({a[ci] for _, a in k1}):
+        sub = [(n, a) for n, a in k1 if a[ci] == C]
         ms = _replay_calls(lib, sub, reps)
         bts = _alg(sub[0][0], sub[0][1], elt)[0]
         per_c[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
@@ -699,7 +706,7 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
                     with torch.cuda.graph(gph):
                         net(x)
             return gph
-        g_full, g_skip = fwd_graph(None), fwd_graph("rdst_wattn_fwd")
+        g_full, g_skip = fwd_graph(None), fwd_graph(fa)
         diffs = sorted(_timed_replay(g_full, 15) - _timed_replay(g_skip, 15) for _ in range(4))   # interleaved
         in_step = 0.5 * (diffs[1] + diffs[2]) / len(k1)
         del g_full, g_skip
@@ -710,7 +717,10 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         t2, t2src = _pmc_traffic("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
         kname, bound_note = "rdst_wattn_fwd (K1, window 16: wattn16_fwd_kernel)", "vector ALU (256 x 256 x 6 exponentials per window); priced against HBM as north_star asks"
     else:
-        traffic, tsrc = _pmc_traffic("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"])
+        if fused:
+            traffic, tsrc = _pmc_traffic("swinattn_fwd_kernel", ["swinattn_fwd.hip", "wattn_hd.h"])
+        else:
+            traffic, tsrc = _pmc_traffic("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"])
         # K2 is two kernels since round 4 (wattn_bwd_mfma.hip, RDST_K2_DMA = 6): C = 60 on wattn_bwd_hd_kernel, C = 90 / 120 on
         # wattn_bwd_pair_kernel; the per-launch traffic of the family is the launch-weighted mean of the two collections
         ta, tasrc = _pmc_traffic("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"])
@@ -722,15 +732,17 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
             t2src = f"{n60} launches x wattn_bwd_hd_kernel ({ta} B) + {nall - n60} x wattn_bwd_pair_kernel ({tb} B): {tasrc}"
         else:
             t2, t2src = None, (tasrc if ta is None else tbsrc)
-        kname, bound_note = "rdst_wattn_fwd (K1, window attention forward)", None
+        kname, bound_note = (("rdst_swin_attn_fwd (K8 = LayerNorm + qkv -> window attention (K1's arithmetic) -> proj + shortcut in one "
+                              "launch; algorithmic bytes 6 C elt + 8 per token: x in; qkv, attention output, x1, statistics out)")
+                             if fused else "rdst_wattn_fwd (K1, window attention forward)"), None
     ach = k1_bytes / (k1_ms * 1e-3) / 1e9
     out["roofline"] = {"kernel": kname, "bound": "hbm",
                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                        "launches": len(k1), "avg_launch_us": round(1e3 * k1_ms, 2),
-                       "how": "COLD: the step's K1 launches (every width, shifted and not) replayed back to back on "
-                              "the step's own buffers, HIP events on the launch stream; in_step = (forward graph with K1) - "
-                              "(forward graph without) / launches, where qkv was just written by the preceding Linear",
+                       "how": "COLD: the step's launches of this kernel (every width, shifted and not) replayed back to back on "
+                              "the step's own buffers, HIP events on the launch stream; in_step = (forward graph with them) - "
+                              "(forward graph without) / launches",
                        "per_shape": per_c, "algorithmic_bytes_per_launch_avg": int(k1_bytes)}
     if bound_note:
         out["roofline"]["note"] = bound_note

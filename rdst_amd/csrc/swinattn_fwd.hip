@@ -29,6 +29,9 @@
 namespace {
 using namespace wahd;
 
+#ifndef SA_ABL
+#define SA_ABL 0   // compile-time ablation switches (tools/abl_build.sh): 1 no qkv stores, 2 no a stores, 4 no x1 stores, 8 no attention,
+#endif             // 16 no G1 arithmetic, 32 no proj arithmetic, 64 no row fetch after the first window
 constexpr int SA_NW = 12, SA_NTH = 64 * SA_NW, SA_NLW = 4;   // waves, threads, loader waves (0 .. 3)
 
 struct SAArgs {
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     int lnw = tid;
     asm volatile("" : "+v"(lnw));
     lnw &= 63;
-    if (loader && more) issue(cur, buf ^ 1, lnw);   // in flight for a whole window
+    if (loader && more && !(SA_ABL & 64)) issue(cur, buf ^ 1, lnw);   // in flight for a whole window
     const char* xb = smem + CF::OFF_X + buf * CF::XBUFB;
     const float* st = statL + buf * 128;
 
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       for (int v = 0; v < 16; ++v) acc[v] = 0.f;
       const char* brow = xb + tok * XS + h * 16;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < ((SA_ABL & 16) ? 0 : KS); ++ks) {
         Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
         if (C % 16 != 0 && ks == KS - 1) {   // the row's last slot ends with the next channels of the memory row: zero them
           constexpr int c0 = C % 16 < 8 ? C % 16 : 8, c1 = C % 16 > 8 ? C % 16 - 8 : 0;
@@ -410,7 +413,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
         u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
         u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
         *reinterpret_cast<u32x4_t*>(srow + ch * 2) = u;
-        const int nv = C - ch;
+        const int nv = (SA_ABL & 1) ? 0 : C - ch;
         if (nv >= 8) {
           u32x4_a4 o;
           o.x = u.x; o.y = u.y; o.z = u.z; o.w = u.w;
@@ -440,6 +443,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
         for (int kt = 0; kt < 2; ++kt) onehot(2 * ((mrow && kt * 4 + (r >> 3) >= thr) ? 1 : 0) + rx, 0x3f80u, c.mK[kt]);
         onehot(2 * ((mrow && yi >= thr) ? 1 : 0) + rx, cbits, c.mQ);
       }
+      if (!(SA_ABL & 8))
       switch (hd) {
         case 0: sa_head<D, 0>(c); break;
         case 1: sa_head<D, 1>(c); break;
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       for (int i = 0; i < CF::NAI; ++i) {
         const int rl = i * CF::RPI + lnw / CF::CPR, chk = lnw % CF::CPR;
         const int row = sw * CF::RPW + rl;
-        if (lnw < CF::RPI * CF::CPR && rl < CF::RPW) {
+        if (lnw < CF::RPI * CF::CPR && rl < CF::RPW && !(SA_ABL & 2)) {
           const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Qs + row * ldt + chk * 16);
           char* dst = reinterpret_cast<char*>(p.a + (int64_t)token(w, row) * p.lda) + chk * 16;
           if (CF::TAILB == 16 || chk < CF::CPR - 1) {
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
         const char* brow = Qs + tok * ldt + h * 16;
         const char* wrow = smem + CF::OFF_WP + (j * KS * 64 + lnw) * 16;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < ((SA_ABL & 32) ? 0 : KS); ++ks) {
           const Pack16 aw = *reinterpret_cast<const Pack16*>(wrow + ks * 1024);
           const Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
           Mma<bf16>::mma(acc, aw, bq);
@@ -514,7 +518,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
             c8[4 + e] = __uint_as_float(sx[1]);
           }
           const int ch = j * 32 + 8 * (2 * gp + h);
-          const int nv = C - ch;
+          const int nv = (SA_ABL & 4) ? 0 : C - ch;
           if (nv >= 8) {
             u32x4_a4 o;
             o.x = pack_bf16x2(c8[0], c8[1]); o.y = pack_bf16x2(c8[2], c8[3]);

@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]]
 # kernel-name substring -> (key in the JSON, source files of that kernel)
 KERNELS = {
+    "swinattn_fwd_kernel": ("swinattn_fwd_kernel", ["swinattn_fwd.hip", "wattn_hd.h"]),
     "wattn_fwd_hd_kernel": ("wattn_fwd_hd_kernel", ["wattn_mfma_hd.hip", "wattn_hd.h"]),
     "wattn_bwd_hd_kernel": ("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"]),
     "wattn_bwd_pair_kernel": ("wattn_bwd_pair_kernel", ["wattn_bwd_pair.hip", "wattn_hd.h"]),
