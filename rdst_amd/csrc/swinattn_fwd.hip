@@ -8,20 +8,23 @@
 //
 // One 12-wave workgroup per CU walks windows g, g + G, ...; per window, three workgroup barriers:
 //   top   x(n) and its LayerNorm statistics are in LDS (put there during window n - 1, see below)
-//   G1    qkv = LN(x) Wqkv^T: 6 / 9 / 12 output tiles (q | k | v, each section padded to whole 32-channel tiles of its own:
+//   A     qkv = LN(x) Wqkv^T: 6 / 9 / 12 output tiles (q | k | v, each section padded to whole 32-channel tiles of its own:
 //         pack.h lin3sec_pack_block) x 2 token halves.  A wave keeps the fragments of ONE tile in registers for the whole
 //         kernel (16 / 24 / 32 registers), B operands are ds_read_b128 of the raw token rows, LayerNorm enters in the epilogue
-//         (lin3_mfma.hip); the tile goes to the Q / K / V section in LDS (16-byte stores of 8 channels of a token) AND to the
-//         qkv rows in HBM, straight from the registers
-//   B1    attention: wave = (head, query half), one of the 12.  K1's data flow (wattn_mfma_hd.hip: S^T = K Q^T with the
-//         bias / scale as initial accumulator, the shift mask as one more k-step, in-register softmax, O^T = V^T P^T) for ONE
-//         head per wave; O overwrites the wave's own Q channels (nobody else reads them)
-//   B2    waves 4-11: a (the Q section now) -> HBM by row copies; proj + bias + x (the residual is read from the x tile in
-//         LDS) -> x1 rows in HBM; its weights (8 / 18 / 32 KB of fragments) live in LDS.
-//         waves 0-3: wait for the NEXT window's rows — each of them put its own 16 rows in flight by LDS-DMA right after the
-//         top barrier, a whole window earlier — and compute their LayerNorm statistics (4 lanes per token, two passes:
-//         lin3's), so that neither the row fetch nor the statistics are ever on the critical path.
-// No vector register ever holds an input row; the only global loads of the steady state are the LDS-DMA pieces.
+//         (lin3_mfma.hip); the tile goes to the Q / K / V section in LDS (16-byte stores of 8 channels of a token).
+//         Beside it (the matrix pipe hides it): the PREVIOUS window's x1 rows leave for HBM (see C)
+//   B1    waves 0-3 put the next window's rows in flight by LDS-DMA (each its own 16 rows); waves 4-11 copy the window's qkv
+//         rows out of the sections, whole rows, a 16-byte chunk per lane; then attention: wave = (head, query half), one of the
+//         12.  K1's data flow (wattn_mfma_hd.hip: S^T = K Q^T with the bias / scale as initial accumulator, the shift mask as
+//         one more k-step, in-register softmax, O^T = V^T P^T) for ONE head per wave; O goes to its own tile
+//   B2    waves 4-11: a (the O tile) -> HBM by row copies; proj + bias + x, with the residual read from the x tile in LDS and
+//         x1 written back IN PLACE (its row copy to HBM rides on the next window's phase A); the proj fragments (8 / 18 /
+//         32 KB) live in LDS.  waves 0-3: wait for the next window's rows and compute their LayerNorm statistics (4 lanes per
+//         token, two passes: lin3's): neither the row fetch nor the statistics are ever on the critical path.
+// Every output row leaves through LDS as whole-row copies (consecutive lanes = consecutive 16-byte chunks of a row): the
+// first cut stored qkv and x1 straight from the accumulators, 16 bytes per lane into 32 different rows per instruction, and
+// spent 22 of its 61 us (C = 120) issuing those stores.  No vector register ever holds an input row; the only global loads
+// of the steady state are the LDS-DMA pieces.
 #include "wattn_hd.h"
 #include "pack.h"
 #include "linear.h"
@@ -32,6 +35,9 @@ using namespace wahd;
 #ifndef SA_ABL
 #define SA_ABL 0   // compile-time ablation switches (tools/abl_build.sh): 1 no qkv stores, 2 no a stores, 4 no x1 stores, 8 no attention,
 #endif             // 16 no G1 arithmetic, 32 no proj arithmetic, 64 no row fetch after the first window
+#ifndef SA_QKV_DIRECT
+#define SA_QKV_DIRECT 1   // 1: the qkv tiles go to HBM straight from the accumulators (16 bytes of a token per lane); 0: as whole-row
+#endif                    // copies out of the sections during the attention phase.  Measured equal within 2 us at every width
 constexpr int SA_NW = 12, SA_NTH = 64 * SA_NW, SA_NLW = 4;   // waves, threads, loader waves (0 .. 3)
 
 struct SAArgs {
@@ -56,14 +62,16 @@ struct SA {
   static constexpr int XS0 = KS * 32, XS = ((XS0 / 16) & 1) ? XS0 : XS0 + 16, XSLOTS = XS / 16, XD = (2 * C + 15) / 16;
   static constexpr int XBUFB = 64 * XS;
   static constexpr int WSLOTS = 16 * XSLOTS, WPIECES = (WSLOTS + 63) / 64;       // a loader wave's 16 rows: slots, DMA pieces
-  // Q / K / V sections: K1's row stride
+  // Q / K sections and the O tile: row stride XS (b128 row reads only); V: K1's row stride (transposed reads: a 256-byte row
+  // gets 80 more bytes, wattn_mfma_hd.hip)
   static constexpr int SEC = C * 2, LDT0 = ((SEC + 31) / 32) * 32;
-  static constexpr int LDT = LDT0 % 256 == 0 ? LDT0 + 80 : (LDT0 / 16) % 2 == 0 ? LDT0 + 16 : LDT0;
-  static constexpr int SECB = 64 * LDT;
+  static constexpr int LDV = LDT0 % 256 == 0 ? LDT0 + 80 : (LDT0 / 16) % 2 == 0 ? LDT0 + 16 : LDT0;
+  static constexpr int LDQ = XS;
   static constexpr int TABF = HEADS * 15 * TSX, TABB = TABF + 8;
   static constexpr int OFF_X = 0;
-  static constexpr int OFF_Q = 2 * XBUFB, OFF_K = OFF_Q + SECB, OFF_V = OFF_K + SECB;
-  static constexpr int OFF_TAB = OFF_V + SECB + 256;                              // (256 zero bytes behind V)
+  static constexpr int OFF_Q = 2 * XBUFB, OFF_K = OFF_Q + 64 * LDQ, OFF_V = OFF_K + 64 * LDQ, OFF_O = OFF_V + 64 * LDV + 256;
+  static constexpr int ZEROB = OFF_O + 64 * LDQ - OFF_Q;                          // Q, K, V, 256 spare bytes, O: zeroed once
+  static constexpr int OFF_TAB = OFF_O + 64 * LDQ;
   static constexpr int OFF_WP = (OFF_TAB + (TABB + TABF + 8) * 4 + 1023) / 1024 * 1024;
   static constexpr int WPB = NTS * KS * 1024;
   static constexpr int OFF_SBQ = OFF_WP + WPB;                                    // [2][NTQ * 32] floats
@@ -73,10 +81,31 @@ struct SA {
   static constexpr int OFF_ST = OFF_SBP + SBPB;                                   // [2 buffers][64][2] floats
   static constexpr int SMEM = OFF_ST + 2 * 64 * 2 * 4;
   static_assert(SMEM <= 160 * 1024, "LDS");
-  // a -> HBM: 16-byte chunks of a row, rows per store instruction, rows per storer wave (waves 4 .. 11)
-  static constexpr int CPR = (SEC + 15) / 16, RPI = 64 / CPR, TAILB = SEC - 16 * (CPR - 1), RPW = 64 / (SA_NW - SA_NLW);
-  static constexpr int NAI = (RPW + RPI - 1) / RPI;
+  // row copies to HBM: 16-byte chunks per row of C channels (a, x1) / of 3 C channels (qkv); bytes of the last chunk
+  static constexpr int CPR = (SEC + 15) / 16, TAILB = SEC - 16 * (CPR - 1);
+  static constexpr int CPR3 = (3 * SEC + 15) / 16, TAILB3 = 3 * SEC - 16 * (CPR3 - 1);
+  static constexpr int sec_off(int sec) { return sec == 0 ? OFF_Q : sec == 1 ? OFF_K : OFF_V; }
+  static constexpr int sec_ld(int sec) { return sec == 2 ? LDV : LDQ; }
 };
+
+// store the first `nb` (4, 8, 12 or 16) bytes of a 16-byte chunk; dst is dword aligned
+__device__ __forceinline__ void store_chunk(char* dst, const u32x4_t& v, int nb) {
+  if (nb >= 16) {
+    u32x4_a4 o;
+    o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+    *reinterpret_cast<u32x4_a4*>(dst) = o;
+  } else if (nb == 12) {
+    u32x3_a4 o;
+    o.x = v.x; o.y = v.y; o.z = v.z;
+    *reinterpret_cast<u32x3_a4*>(dst) = o;
+  } else if (nb == 8) {
+    u32x2_a4 o;
+    o.x = v.x; o.y = v.y;
+    *reinterpret_cast<u32x2_a4*>(dst) = o;
+  } else {
+    *reinterpret_cast<uint32_t*>(dst) = v.x;
+  }
+}
 
 struct SaCtx {
   lds_cp Qp, Kp, Vp, Op;
@@ -87,11 +116,11 @@ struct SaCtx {
   Pack16 mK[2], mQ;
 };
 
-// one head of one wave: 32 queries (lane & 31) x 64 keys; O (normalised) -> the head's channels of the wave's Q rows
-template <int D, int HD>
-__device__ __forceinline__ void sa_head(const SaCtx& c) {
+// one head of one wave: 32 queries (lane & 31) x 64 keys; O (normalised) -> the head's channels of the wave's rows of the O tile
+template <int D, int HD, class IO>
+__device__ __forceinline__ void sa_head(const SaCtx& c, IO io) {
   using CF = SA<D>;
-  constexpr int ldt = CF::LDT;
+  constexpr int ldq = CF::LDQ, ldv = CF::LDV;
   constexpr int c_lo = HD * D, c_hi = c_lo + D;
   constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16;
   constexpr int r_lo = c_lo & ~3;
@@ -116,7 +145,7 @@ __device__ __forceinline__ void sa_head(const SaCtx& c) {
     }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      const Pack16 ka = lds_pack(c.Kp + kt * 32 * ldt + t * 32);
+      const Pack16 ka = lds_pack(c.Kp + kt * 32 * ldq + t * 32);
       Mma<bf16>::mma(X[kt], ka, qb);
     }
   }
@@ -124,6 +153,7 @@ __device__ __forceinline__ void sa_head(const SaCtx& c) {
     Mma<bf16>::mma(X[0], c.mK[0], c.mQ);
     Mma<bf16>::mma(X[1], c.mK[1], c.mQ);
   }
+  io(0);   // (row copies to HBM trickle out between the stages: a burst in front of the head blocks the wave at the store queue)
   float m = X[0][0];
 #pragma unroll
   for (int v = 1; v < 16; ++v) m = __builtin_fmaxf(m, X[0][v]);
@@ -151,6 +181,7 @@ __device__ __forceinline__ void sa_head(const SaCtx& c) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) pb[kt][s].w[e] = pack_bf16x2(X[kt][8 * s + 2 * e], X[kt][8 * s + 2 * e + 1]);
   const float inv = __builtin_amdgcn_rcpf(half_swap_sum(l0 + l1));
+  io(1);
   f32x16 acc;
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] = 0.f;
@@ -158,10 +189,11 @@ __device__ __forceinline__ void sa_head(const SaCtx& c) {
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const lds_cp vb = c.Vp + r_lo * 2 + (kt * 32 + 16 * s) * ldt;
-      const Pack16 va = lds_tr_pack(vb, vb + 8 * ldt);
+      const lds_cp vb = c.Vp + r_lo * 2 + (kt * 32 + 16 * s) * ldv;
+      const Pack16 va = lds_tr_pack(vb, vb + 8 * ldv);
       Mma<bf16>::mma(acc, va, pb[kt][s]);   // rows = channels r_lo .. r_lo + 31 (V^T), cols = queries
     }
+  io(2);
   store_tile_rows<r_lo, c_lo, c_hi>(c.Op, acc, inv, h);
 }
 
@@ -169,7 +201,7 @@ template <int D>
 __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CF = SA<D>;
-  constexpr int C = CF::C, KS = CF::KS, NTS = CF::NTS, NTQ = CF::NTQ, XS = CF::XS, ldt = CF::LDT;
+  constexpr int C = CF::C, KS = CF::KS, NTS = CF::NTS, NTQ = CF::NTQ, XS = CF::XS, ldq = CF::LDQ, ldv = CF::LDV;
   const WinGeom g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,6 +209,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
   char* Qs = smem + CF::OFF_Q;
   char* Ks = smem + CF::OFF_K;
   char* Vs = smem + CF::OFF_V;
+  char* Os = smem + CF::OFF_O;
   float* tabL = reinterpret_cast<float*>(smem + CF::OFF_TAB);
   const float* sbqL = reinterpret_cast<const float*>(smem + CF::OFF_SBQ);
   const float* sbpL = reinterpret_cast<const float*>(smem + CF::OFF_SBP);
@@ -297,7 +330,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
   WinPos cur = locate(win < nwin ? win : 0);
   if (loader) issue(cur, 0, lane);
   // ---- one-time LDS state -----------------------------------------------------------------------------------------------
-  for (int i = tid * 16; i < 3 * CF::SECB + 256; i += SA_NTH * 16) *reinterpret_cast<float4*>(Qs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid * 16; i < CF::ZEROB; i += SA_NTH * 16) *reinterpret_cast<float4*>(Qs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   {  // proj fragments, S / b' of both Linears: plain copies (L2-resident, once per workgroup)
     const u32x4_a4* src = reinterpret_cast<const u32x4_a4*>(p.Wp);
     for (int i = tid; i < CF::WPB / 16; i += SA_NTH) *reinterpret_cast<u32x4_a4*>(smem + CF::OFF_WP + i * 16) = src[i];
@@ -332,13 +365,13 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
   const int thr = g.ws - g.shift;
   SaCtx c;
   c.h = h;
-  c.Qp = (lds_cp)(Qs + (qt * 32 + r) * ldt + h * 16);
-  c.Kp = (lds_cp)(Ks + r * ldt + h * 16);
+  c.Qp = (lds_cp)(Qs + (qt * 32 + r) * ldq + h * 16);
+  c.Kp = (lds_cp)(Ks + r * ldq + h * 16);
   {
     const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    c.Vp = (lds_cp)(Vs + (4 * h + q) * ldt + (16 * (gq & 1) + 4 * pp) * 2);
+    c.Vp = (lds_cp)(Vs + (4 * h + q) * ldv + (16 * (gq & 1) + 4 * pp) * 2);
   }
-  c.Op = (lds_cp)(Qs + (qt * 32 + r) * ldt);
+  c.Op = (lds_cp)(Os + (qt * 32 + r) * ldq);
   {
     const int u0 = 4 * h - xi + 7;
     const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
@@ -353,7 +386,46 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wfr[ks]));
   if (loader && win < nwin) row_stats(cur, 0, lane);
 
+  // whole-row copies LDS -> HBM: instruction i of a tile moves chunks 64 i .. 64 i + 63 of its 64 x CPR chunks; the waves
+  // [w0, w0 + nwv) share the instructions
+  auto copy_rows = [&](const char* tile, int ld, bf16* dstp, int64_t ldd, const WinPos& w, int ln, int w0, int nwv) {
+    for (int i = wv - w0; i < CF::CPR; i += nwv) {
+      const int f = 64 * i + ln;
+      const int row = f / CF::CPR, chk = f - row * CF::CPR;
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(tile + row * ld + chk * 16);
+      char* dst = reinterpret_cast<char*>(dstp + (int64_t)token(w, row) * ldd) + chk * 16;
+      store_chunk(dst, v, (CF::TAILB == 16 || chk < CF::CPR - 1) ? 16 : CF::TAILB);
+    }
+  };
+  // the window's qkv rows (3 C channels: the Q, K and V sections side by side), waves [w0, w0 + nwv)
+  auto copy_qkv = [&](const WinPos& w, int ln, int w0, int nwv, int part, int nparts) {
+    for (int i = wv - w0 + nwv * part; i < CF::CPR3; i += nwv * nparts) {
+      const int f = 64 * i + ln;
+      const int row = f / CF::CPR3, chk = f - row * CF::CPR3;
+      const int b0 = chk * 16;
+      u32x4_t v;
+      if constexpr (CF::SEC % 16 == 0) {
+        const int sec = (b0 >= CF::SEC ? 1 : 0) + (b0 >= 2 * CF::SEC ? 1 : 0);
+        const char* src = smem + (sec == 0 ? CF::OFF_Q : sec == 1 ? CF::OFF_K : CF::OFF_V) + row * (sec == 2 ? ldv : ldq) + (b0 - sec * CF::SEC);
+        v = *reinterpret_cast<const u32x4_t*>(src);
+      } else {   // a chunk may straddle two sections: dword by dword
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          int b = b0 + 4 * d;
+          b = b < 3 * CF::SEC ? b : 3 * CF::SEC - 4;
+          const int sec = (b >= CF::SEC ? 1 : 0) + (b >= 2 * CF::SEC ? 1 : 0);
+          const char* src = smem + (sec == 0 ? CF::OFF_Q : sec == 1 ? CF::OFF_K : CF::OFF_V) + row * (sec == 2 ? ldv : ldq) + (b - sec * CF::SEC);
+          v[d] = *reinterpret_cast<const uint32_t*>(src);
+        }
+      }
+      char* dst = reinterpret_cast<char*>(p.qkv + (int64_t)token(w, row) * p.ldq) + b0;
+      store_chunk(dst, v, (CF::TAILB3 == 16 || chk < CF::CPR3 - 1) ? 16 : CF::TAILB3);
+    }
+  };
+
   int buf = 0;
+  bool have_prev = false;
+  WinPos prev = cur;
   for (; win < nwin; win += p.G) {
     __syncthreads();   // top: x(n) + statistics in LDS; everybody is done with window n - 1
     const WinPos w = cur;
@@ -363,11 +435,10 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     int lnw = tid;
     asm volatile("" : "+v"(lnw));
     lnw &= 63;
-    if (loader && more && !(SA_ABL & 64)) issue(cur, buf ^ 1, lnw);   // in flight for a whole window
-    const char* xb = smem + CF::OFF_X + buf * CF::XBUFB;
+    char* xb = smem + CF::OFF_X + buf * CF::XBUFB;
     const float* st = statL + buf * 128;
 
-    // ---- G1: qkv tile(s) of this wave -----------------------------------------------------------------------------------
+    // ---- A: qkv tile(s) of this wave -> the sections ------------------------------------------------------------------------
     for (int hf = hf0; hf < hf1; ++hf) {
       const int tok = hf * 32 + r;
       f32x16 acc;
@@ -396,9 +467,8 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
         acc[4 * g4 + 2] = fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4.z, B4.z));
         acc[4 * g4 + 3] = fmaf(rstd, acc[4 * g4 + 3], fmaf(nrm, S4.w, B4.w));
       }
-      const int64_t grow = token(w, tok);
-      char* srow = smem + CF::OFF_Q + secq * CF::SECB + tok * ldt;
-      bf16* qrow = p.qkv + grow * p.ldq + secq * C;
+      char* srow = smem + (secq == 0 ? CF::OFF_Q : secq == 1 ? CF::OFF_K : CF::OFF_V) + tok * (secq == 2 ? ldv : ldq);
+      bf16* qrow = p.qkv + (int64_t)token(w, tok) * p.ldq + secq * C;
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
         float c8[8];
@@ -413,21 +483,23 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
         u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
         u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
         *reinterpret_cast<u32x4_t*>(srow + ch * 2) = u;
-        const int nv = (SA_ABL & 1) ? 0 : C - ch;
-        if (nv >= 8) {
-          u32x4_a4 o;
-          o.x = u.x; o.y = u.y; o.z = u.z; o.w = u.w;
-          *reinterpret_cast<u32x4_a4*>(qrow + ch) = o;
-        } else if (nv > 0) {
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            if (2 * d + 2 <= nv) *reinterpret_cast<uint32_t*>(qrow + ch + 2 * d) = u[d];
+        if (SA_QKV_DIRECT && !(SA_ABL & 1)) {
+          const int nv = C - ch;
+          if (nv >= 8) store_chunk(reinterpret_cast<char*>(qrow + ch), u, 16);
+          else if (nv > 0) store_chunk(reinterpret_cast<char*>(qrow + ch), u, 2 * nv);   // 4 (C = 90) or 8 (C = 60) bytes
         }
       }
     }
-    __syncthreads();   // B1: the window's q | k | v are in LDS
+    // the previous window's x1 rows (written in place of its x tile, phase C) and a rows (the O tile) -> HBM
+    if (have_prev && !(SA_ABL & 4)) copy_rows(smem + CF::OFF_X + (buf ^ 1) * CF::XBUFB, XS, p.x1, p.ld1, prev, lnw, 0, SA_NW);
+    if (have_prev && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
+    __syncthreads();   // B1: the window's q | k | v are in LDS; the other x buffer is free
 
-    // ---- attention: (head hd, query half qt) -----------------------------------------------------------------------------
+    // ---- B: next rows in flight, qkv rows out, attention -------------------------------------------------------------------
+    if (loader && more && !(SA_ABL & 64)) issue(cur, buf ^ 1, lnw);
+    auto io = [&](int k) {
+      if (!SA_QKV_DIRECT && !loader && !(SA_ABL & 1)) copy_qkv(w, lnw, SA_NLW, SA_NW - SA_NLW, k, 3);
+    };
     {
       const bool mrow = g.shift > 0 && w.wr == g.nWh - 1, mcol = g.shift > 0 && w.wc == g.nWw - 1;
       c.masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
@@ -445,51 +517,30 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       }
       if (!(SA_ABL & 8))
       switch (hd) {
-        case 0: sa_head<D, 0>(c); break;
-        case 1: sa_head<D, 1>(c); break;
-        case 2: sa_head<D, 2>(c); break;
-        case 3: sa_head<D, 3>(c); break;
-        case 4: sa_head<D, 4>(c); break;
-        default: sa_head<D, 5>(c); break;
+        case 0: sa_head<D, 0>(c, io); break;
+        case 1: sa_head<D, 1>(c, io); break;
+        case 2: sa_head<D, 2>(c, io); break;
+        case 3: sa_head<D, 3>(c, io); break;
+        case 4: sa_head<D, 4>(c, io); break;
+        default: sa_head<D, 5>(c, io); break;
       }
     }
-    __syncthreads();   // B2: a (the attention output) lies where q was
+    __syncthreads();   // B2: the attention output a is in the O tile
 
+    // ---- C: a rows out, proj + shortcut (x1 in place of x); the loader waves: statistics of the next window ------------
     if (loader) {
-      // the next window's rows of this wave have landed (and its qkv stores, issued an attention phase ago, are done)
+      // the next window's rows of this wave have landed (issued an attention phase ago)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (more) row_stats(cur, buf ^ 1, lnw);
     } else {
       const int sw = wv - SA_NLW;   // 0 .. 7
-      // a rows -> HBM
-#pragma unroll
-      for (int i = 0; i < CF::NAI; ++i) {
-        const int rl = i * CF::RPI + lnw / CF::CPR, chk = lnw % CF::CPR;
-        const int row = sw * CF::RPW + rl;
-        if (lnw < CF::RPI * CF::CPR && rl < CF::RPW && !(SA_ABL & 2)) {
-          const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Qs + row * ldt + chk * 16);
-          char* dst = reinterpret_cast<char*>(p.a + (int64_t)token(w, row) * p.lda) + chk * 16;
-          if (CF::TAILB == 16 || chk < CF::CPR - 1) {
-            u32x4_a4 o;
-            o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
-            *reinterpret_cast<u32x4_a4*>(dst) = o;
-          } else if (CF::TAILB == 8) {
-            u32x2_a4 o;
-            o.x = v.x; o.y = v.y;
-            *reinterpret_cast<u32x2_a4*>(dst) = o;
-          } else {
-            *reinterpret_cast<uint32_t*>(dst) = v.x;
-          }
-        }
-      }
-      // proj + bias + shortcut: item sw = (tile j, token half)
-      if (sw < 2 * NTS) {
+      if (sw < 2 * NTS) {   // item sw = (tile j, token half)
         const int j = sw % NTS, hf = sw / NTS;
         const int tok = hf * 32 + r;
         f32x16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const char* brow = Qs + tok * ldt + h * 16;
+        const char* brow = Os + tok * ldq + h * 16;
         const char* wrow = smem + CF::OFF_WP + (j * KS * 64 + lnw) * 16;
 #pragma unroll
         for (int ks = 0; ks < ((SA_ABL & 32) ? 0 : KS); ++ks) {
@@ -497,42 +548,31 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
           const Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
           Mma<bf16>::mma(acc, aw, bq);
         }
-        const char* xr = xb + tok * XS;
+        char* xr = xb + tok * XS;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int n0 = j * 32 + 8 * g4 + 4 * h;
           const float4 B4 = *reinterpret_cast<const float4*>(sbpL + NTS * 32 + n0);
-          acc[4 * g4] += B4.x; acc[4 * g4 + 1] += B4.y; acc[4 * g4 + 2] += B4.z; acc[4 * g4 + 3] += B4.w;
           const u32x2_a4 rr = *reinterpret_cast<const u32x2_a4*>(xr + n0 * 2);
-          acc[4 * g4] += bf16lo(rr.x); acc[4 * g4 + 1] += bf16hi(rr.x);
-          acc[4 * g4 + 2] += bf16lo(rr.y); acc[4 * g4 + 3] += bf16hi(rr.y);
-        }
-        bf16* yrow = p.x1 + (int64_t)token(w, tok) * p.ld1;
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-          float c8[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * gp + e]), __float_as_uint(acc[8 * gp + 4 + e]), false, false);
-            c8[e] = __uint_as_float(sx[0]);
-            c8[4 + e] = __uint_as_float(sx[1]);
-          }
-          const int ch = j * 32 + 8 * (2 * gp + h);
-          const int nv = (SA_ABL & 4) ? 0 : C - ch;
-          if (nv >= 8) {
-            u32x4_a4 o;
-            o.x = pack_bf16x2(c8[0], c8[1]); o.y = pack_bf16x2(c8[2], c8[3]);
-            o.z = pack_bf16x2(c8[4], c8[5]); o.w = pack_bf16x2(c8[6], c8[7]);
-            *reinterpret_cast<u32x4_a4*>(yrow + ch) = o;
-          } else if (nv > 0) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d)
-              if (2 * d + 2 <= nv) *reinterpret_cast<uint32_t*>(yrow + ch + 2 * d) = pack_bf16x2(c8[2 * d], c8[2 * d + 1]);
-          }
+          const float y0 = acc[4 * g4] + B4.x + bf16lo(rr.x), y1 = acc[4 * g4 + 1] + B4.y + bf16hi(rr.x);
+          const float y2 = acc[4 * g4 + 2] + B4.z + bf16lo(rr.y), y3 = acc[4 * g4 + 3] + B4.w + bf16hi(rr.y);
+          u32x2_a4 o;
+          o.x = pack_bf16x2(y0, y1); o.y = pack_bf16x2(y2, y3);
+          if (n0 < C) *reinterpret_cast<u32x2_a4*>(xr + n0 * 2) = o;   // x1 where x was (this item's own 4 channels of its own token)
         }
       }
     }
+    prev = w;
+    have_prev = true;
     buf ^= 1;
+  }
+  __syncthreads();
+  if (have_prev && !(SA_ABL & 4)) {   // the last window's x1 rows
+    int lnw = tid;
+    asm volatile("" : "+v"(lnw));
+    lnw &= 63;
+    copy_rows(smem + CF::OFF_X + (buf ^ 1) * CF::XBUFB, XS, p.x1, p.ld1, prev, lnw, 0, SA_NW);
+    if (!(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
   }
 }
 
