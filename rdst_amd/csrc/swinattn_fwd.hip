@@ -28,6 +28,7 @@
 #include "wattn_hd.h"
 #include "pack.h"
 #include "linear.h"
+#include <stdlib.h>
 
 namespace {
 using namespace wahd;
@@ -52,6 +53,9 @@ struct SAArgs {
   WinGeom g;
   float scale;
   int G;
+#ifdef SA_STAMPS
+  unsigned long long* stamps;   // [grid][12 waves][8] accumulated cycles per phase (diagnostic build only: tools/abl_build.sh -DSA_STAMPS)
+#endif
 };
 
 template <int D>
@@ -426,8 +430,16 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
   int buf = 0;
   bool have_prev = false;
   WinPos prev = cur;
+#ifdef SA_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter(), tn;
+#define SA_ST(k) { tn = __builtin_readcyclecounter(); tacc[k] += tn - tl; tl = tn; }
+#else
+#define SA_ST(k)
+#endif
+  SA_ST(0)   // 0: prologue
   for (; win < nwin; win += p.G) {
     __syncthreads();   // top: x(n) + statistics in LDS; everybody is done with window n - 1
+    SA_ST(1)   // 1: wait at the top barrier
     const WinPos w = cur;
     const int nxt = win + p.G;
     const bool more = nxt < nwin;
@@ -439,33 +451,48 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     const float* st = statL + buf * 128;
 
     // ---- A: qkv tile(s) of this wave -> the sections ------------------------------------------------------------------------
-    for (int hf = hf0; hf < hf1; ++hf) {
+    // both token halves' MFMA chains are issued before either epilogue: the second chain runs on the matrix pipe while the
+    // first tile is finished on the vector ALUs (in program order chain, epilogue, chain, epilogue the pipe idles)
+    // One item = (tile tq, token half hf).  Every LDS operand of the item — the 4 / 6 / 8 B fragments of the token rows, the
+    // token's statistics, S and b' of the lane's 16 channels — is requested BEFORE the MFMA chain starts: written as a loop
+    // the compiler issues two k-steps of reads, waits for them, issues two MFMAs, and so on: a wave then spends most of the
+    // item in LDS round trips (measured with the per-phase stamps of the -DSA_STAMPS build: 5.5 thousand cycles per window in
+    // this phase at C = 120, against 1.5 thousand of matrix-pipe time)
+    auto g1_item = [&](int hf) {
       const int tok = hf * 32 + r;
+      const char* brow = xb + tok * XS + h * 16;
+      Pack16 bq[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bq[ks] = *reinterpret_cast<const Pack16*>(brow + ks * 32);
+      __builtin_amdgcn_sched_barrier(0);   // (the reads above stay above the chain)
+      if (C % 16 != 0) {   // the row's last slot ends with the next channels of the memory row: zero them
+        constexpr int c0 = C % 16 < 8 ? C % 16 : 8, c1 = C % 16 > 8 ? C % 16 - 8 : 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bq[KS - 1].w[d] = (2 * d < (h ? c1 : c0)) ? bq[KS - 1].w[d] : 0u;
+      }
       f32x16 acc;
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-      const char* brow = xb + tok * XS + h * 16;
 #pragma unroll
-      for (int ks = 0; ks < ((SA_ABL & 16) ? 0 : KS); ++ks) {
-        Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
-        if (C % 16 != 0 && ks == KS - 1) {   // the row's last slot ends with the next channels of the memory row: zero them
-          constexpr int c0 = C % 16 < 8 ? C % 16 : 8, c1 = C % 16 > 8 ? C % 16 - 8 : 0;
-#pragma unroll
-          for (int d = 0; d < 4; ++d) bq.w[d] = (2 * d < (h ? c1 : c0)) ? bq.w[d] : 0u;
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfr[ks]), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0);
-      }
+      for (int ks = 0; ks < ((SA_ABL & 16) ? 0 : KS); ++ks)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfr[ks]), __builtin_bit_cast(bf16x8_t, bq[ks]), acc, 0, 0, 0);
+      // the epilogue's operands are requested while the chain runs
       const float2 mr = *reinterpret_cast<const float2*>(st + tok * 2);
-      const float rstd = mr.y, nrm = -mr.y * mr.x;
+      float4 S4[4], B4[4];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int n0 = tq * 32 + 8 * g4 + 4 * h;
-        const float4 S4 = *reinterpret_cast<const float4*>(sbqL + n0);
-        const float4 B4 = *reinterpret_cast<const float4*>(sbqL + NTQ * 32 + n0);
-        acc[4 * g4] = fmaf(rstd, acc[4 * g4], fmaf(nrm, S4.x, B4.x));
-        acc[4 * g4 + 1] = fmaf(rstd, acc[4 * g4 + 1], fmaf(nrm, S4.y, B4.y));
-        acc[4 * g4 + 2] = fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4.z, B4.z));
-        acc[4 * g4 + 3] = fmaf(rstd, acc[4 * g4 + 3], fmaf(nrm, S4.w, B4.w));
+        S4[g4] = *reinterpret_cast<const float4*>(sbqL + n0);
+        B4[g4] = *reinterpret_cast<const float4*>(sbqL + NTQ * 32 + n0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float rstd = mr.y, nrm = -mr.y * mr.x;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        acc[4 * g4] = fmaf(rstd, acc[4 * g4], fmaf(nrm, S4[g4].x, B4[g4].x));
+        acc[4 * g4 + 1] = fmaf(rstd, acc[4 * g4 + 1], fmaf(nrm, S4[g4].y, B4[g4].y));
+        acc[4 * g4 + 2] = fmaf(rstd, acc[4 * g4 + 2], fmaf(nrm, S4[g4].z, B4[g4].z));
+        acc[4 * g4 + 3] = fmaf(rstd, acc[4 * g4 + 3], fmaf(nrm, S4[g4].w, B4[g4].w));
       }
       char* srow = smem + (secq == 0 ? CF::OFF_Q : secq == 1 ? CF::OFF_K : CF::OFF_V) + tok * (secq == 2 ? ldv : ldq);
       bf16* qrow = p.qkv + (int64_t)token(w, tok) * p.ldq + secq * C;
@@ -489,11 +516,14 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
           else if (nv > 0) store_chunk(reinterpret_cast<char*>(qrow + ch), u, 2 * nv);   // 4 (C = 90) or 8 (C = 60) bytes
         }
       }
-    }
+    };
+    for (int hf = hf0; hf < hf1; ++hf) g1_item(hf);
     // the previous window's x1 rows (written in place of its x tile, phase C) and a rows (the O tile) -> HBM
     if (have_prev && !(SA_ABL & 4)) copy_rows(smem + CF::OFF_X + (buf ^ 1) * CF::XBUFB, XS, p.x1, p.ld1, prev, lnw, 0, SA_NW);
     if (have_prev && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
+    SA_ST(2)   // 2: phase A work
     __syncthreads();   // B1: the window's q | k | v are in LDS; the other x buffer is free
+    SA_ST(3)   // 3: wait at B1
 
     // ---- B: next rows in flight, qkv rows out, attention -------------------------------------------------------------------
     if (loader && more && !(SA_ABL & 64)) issue(cur, buf ^ 1, lnw);
@@ -525,7 +555,9 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
         default: sa_head<D, 5>(c, io); break;
       }
     }
+    SA_ST(4)   // 4: phase B work
     __syncthreads();   // B2: the attention output a is in the O tile
+    SA_ST(5)   // 5: wait at B2
 
     // ---- C: a rows out, proj + shortcut (x1 in place of x); the loader waves: statistics of the next window ------------
     if (loader) {
@@ -537,25 +569,46 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       if (sw < 2 * NTS) {   // item sw = (tile j, token half)
         const int j = sw % NTS, hf = sw / NTS;
         const int tok = hf * 32 + r;
+        const char* brow = Os + tok * ldq + h * 16;
+        const char* wrow = smem + CF::OFF_WP + (j * KS * 64 + lnw) * 16;
+        char* xr = xb + tok * XS;
+        // LDS operands ahead of the chain (see phase A), in two batches of k-steps: the second batch is requested while the
+        // first half of the chain runs; the epilogue's operands while the second half runs
         f32x16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-        const char* brow = Os + tok * ldq + h * 16;
-        const char* wrow = smem + CF::OFF_WP + (j * KS * 64 + lnw) * 16;
+        constexpr int KH = (KS + 1) / 2;
 #pragma unroll
-        for (int ks = 0; ks < ((SA_ABL & 32) ? 0 : KS); ++ks) {
-          const Pack16 aw = *reinterpret_cast<const Pack16*>(wrow + ks * 1024);
-          const Pack16 bq = *reinterpret_cast<const Pack16*>(brow + ks * 32);
-          Mma<bf16>::mma(acc, aw, bq);
+        for (int bt = 0; bt < 2; ++bt) {
+          Pack16 aw[KH], bq[KH];
+#pragma unroll
+          for (int i = 0; i < KH; ++i) {
+            const int ks = bt * KH + i;
+            if (ks < KS) {
+              aw[i] = *reinterpret_cast<const Pack16*>(wrow + ks * 1024);
+              bq[i] = *reinterpret_cast<const Pack16*>(brow + ks * 32);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < KH; ++i)
+            if (bt * KH + i < ((SA_ABL & 32) ? 0 : KS)) Mma<bf16>::mma(acc, aw[i], bq[i]);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        char* xr = xb + tok * XS;
+        float4 B4[4];
+        u32x2_a4 rr[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int n0 = j * 32 + 8 * g4 + 4 * h;
-          const float4 B4 = *reinterpret_cast<const float4*>(sbpL + NTS * 32 + n0);
-          const u32x2_a4 rr = *reinterpret_cast<const u32x2_a4*>(xr + n0 * 2);
-          const float y0 = acc[4 * g4] + B4.x + bf16lo(rr.x), y1 = acc[4 * g4 + 1] + B4.y + bf16hi(rr.x);
-          const float y2 = acc[4 * g4 + 2] + B4.z + bf16lo(rr.y), y3 = acc[4 * g4 + 3] + B4.w + bf16hi(rr.y);
+          B4[g4] = *reinterpret_cast<const float4*>(sbpL + NTS * 32 + n0);
+          rr[g4] = *reinterpret_cast<const u32x2_a4*>(xr + n0 * 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int n0 = j * 32 + 8 * g4 + 4 * h;
+          const float y0 = acc[4 * g4] + B4[g4].x + bf16lo(rr[g4].x), y1 = acc[4 * g4 + 1] + B4[g4].y + bf16hi(rr[g4].x);
+          const float y2 = acc[4 * g4 + 2] + B4[g4].z + bf16lo(rr[g4].y), y3 = acc[4 * g4 + 3] + B4[g4].w + bf16hi(rr[g4].y);
           u32x2_a4 o;
           o.x = pack_bf16x2(y0, y1); o.y = pack_bf16x2(y2, y3);
           if (n0 < C) *reinterpret_cast<u32x2_a4*>(xr + n0 * 2) = o;   // x1 where x was (this item's own 4 channels of its own token)
@@ -565,8 +618,15 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     prev = w;
     have_prev = true;
     buf ^= 1;
+    SA_ST(6)   // 6: phase C work
   }
   __syncthreads();
+#ifdef SA_STAMPS
+  if (p.stamps && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.stamps[((size_t)blockIdx.x * SA_NW + wv) * 8 + k] = tacc[k];
+  }
+#endif
   if (have_prev && !(SA_ABL & 4)) {   // the last window's x1 rows
     int lnw = tid;
     asm volatile("" : "+v"(lnw));
@@ -589,6 +649,38 @@ int launch_sa(SAArgs& p, hipStream_t st) {
   int64_t G = 256;
   if (G > nwin) G = nwin;
   p.G = (int)G;
+#ifdef SA_STAMPS
+  {
+    static int left = -1;
+    if (left < 0) { const char* e = getenv("SA_STAMPS_N"); left = e ? atoi(e) : 0; }
+    if (left > 0) {
+      const size_t n = (size_t)G * SA_NW * 8;
+      (void)hipMalloc((void**)&p.stamps, n * 8);
+      (void)hipMemsetAsync(p.stamps, 0, n * 8, st);
+      hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SA_NTH), CF::SMEM, st, p);
+      (void)hipStreamSynchronize(st);
+      unsigned long long* hst = (unsigned long long*)malloc(n * 8);
+      (void)hipMemcpy(hst, p.stamps, n * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(p.stamps);
+      if (--left == 0) {
+        static const char* nm[8] = {"prologue", "wait top", "A work", "wait B1", "B work", "wait B2", "C work", "-"};
+        fprintf(stderr, "[K8 stamps D=%d grid=%d] mean cycles per workgroup over the launch, by wave:\n", D, (int)G);
+        for (int w = 0; w < SA_NW; ++w) {
+          fprintf(stderr, "  wave %2d:", w);
+          for (int k = 0; k < 7; ++k) {
+            double sum = 0;
+            for (int b = 0; b < (int)G; ++b) sum += (double)hst[((size_t)b * SA_NW + w) * 8 + k];
+            fprintf(stderr, " %s %.0f", nm[k], sum / (double)G);
+          }
+          fprintf(stderr, "\n");
+        }
+      }
+      free(hst);
+      return rdst_launch_status("swinattn_fwd");
+    }
+    p.stamps = nullptr;
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(SA_NTH), CF::SMEM, st, p);
   return rdst_launch_status("swinattn_fwd");
 }

@@ -92,21 +92,50 @@ def test_config5_train_step_all_gradients_vs_oracle_fp32(mode, layers):
 
 
 @pytest.mark.timeout(1800)
-def test_config5_label_hr_fp32_is_no_further_from_float64_than_the_fp32_oracle():
-    """The 4e-2 gate above, adjudicated: oracle(RDSTSR) -> oracle(SegUNet_F 'label-hr') evaluated in float64 is the truth; over
-    all 750 parameter gradients the HIP fp32 step must be no further from it than the fp32 oracles are (factor 2)."""
+def test_config5_label_hr_fp32_adjudicated_given_the_labels():
+    """The 4e-2 gate of the 'label-hr' case above, adjudicated against float64 (oracle(RDSTSR) -> oracle(SegUNet_F) in float64 =
+    the truth) in two steps:
+    (1) the labels.  'label-hr' takes argmax(UNet(HR)) as the Dice target; a pixel whose two largest logits are closer than the
+        fp32 noise of a 50-layer network gets a different class in different fp32 summation orders, and every flipped pixel
+        moves d(loss)/d(SR) by a whole one-hot.  The flipped pixels of the HIP fp32 pass and of the fp32 oracle against the
+        float64 labels are COUNTED: both must be a handful of the 131072, and that (not arithmetic error) is what the end-to-end
+        distances of the test above consist of — which implementation is "closer to float64" there is decided by whose tie
+        pixels happen to agree with float64's (measured, round 4: 1.97e-2 against 1.05e-2);
+    (2) the arithmetic GIVEN the labels: the same step in 'label-gt' mode (loss/seg_unet.py:117-123: identical arithmetic with
+        the labels passed in) with float64's labels handed to all three.  Over all 750 parameter gradients the HIP fp32 step must
+        be within 1.25 x of the fp32 oracle's own distance to float64."""
     from util import build_net
     cfg = O.CFG_E1
-    B, mode, layers = 2, "label-hr", []
+    B = 2
     sd = O.make_weights(cfg, 21)
-    net = build_net(cfg)
-    net.load_state_dict(sd, strict=True)
-    net.to(DEV).train()
-    sl, usd = _loss(mode, layers, "fp32")
     g = torch.Generator().manual_seed(77)
     x = torch.rand(B, 1, 64, 64, generator=g)
     tgt = torch.rand(B, 1, 256, 256, generator=g)
-    loss, _ = sl(net(x.to(DEV)), tgt.to(DEV))
+    usd = S.make_unet_weights(1, 4, 2)
+    # ---- (1) labels of the HR image: float64 oracle, fp32 oracle, HIP fp32 ----
+    lab = {}
+    for name, dt in (("f64", torch.float64), ("o32", torch.float32)):
+        uu = {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in usd.items()}
+        with torch.no_grad():
+            lab[name] = torch.argmax(S.unet_forward(tgt.to(dt), uu, "label-hr", S.BNState(uu, False)), dim=1)
+    net = build_net(cfg)
+    net.load_state_dict(sd, strict=True)
+    net.to(DEV).train()
+    sl, _ = _loss("label-hr", [], "fp32")
+    unet = sl.loss_functions["UNet-F"]
+    unet.keep_debug = True
+    sl(net(x.to(DEV)), tgt.to(DEV))[0].backward()
+    torch.cuda.synchronize()
+    lab["hip"] = unet.debug_last["hr_logits"].float().cpu().argmax(-1).reshape(lab["f64"].shape)
+    npx = lab["f64"].numel()
+    flips = {k: int((lab[k] != lab["f64"]).sum()) for k in ("o32", "hip")}
+    print(f"\nconfig 5 label-hr: HR pixels whose argmax differs from float64's: fp32 oracle {flips['o32']}, HIP fp32 {flips['hip']} of {npx}")
+    assert flips["o32"] <= 64 and flips["hip"] <= 64, flips      # a handful: ties, not a different segmentation
+    # ---- (2) the whole step GIVEN float64's labels ('label-gt' = the same arithmetic with the labels passed in) ----
+    labels = lab["f64"].unsqueeze(1)
+    net.zero_grad(set_to_none=True)
+    sg, _ = _loss("label-gt", [], "fp32")
+    loss, _ = sg(net(x.to(DEV)), tgt.to(DEV), gt_label=labels.to(DEV))
     loss.backward()
     torch.cuda.synchronize()
     params = {k: p for k, p in net.named_parameters() if p.requires_grad}
@@ -116,14 +145,14 @@ def test_config5_label_hr_fp32_is_no_further_from_float64_than_the_fp32_oracle()
                for k, v in sd.items()}
         uu = {k: (v.to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in usd.items()}
         oy = O.rdstsr_forward(x.to(dt), osd, cfg)
-        (0.1 * F.l1_loss(oy, tgt.to(dt)) + S.segunet_loss(oy, tgt.to(dt), uu, mode, layers)).backward()
+        (0.1 * F.l1_loss(oy, tgt.to(dt)) + S.segunet_loss(oy, tgt.to(dt), uu, "label-gt", [], gt_label=labels)).backward()
         ref[name] = {k: osd[k].grad.double() for k in params}
     d_hip = sum((params[k].grad.double().cpu() - ref["f64"][k]).norm().item() ** 2 for k in params) ** 0.5
     d_o32 = sum((ref["o32"][k] - ref["f64"][k]).norm().item() ** 2 for k in params) ** 0.5
     n64 = sum(ref["f64"][k].norm().item() ** 2 for k in params) ** 0.5
-    print(f"\nconfig 5 label-hr adjudicator: |hip32 - f64| = {d_hip / n64:.3e}, |oracle32 - f64| = {d_o32 / n64:.3e} (750 gradients, relative to |f64|)")
+    print(f"config 5 given the labels: |hip32 - f64| = {d_hip / n64:.3e}, |oracle32 - f64| = {d_o32 / n64:.3e} (750 gradients, relative to |f64|)")
     assert len(params) == 750
-    assert d_hip <= 2.0 * d_o32 + 1e-6 * n64, (d_hip / n64, d_o32 / n64)
+    assert d_hip <= 1.25 * d_o32 + 1e-6 * n64, (d_hip / n64, d_o32 / n64)
 
 
 @pytest.mark.parametrize("mode,layers", [("encoder-L1", [1]), ("label-hr", [])])

@@ -10,7 +10,7 @@ from util import rand
 
 lib = _lib.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-B, H, W = 32, 64, 64
+B, H, W = (int(sys.argv[2]) if len(sys.argv) > 2 else 32), 64, 64
 M = B * H * W
 for C in (60, 90, 120):
     scale = (C // 6) ** -0.5
