@@ -475,3 +475,38 @@ def test_ws16_fp32_train_step_all_gradients_vs_oracle():
     rel L2 <= 1e-4 per tensor (measured worst 3.4e-6), <= 1e-5 in total (2.5e-7), |dPSNR| < 5e-6 dB (5.1e-8; the claim is four
     decimals), loss to 1e-6."""
     _ws16_all_gradients(torch.float32, 1, 1e-4, 1e-5, 5e-6, 1e-6)
+
+
+def test_e1_fp32_bench_shape_psnr_equal_to_4_decimals():
+    """north_star's stated tolerance at THE benchmark shape: RDST-E1 x4 on 1x64x64 LR patches (B = 4 of BASELINE configs[1]'s
+    32: the oracle is a CPU pass), parity mode (fp32 activations, exact-fp32 matrix-core kernels), forward + L1 + backward
+    against the oracle: |dPSNR| < 5e-5 dB (PSNR equal to >= 4 decimal places, metrics/sr_metrics.py:8-9, border 4 as
+    trans_sr_tester.py:155 passes it), loss to 1e-6, every one of the 750 gradients to 1e-3 relative."""
+    from util import build_net
+    cfg = O.CFG_E1
+    B = 4
+    sd = O.make_weights(cfg, 11)
+    net = build_net(cfg)
+    net.load_state_dict(sd, strict=True)
+    net.to(DEV).train()
+    g = torch.Generator().manual_seed(4321)
+    x = torch.rand(B, 1, 64, 64, generator=g)
+    tgt = torch.rand(B, 1, 256, 256, generator=g)
+    y = net(x.to(DEV))
+    loss = F.l1_loss(y, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    params = dict(net.named_parameters())
+    osd = {k: (v.clone().requires_grad_(True) if (k in params and params[k].requires_grad) else v) for k, v in sd.items()}
+    oy = O.rdstsr_forward(x, osd, cfg)
+    oloss = F.l1_loss(oy, tgt)
+    oloss.backward()
+    yc = y.detach().float().cpu()
+    p_hip, p_ref = O.psnr(tgt, yc, 4), O.psnr(tgt, oy.detach(), 4)
+    worst = max(((p.grad.cpu() - osd[k].grad).norm().item() / max(osd[k].grad.norm().item(), 1e-12), k)
+                for k, p in params.items() if p.requires_grad)
+    print(f"\nE1 fp32 B={B} 64x64: PSNR {p_hip:.6f} vs {p_ref:.6f} dB (|d| {abs(p_hip - p_ref):.2e})  out max|d| "
+          f"{(yc - oy.detach()).abs().max().item():.2e}  loss {loss.item():.7f} vs {oloss.item():.7f}  worst gradient {worst[0]:.2e} ({worst[1]})")
+    assert abs(p_hip - p_ref) < 5e-5
+    assert abs(loss.item() - oloss.item()) <= 1e-6
+    assert worst[0] <= 1e-3, worst

@@ -201,3 +201,65 @@ def test_wattn16_fp32_is_bit_deterministic():
         res.append((o.detach().clone(), q.grad.clone(), t.grad.clone()))
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# K2, the (window, 6 heads) kernel with the LDS-DMA ring (csrc/wattn_bwd_pair.hip, default for C = 90 / 120): the cases the
+# ring's prefetch guards and the loader / storer split are written for
+# ------------------------------------------------------------------------------------------------------------------
+def _k2_case(B, H, W, C, shift, seed):
+    heads, ws = 6, 8
+    scale = (C // heads) ** -0.5
+    qkv = _rand((B, H, W, 3 * C), seed).bfloat16()
+    table = _rand(((2 * ws - 1) ** 2, heads), seed + 1, 0.5)
+    gout = _rand((B, H, W, C), seed + 2).bfloat16()
+    return heads, ws, scale, qkv, table, gout
+
+
+@pytest.mark.parametrize("C", [90, 120])
+@pytest.mark.parametrize("B,H,W,shift", [(257, 8, 8, 0), (3, 80, 80, 1), (1, 136, 24, 3), (7, 64, 72, 7), (2, 8, 16, 5)])
+def test_k2_pair_ragged_groups_and_shifts_vs_oracle(C, B, H, W, shift):
+    """Window counts that are not multiples of the 256 workgroups (257: one group with 2 items, 255 with 1; 300; 51; 504;
+    4: fewer windows than ring slots), so the NBUF - 1 items a group keeps in flight run past its last window, and shifts
+    other than 0 / 4 (every split of the wrapped window rows)."""
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    heads, ws, scale, qkv, table, gout = _k2_case(B, H, W, C, shift, 31 + C + shift)
+    q_ref = qkv.float().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale).backward(gout.float())
+    q = qkv.to(dev).requires_grad_(True)
+    t = table.to(dev).requires_grad_(True)
+    ops.window_attention(q, t, H, W, heads, ws, shift, scale).backward(gout.to(dev))
+    torch.cuda.synchronize()
+    assert torch.isfinite(q.grad.float()).all()
+    assert (q.grad.float().cpu() - q_ref.grad).abs().max().item() <= 6e-2
+    rel_q = (q.grad.float().cpu() - q_ref.grad).norm().item() / q_ref.grad.norm().item()
+    rel_t = (t.grad.cpu() - t_ref.grad).norm().item() / t_ref.grad.norm().item()
+    assert rel_q <= 1e-2 and rel_t <= 2e-2, (rel_q, rel_t)
+
+
+@pytest.mark.parametrize("C", [90, 120])
+def test_k2_pair_equals_the_strided_row_fallback(C):
+    """Rows that are not dense (qkv inside a wider buffer) make the pair kernel refuse (RDST_ENOTSUP) and the (window, 12 wave)
+    kernel of rounds 1-3 run: same function, two kernels — dqkv within bf16 rounding of each other (both round each gradient
+    once), d(table) to 2e-3 (both sum fp32 partials in a fixed order, in different orders), and each bit-deterministic."""
+    from rdst_amd import ops
+    dev = torch.device("cuda:0")
+    B, H, W, shift = 5, 64, 72, 4
+    heads, ws, scale, qkv, table, gout = _k2_case(B, H, W, C, shift, 77 + C)
+    big = torch.zeros(B, H, W, 3 * C + 8, dtype=torch.bfloat16)
+    big[..., :3 * C] = qkv
+    res = []
+    for src in (qkv.to(dev), big.to(dev)[..., :3 * C]):
+        for _ in range(2):
+            q = src.detach().requires_grad_(True)
+            t = table.to(dev).requires_grad_(True)
+            ops.window_attention(q, t, H, W, heads, ws, shift, scale).backward(gout.to(dev))
+            torch.cuda.synchronize()
+            res.append((q.grad.float().cpu()[..., :3 * C].clone(), t.grad.cpu().clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])       # dense rows (pair kernel): run to run
+    assert torch.equal(res[2][0], res[3][0]) and torch.equal(res[2][1], res[3][1])       # strided rows (fallback): run to run
+    dq = (res[0][0] - res[2][0]).abs().max().item()
+    assert dq <= 2 ** -7 * max(1.0, res[0][0].abs().max().item()), dq                       # one bf16 ulp of the largest gradient
+    assert (res[0][1] - res[2][1]).norm().item() <= 2e-3 * res[0][1].norm().item()

@@ -14,7 +14,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for row in csv.DictReader(open(f)):
     k = row["Kernel_Name"]
     if sub in k:
-        acc[k.split("(")[0][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        kk = k.replace("(anonymous namespace)::", "").replace("void ", "")
+        acc[kk.split("(")[0][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
     print(k)
     for c, v in d.items():
