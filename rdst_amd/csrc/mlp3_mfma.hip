@@ -38,7 +38,12 @@ struct M3Args {
   unsigned long long* stamps;   // debug build: [grid][8] cycle counters (RDST_M3_STAMPS), else null
 };
 
-constexpr int m3_nw(int C) { return ((2 * C + 31) / 32) % 3 == 0 ? 6 : 8; }   // hidden tiles 4 / 6 / 8 -> 8 / 6 / 8 waves
+#ifndef M3_NW90
+#define M3_NW90 12
+#endif
+// hidden tiles 4 / 6 / 8 -> 8 / 12 / 8 waves.  C = 90 (6 hidden tiles, 105 KB of LDS: one workgroup per CU) ran 6 waves per CU until
+// round 5 and took as long as C = 120 (35.9 against 38.6 us in the step); 12 waves = two per hidden tile, one output item each
+constexpr int m3_nw(int C) { return ((2 * C + 31) / 32) % 3 == 0 ? M3_NW90 : 8; }
 
 template <int C>
 struct M3Cfg {
