@@ -36,6 +36,12 @@ using namespace wahd;
 #ifndef SA_ABL
 #define SA_ABL 0   // compile-time ablation switches (tools/abl_build.sh): 1 no qkv stores, 2 no a stores, 4 no x1 stores, 8 no attention,
 #endif             // 16 no G1 arithmetic, 32 no proj arithmetic, 64 no row fetch after the first window
+#ifndef SA_PRIO
+#define SA_PRIO 0         // 1: s_setprio by dispatch age (waves 4-7: 1, waves 8-11: 2): the youngest wave of a SIMD is the slowest in every phase
+#endif
+#ifndef SA_ACOPY_C
+#define SA_ACOPY_C 1      // 1: the a rows leave in phase C on the loader waves (which only have the statistics to do there); 0: in the
+#endif                    // next window's phase A on all waves, beside the x1 rows
 #ifndef SA_QKV_DIRECT
 #define SA_QKV_DIRECT 1   // 1: the qkv tiles go to HBM straight from the accumulators (16 bytes of a token per lane); 0: as whole-row
 #endif                    // copies out of the sections during the attention phase.  Measured equal within 2 us at every width
@@ -427,6 +433,10 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     }
   };
 
+  if (SA_PRIO) {
+    if (wv >= 8) __builtin_amdgcn_s_setprio(2);
+    else if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+  }
   int buf = 0;
   bool have_prev = false;
   WinPos prev = cur;
@@ -520,7 +530,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     for (int hf = hf0; hf < hf1; ++hf) g1_item(hf);
     // the previous window's x1 rows (written in place of its x tile, phase C) and a rows (the O tile) -> HBM
     if (have_prev && !(SA_ABL & 4)) copy_rows(smem + CF::OFF_X + (buf ^ 1) * CF::XBUFB, XS, p.x1, p.ld1, prev, lnw, 0, SA_NW);
-    if (have_prev && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
+    if (!SA_ACOPY_C && have_prev && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
     SA_ST(2)   // 2: phase A work
     __syncthreads();   // B1: the window's q | k | v are in LDS; the other x buffer is free
     SA_ST(3)   // 3: wait at B1
@@ -564,6 +574,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       // the next window's rows of this wave have landed (issued an attention phase ago)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (more) row_stats(cur, buf ^ 1, lnw);
+      if (SA_ACOPY_C && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, w, lnw, 0, SA_NLW);
     } else {
       const int sw = wv - SA_NLW;   // 0 .. 7
       if (sw < 2 * NTS) {   // item sw = (tile j, token half)
@@ -632,7 +643,7 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     asm volatile("" : "+v"(lnw));
     lnw &= 63;
     copy_rows(smem + CF::OFF_X + (buf ^ 1) * CF::XBUFB, XS, p.x1, p.ld1, prev, lnw, 0, SA_NW);
-    if (!(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
+    if (!SA_ACOPY_C && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, prev, lnw, 0, SA_NW);
   }
 }
 
