@@ -36,12 +36,10 @@ using namespace wahd;
 #ifndef SA_ABL
 #define SA_ABL 0   // compile-time ablation switches (tools/abl_build.sh): 1 no qkv stores, 2 no a stores, 4 no x1 stores, 8 no attention,
 #endif             // 16 no G1 arithmetic, 32 no proj arithmetic, 64 no row fetch after the first window
-#ifndef SA_PRIO
-#define SA_PRIO 0         // 1: s_setprio by dispatch age (waves 4-7: 1, waves 8-11: 2): the youngest wave of a SIMD is the slowest in every phase
-#endif
 #ifndef SA_ACOPY_C
-#define SA_ACOPY_C 1      // 1: the a rows leave in phase C on the loader waves (which only have the statistics to do there); 0: in the
-#endif                    // next window's phase A on all waves, beside the x1 rows
+#define SA_ACOPY_C 0      // 1: the a rows leave in phase C on the loader waves (which only have the statistics to do there); 0: in the
+#endif                    // next window's phase A on all waves, beside the x1 rows.  Measured equal (+-0.7 us); s_setprio by dispatch
+                          // age (the youngest wave of a SIMD is the slowest in every phase) was measured too: +2 .. 3 us
 #ifndef SA_QKV_DIRECT
 #define SA_QKV_DIRECT 1   // 1: the qkv tiles go to HBM straight from the accumulators (16 bytes of a token per lane); 0: as whole-row
 #endif                    // copies out of the sections during the attention phase.  Measured equal within 2 us at every width
@@ -433,10 +431,6 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     }
   };
 
-  if (SA_PRIO) {
-    if (wv >= 8) __builtin_amdgcn_s_setprio(2);
-    else if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-  }
   int buf = 0;
   bool have_prev = false;
   WinPos prev = cur;
