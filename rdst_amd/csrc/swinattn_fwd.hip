@@ -43,7 +43,12 @@ using namespace wahd;
 #ifndef SA_QKV_DIRECT
 #define SA_QKV_DIRECT 1   // 1: the qkv tiles go to HBM straight from the accumulators (16 bytes of a token per lane); 0: as whole-row
 #endif                    // copies out of the sections during the attention phase.  Measured equal within 2 us at every width
-constexpr int SA_NW = 12, SA_NTH = 64 * SA_NW, SA_NLW = 4;   // waves, threads, loader waves (0 .. 3)
+constexpr int SA_NLW = 4;   // loader waves (0 .. 3)
+#ifndef SA_NW10
+#define SA_NW10 12  // waves per workgroup at C = 60: 12 = one workgroup per CU as at C = 90 / 120; 6 = TWO workgroups per CU (79 KB of LDS each),
+#endif              // each wave two GEMM items and both query halves of its head — measured: 52 us against 40 (two half-size workgroups
+                    // double every wave's dependent chain and pay two prologues; their phases do not interleave usefully)
+constexpr int sa_nw(int D) { return D == 10 ? SA_NW10 : 12; }
 
 struct SAArgs {
   const bf16* X; int64_t ldx; uint32_t x_bytes;
@@ -206,9 +211,11 @@ __device__ __forceinline__ void sa_head(const SaCtx& c, IO io) {
 }
 
 template <int D>
-__global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p) {
+__global__ void __launch_bounds__(64 * sa_nw(D), 3) swinattn_fwd_kernel(const SAArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CF = SA<D>;
+  constexpr int SA_NW = sa_nw(D), SA_NTH = 64 * SA_NW;
+  static_assert(SA_NW == 12 || (SA_NW == 6 && D == 10), "wave roles");
   constexpr int C = CF::C, KS = CF::KS, NTS = CF::NTS, NTQ = CF::NTQ, XS = CF::XS, ldq = CF::LDQ, ldv = CF::LDV;
   const WinGeom g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -245,7 +252,10 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
   //   D = 15: 9 tiles: waves 0-5 a tile with both halves, waves 6-11 tiles 6-8 with one half each
   int tq, hf0, hf1;
   if constexpr (D == 20) { tq = wv; hf0 = 0; hf1 = 2; }
-  else if constexpr (D == 10) { tq = wv % 6; hf0 = wv / 6; hf1 = hf0 + 1; }
+  else if constexpr (D == 10) {
+    if constexpr (SA_NW == 6) { tq = wv; hf0 = 0; hf1 = 2; }
+    else { tq = wv % 6; hf0 = wv / 6; hf1 = hf0 + 1; }
+  }
   else {
     if (wv < 6) { tq = wv; hf0 = 0; hf1 = 2; }
     else { tq = 6 + (wv - 6) % 3; hf0 = (wv - 6) / 3; hf1 = hf0 + 1; }
@@ -367,24 +377,27 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       }
     }
   }
-  // attention role: wave = (head hd, query half qt)
-  const int qt = wv & 1, hd = wv >> 1;
-  const int yi = qt * 4 + (r >> 3), xi = r & 7;
+  // attention role: wave = (head hd, query half qt); with 6 waves a wave takes both query halves of its head, one after the other
+  const int hd = SA_NW == 6 ? wv : wv >> 1;
+  const int xi = r & 7;
   const int thr = g.ws - g.shift;
   SaCtx c;
   c.h = h;
-  c.Qp = (lds_cp)(Qs + (qt * 32 + r) * ldq + h * 16);
   c.Kp = (lds_cp)(Ks + r * ldq + h * 16);
   {
     const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     c.Vp = (lds_cp)(Vs + (4 * h + q) * ldv + (16 * (gq & 1) + 4 * pp) * 2);
   }
-  c.Op = (lds_cp)(Os + (qt * 32 + r) * ldq);
-  {
+  auto set_qt = [&](int qt) {   // the lane's query row: positions of its Q row, its O row and its bias-table row
+    const int yi = qt * 4 + (r >> 3);
+    c.Qp = (lds_cp)(Qs + (qt * 32 + r) * ldq + h * 16);
+    c.Op = (lds_cp)(Os + (qt * 32 + r) * ldq);
     const int u0 = 4 * h - xi + 7;
     const float* tb = (u0 & 1) ? tabL + CF::TABB + yi * TSX + (u0 - 1) : tabL + yi * TSX + u0;
     c.tb = (const LDS_AS f32x2*)tb;
-  }
+    return yi;
+  };
+  int yi = set_qt(SA_NW == 6 ? 0 : (wv & 1));
   const uint32_t cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
   c.scale2 = p.scale * LOG2E;
 
@@ -537,26 +550,29 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
     {
       const bool mrow = g.shift > 0 && w.wr == g.nWh - 1, mcol = g.shift > 0 && w.wc == g.nWw - 1;
       c.masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
+      auto onehot = [&](int reg, uint32_t v, Pack16& q) {
+        q.w[0] = h ? 0u : ((reg == 0 ? v : 0u) | (reg == 1 ? v << 16 : 0u));
+        q.w[1] = h ? 0u : ((reg == 2 ? v : 0u) | (reg == 3 ? v << 16 : 0u));
+        q.w[2] = 0u;
+        q.w[3] = 0u;
+      };
+      const int rx = (mcol && xi >= thr) ? 1 : 0;
       if (c.masked) {
-        auto onehot = [&](int reg, uint32_t v, Pack16& q) {
-          q.w[0] = h ? 0u : ((reg == 0 ? v : 0u) | (reg == 1 ? v << 16 : 0u));
-          q.w[1] = h ? 0u : ((reg == 2 ? v : 0u) | (reg == 3 ? v << 16 : 0u));
-          q.w[2] = 0u;
-          q.w[3] = 0u;
-        };
-        const int rx = (mcol && xi >= thr) ? 1 : 0;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) onehot(2 * ((mrow && kt * 4 + (r >> 3) >= thr) ? 1 : 0) + rx, 0x3f80u, c.mK[kt]);
-        onehot(2 * ((mrow && yi >= thr) ? 1 : 0) + rx, cbits, c.mQ);
       }
-      if (!(SA_ABL & 8))
-      switch (hd) {
-        case 0: sa_head<D, 0>(c, io); break;
-        case 1: sa_head<D, 1>(c, io); break;
-        case 2: sa_head<D, 2>(c, io); break;
-        case 3: sa_head<D, 3>(c, io); break;
-        case 4: sa_head<D, 4>(c, io); break;
-        default: sa_head<D, 5>(c, io); break;
+      for (int pass = 0; pass < (SA_NW == 6 ? 2 : 1); ++pass) {
+        if (SA_NW == 6) yi = set_qt(pass);
+        if (c.masked) onehot(2 * ((mrow && yi >= thr) ? 1 : 0) + rx, cbits, c.mQ);
+        if (!(SA_ABL & 8))
+        switch (hd) {
+          case 0: sa_head<D, 0>(c, io); break;
+          case 1: sa_head<D, 1>(c, io); break;
+          case 2: sa_head<D, 2>(c, io); break;
+          case 3: sa_head<D, 3>(c, io); break;
+          case 4: sa_head<D, 4>(c, io); break;
+          default: sa_head<D, 5>(c, io); break;
+        }
       }
     }
     SA_ST(4)   // 4: phase B work
@@ -569,9 +585,12 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (more) row_stats(cur, buf ^ 1, lnw);
       if (SA_ACOPY_C && !(SA_ABL & 2)) copy_rows(Os, ldq, p.a, p.lda, w, lnw, 0, SA_NLW);
-    } else {
-      const int sw = wv - SA_NLW;   // 0 .. 7
-      if (sw < 2 * NTS) {   // item sw = (tile j, token half)
+    }
+    {
+      // the proj items go to the last waves of the workgroup (12 waves: 4 .. 11, none of them a loader; 6 waves: 2 .. 5)
+      constexpr int P0 = SA_NW == 12 ? SA_NLW : SA_NW - 2 * NTS;
+      const int sw = wv - P0;
+      if (sw >= 0 && sw < 2 * NTS) {   // item sw = (tile j, token half)
         const int j = sw % NTS, hf = sw / NTS;
         const int tok = hf * 32 + r;
         const char* brow = Os + tok * ldq + h * 16;
@@ -644,6 +663,9 @@ __global__ void __launch_bounds__(SA_NTH, 3) swinattn_fwd_kernel(const SAArgs p)
 template <int D>
 int launch_sa(SAArgs& p, hipStream_t st) {
   using CF = SA<D>;
+  constexpr int SA_NW = sa_nw(D), SA_NTH = 64 * SA_NW;
+  constexpr int WGCU = SA_NW == 6 ? 2 : 1;   // workgroups per CU
+  static_assert(WGCU * CF::SMEM <= 160 * 1024, "LDS per CU");
   auto kern = swinattn_fwd_kernel<D>;
   static bool attr = false;
   if (!attr) {
@@ -651,7 +673,7 @@ int launch_sa(SAArgs& p, hipStream_t st) {
     attr = true;
   }
   const int64_t nwin = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
-  int64_t G = 256;
+  int64_t G = 256 * WGCU;
   if (G > nwin) G = nwin;
   p.G = (int)G;
 #ifdef SA_STAMPS
