@@ -15,7 +15,7 @@ python3 -m pytest tests/test_fullsize_gpu.py tests/test_segunet_gpu.py tests/tes
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-line > $O/bench_traced.json 2> $O/trace.err
 cd $R
 f=$(find $O/trace -name '*kernel_trace.csv' | head -1)
-python3 tools/cold_from_trace.py $f wattn_fwd_hd_kernel > $O/k1_cold_vs_step.txt
+python3 tools/cold_from_trace.py $f swinattn_fwd_kernel > $O/k8_cold_vs_step.txt
 python3 tools/cold_from_trace.py $f wattn_bwd_hd_kernel > $O/k2_cold_vs_step.txt
 python3 tools/cold_from_trace.py $f wattn_bwd_pair_kernel >> $O/k2_cold_vs_step.txt
 rm -rf $O/trace
