@@ -1,12 +1,13 @@
-// rdst_pack_batch: the bf16 fragment images of MANY layers' weights in a handful of launches (16 layers each) instead
+// rdst_pack_batch: the bf16 fragment images of MANY layers' weights in a handful of launches (48 layers each) instead
 // of one ~5 us pack kernel in front of every forward op (120 Linear + 11 conv ops in an RDST-E1 step).  The host side
 // (rdst_amd/ops.py: PackPlan) runs it once at the start of a network forward and hands every op its slice of the arena
 // with workspace_bytes = RDST_PREPACKED.
 #include "pack.h"
 
 namespace {
-constexpr int PB_MAX = 16;
+constexpr int PB_MAX = 48;   // jobs per launch (the table travels by value in the kernel arguments: 48 x 64 + 200 bytes < 4 KB)
 struct PackBatch { rdst_pack_job j[PB_MAX]; int first[PB_MAX + 1]; int n; };
+static_assert(sizeof(PackBatch) <= 4000, "kernel arguments");
 
 __global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch bt) {
   int k = 0;
