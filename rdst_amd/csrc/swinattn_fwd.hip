@@ -11,20 +11,21 @@
 //   A     qkv = LN(x) Wqkv^T: 6 / 9 / 12 output tiles (q | k | v, each section padded to whole 32-channel tiles of its own:
 //         pack.h lin3sec_pack_block) x 2 token halves.  A wave keeps the fragments of ONE tile in registers for the whole
 //         kernel (16 / 24 / 32 registers), B operands are ds_read_b128 of the raw token rows, LayerNorm enters in the epilogue
-//         (lin3_mfma.hip); the tile goes to the Q / K / V section in LDS (16-byte stores of 8 channels of a token).
-//         Beside it (the matrix pipe hides it): the PREVIOUS window's x1 rows leave for HBM (see C)
-//   B1    waves 0-3 put the next window's rows in flight by LDS-DMA (each its own 16 rows); waves 4-11 copy the window's qkv
-//         rows out of the sections, whole rows, a 16-byte chunk per lane; then attention: wave = (head, query half), one of the
-//         12.  K1's data flow (wattn_mfma_hd.hip: S^T = K Q^T with the bias / scale as initial accumulator, the shift mask as
-//         one more k-step, in-register softmax, O^T = V^T P^T) for ONE head per wave; O goes to its own tile
-//   B2    waves 4-11: a (the O tile) -> HBM by row copies; proj + bias + x, with the residual read from the x tile in LDS and
-//         x1 written back IN PLACE (its row copy to HBM rides on the next window's phase A); the proj fragments (8 / 18 /
-//         32 KB) live in LDS.  waves 0-3: wait for the next window's rows and compute their LayerNorm statistics (4 lanes per
+//         (lin3_mfma.hip); the tile goes to the Q / K / V section in LDS (16-byte stores of 8 channels of a token) and, from
+//         the same registers, to the qkv rows in HBM (SA_QKV_DIRECT).  Beside it: the PREVIOUS window's x1 and a rows leave
+//         for HBM as whole-row copies (see C)
+//   B1    waves 0-3 put the next window's rows in flight by LDS-DMA (each its own 16 rows); attention: wave = (head, query
+//         half), one of the 12.  K1's data flow (wattn_mfma_hd.hip: S^T = K Q^T with the bias / scale as initial accumulator,
+//         the shift mask as one more k-step, in-register softmax, O^T = V^T P^T) for ONE head per wave; O goes to its own tile
+//   B2    waves 4-11: proj + bias + x, with the residual read from the x tile in LDS and x1 written back IN PLACE (its row
+//         copy to HBM rides on the next window's phase A, like a's out of the O tile); the proj fragments (8 / 18 / 32 KB)
+//         live in LDS.  waves 0-3: wait for the next window's rows and compute their LayerNorm statistics (4 lanes per
 //         token, two passes: lin3's): neither the row fetch nor the statistics are ever on the critical path.
-// Every output row leaves through LDS as whole-row copies (consecutive lanes = consecutive 16-byte chunks of a row): the
-// first cut stored qkv and x1 straight from the accumulators, 16 bytes per lane into 32 different rows per instruction, and
-// spent 22 of its 61 us (C = 120) issuing those stores.  No vector register ever holds an input row; the only global loads
-// of the steady state are the LDS-DMA pieces.
+// No vector register ever holds an input row; the only global loads of the steady state are the LDS-DMA pieces.
+// What bounds it: the NUMBER of vector instructions (480 per wave and window on the mean, 4.4
+// SIMD cycles each) issued by three waves per SIMD that reach the same dependency at the same time — not bytes (0.33-0.41
+// of 8 TB/s), not the matrix pipe (16 % busy).  Seven variants of the store / copy / prefetch structure were measured on one
+// box each (tools/sa_ab.sh); the switches below keep the ones that are still a compile-time choice.
 #include "wattn_hd.h"
 #include "pack.h"
 #include "linear.h"
