@@ -76,6 +76,12 @@ def _alg(name, a, elt):
         B, H, W, C = a[18:22]
         M, N = B * H * W, a[23] * a[23]
         return M * (6 * C * elt + 8), 2 * M * C * 3 * C + 4 * M * N * C + 2 * M * C * C
+    if name == "rdst_wattn_fwd_lse":    # window 16 with the row statistics kept: + 4 bytes per (token, head)
+        B, H, W, C = a[6:10]
+        return B * H * W * (4 * C * elt + 4 * a[10]), 4 * B * H * W * a[11] * a[11] * C
+    if name == "rdst_wattn_bwd_lse":    # reads qkv (3C) + dout (C) + the forward's output (C) + statistics, writes dqkv (3C)
+        B, H, W, C = a[13:17]
+        return B * H * W * (8 * C * elt + 4 * a[17]), 10 * B * H * W * a[18] * a[18] * C
     if name == "rdst_wattn_bwd":        # read qkv (3C) + dout (C), write dqkv (3C)
         B, H, W, C = a[12:16]
         return B * H * W * 7 * C * elt, 10 * B * H * W * a[17] * a[17] * C
@@ -108,7 +114,7 @@ def _alg(name, a, elt):
 class Recorder:
     """Wraps the C-ABI entry points of the loaded library: records (name, args) of every call and can leave the calls of
     one entry point out (`skip`), which is how an op's time INSIDE the step is measured (step with - step without)."""
-    OPS = ("rdst_swin_attn_fwd", "rdst_wattn_fwd", "rdst_wattn_bwd", "rdst_ln_linear_fwd", "rdst_ln_linear_bwd", "rdst_ln_linear_bwd2", "rdst_mlp_fwd",
+    OPS = ("rdst_swin_attn_fwd", "rdst_wattn_fwd", "rdst_wattn_bwd", "rdst_wattn_fwd_lse", "rdst_wattn_bwd_lse", "rdst_ln_linear_fwd", "rdst_ln_linear_bwd", "rdst_ln_linear_bwd2", "rdst_mlp_fwd",
            "rdst_mlp_bwd", "rdst_conv_fwd", "rdst_conv_bwd", "rdst_nchw_to_rows", "rdst_rows_to_nchw")
     STREAM_ARG = {"rdst_ln_linear_bwd2": 24}   # position of the stream argument where it is not the last one
 
@@ -122,7 +128,7 @@ class Recorder:
 
             def wrap(*a, _n=n, _f=f):
                 self.calls.append((_n, a))
-                return 0 if _n == self.skip else _f(*a)
+                return 0 if _op_key(_n) == self.skip else _f(*a)
             setattr(self.lib, n, wrap)
         return self
 
@@ -577,7 +583,7 @@ def extra_config(name, device, lib, e1_ms, steps=5):
         line["data"] = "synthetic (seg-UNet: seeded random init, the reference's loss/unet_oasis.pt is not in the repository)"
     if name == "ws16" and ok and rec.calls:
         for key, op in (("roofline", "rdst_wattn_fwd"), ("roofline_bwd", "rdst_wattn_bwd")):
-            calls = [(n, a) for n, a in rec.calls if n == op]
+            calls = [(n, a) for n, a in rec.calls if _op_key(n) == op]
             ms = _replay_calls(lib, calls, 2)
             nbytes = sum(_alg(n, a, 2)[0] for n, a in calls) / len(calls)
             ach = nbytes / (ms * 1e-3) / 1e9
@@ -647,7 +653,15 @@ def fp32_line(device, x, tgt, B, lib):
 
 
 def _op_key(n):
-    return "rdst_ln_linear_bwd" if n == "rdst_ln_linear_bwd2" else n   # one op, two entry points (with / without a second addend)
+    # one op, two entry points: the Linear backward with / without a second addend; window attention with / without the
+    # forward's row statistics kept for the backward (window 16)
+    return {"rdst_ln_linear_bwd2": "rdst_ln_linear_bwd", "rdst_wattn_fwd_lse": "rdst_wattn_fwd",
+            "rdst_wattn_bwd_lse": "rdst_wattn_bwd"}.get(n, n)
+
+
+def _attn_c(n, a):
+    """The channel count C among the positional arguments of a window-attention entry point."""
+    return a[{"rdst_swin_attn_fwd": 21, "rdst_wattn_fwd": 10, "rdst_wattn_fwd_lse": 9, "rdst_wattn_bwd": 15, "rdst_wattn_bwd_lse": 16}[n]]
 
 
 def _op_table(lib, recorded, elt, reps, mfma_peak):
@@ -687,8 +701,8 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
     k1_ms = next(r["avg_us"] for r in table if r["op"] == fa) * 1e-3
     k1_bytes = sum(_alg(n, a, elt)[0] for n, a in k1) / len(k1)
     per_c = {}
-    for C in sorted({a[ci] for _, a in k1}):
-        sub = [(n, a) for n, a in k1 if a[ci] == C]
+    for C in sorted({_attn_c(n, a) for n, a in k1}):
+        sub = [(n, a) for n, a in k1 if _attn_c(n, a) == C]
         ms = _replay_calls(lib, sub, reps)
         bts = _alg(sub[0][0], sub[0][1], elt)[0]
         per_c[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
@@ -714,7 +728,9 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         print(f"bench.py: in-step K1 timing unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     if ws16:
         traffic, tsrc = _pmc_traffic("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
-        t2, t2src = _pmc_traffic("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
+        t2, t2src = _pmc_traffic("wattn16_bwd3_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])   # (round 5: the 16-wave kernel)
+        if t2 is None:
+            t2, t2src = _pmc_traffic("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
         kname, bound_note = "rdst_wattn_fwd (K1, window 16: wattn16_fwd_kernel)", "vector ALU (256 x 256 x 6 exponentials per window); priced against HBM as north_star asks"
     else:
         if fused:
@@ -725,7 +741,7 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         # wattn_bwd_pair_kernel; the per-launch traffic of the family is the launch-weighted mean of the two collections
         ta, tasrc = _pmc_traffic("wattn_bwd_hd_kernel", ["wattn_bwd_mfma_hd.hip", "wattn_hd.h"])
         tb, tbsrc = _pmc_traffic("wattn_bwd_pair_kernel", ["wattn_bwd_pair.hip", "wattn_hd.h"])
-        n60 = sum(1 for _, a in groups["rdst_wattn_bwd"] if a[15] == 60)
+        n60 = sum(1 for n, a in groups["rdst_wattn_bwd"] if _attn_c(n, a) == 60)
         nall = len(groups["rdst_wattn_bwd"])
         if ta is not None and tb is not None and nall:
             t2 = int((n60 * ta + (nall - n60) * tb) / nall)
@@ -753,8 +769,8 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
     k2r = next(r for r in table if r["op"] == "rdst_wattn_bwd")
     k2 = groups["rdst_wattn_bwd"]
     per_c2 = {}
-    for C in sorted({a[15] for _, a in k2}):
-        sub = [(n, a) for n, a in k2 if a[15] == C]
+    for C in sorted({_attn_c(n, a) for n, a in k2}):
+        sub = [(n, a) for n, a in k2 if _attn_c(n, a) == C]
         ms = _replay_calls(lib, sub, reps)
         bts = _alg(sub[0][0], sub[0][1], elt)[0]
         per_c2[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}

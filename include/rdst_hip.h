@@ -201,6 +201,22 @@ int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const float* Wc, cons
                   float* dbias, void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout,
                   int ksize, float out_scale, int shuffle_r, int dtype, void* stream);
 
+/* ---- K1 / K2 with the forward's row statistics kept (window 16, bf16; round 5) --------------------------------------
+ * rdst_wattn_fwd_lse = rdst_wattn_fwd (no explicit mask) that also writes nlse (B*H*W, heads) fp32:
+ *   nlse[i][h] = -(scale log2(e) max_j S'_ij + log2 sum_j 2^(scale log2(e) (S'_ij - max))),  S' = q.k + bias / scale (+ mask),
+ * i.e. 2^(scale log2(e) S'_ij + nlse[i][h]) is the attention weight of (i, j).  rdst_wattn_bwd_lse = rdst_wattn_bwd given
+ * those statistics and the forward's output `out` (M, C): delta_i = sum_c dout_ic out_ic replaces the row reduction
+ * sum_j P_ij dP_ij, so the first pass of the window-16 backward streams its key tiles (5.5 instead of 8.5 vector
+ * instructions per logit, half the matrix instructions).  Same gradients within the bf16 rounding of `out`.
+ * Covered: bf16, ws = 16, heads = 6, C/heads in {10, 15, 20}; everything else returns RDST_ENOTSUP (use the plain entry
+ * points).  workspace as for rdst_wattn_bwd. */
+int rdst_wattn_fwd_lse(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out, float* nlse,
+                       int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype, void* stream);
+int rdst_wattn_bwd_lse(const void* qkv, int64_t ld_qkv, const float* table, const void* dout, int64_t ld_dout,
+                       const void* out, int64_t ld_out, const float* nlse, void* dqkv, int64_t ld_dqkv, float* dtable,
+                       void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift,
+                       float scale, int dtype, void* stream);
+
 /* ---- K8: the attention half of a Swin block in ONE launch ------------------------------------------------------
  *   x1 = X + proj(WindowAttention(qkv(LayerNorm(X))))     networks/swin_transformer_sr.py:240-271 with :110-141 inside
  * i.e. rdst_ln_linear_fwd (norm1 + qkv) -> rdst_wattn_fwd -> rdst_ln_linear_fwd (proj + shortcut) without the two round

@@ -37,6 +37,8 @@ SIGNATURES = {
     "rdst_mlp_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_mlp_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p, _z, _l, _i, _i, _i,
                           _p]),
+    "rdst_wattn_fwd_lse": (_i, [_p, _l, _p, _p, _l, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rdst_wattn_bwd_lse": (_i, [_p, _l, _p, _p, _l, _p, _l, _p, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rdst_swin_attn_fwd_supported": (_i, [_i, _i, _i, _i]),
     "rdst_swin_attn_fwd_workspace": (_z, [_i]),
     "rdst_swin_attn_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i,
@@ -79,7 +81,7 @@ SIGNATURES = {
     "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
-ABI_VERSION = 9             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
+ABI_VERSION = 10             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 

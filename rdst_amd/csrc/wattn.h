@@ -73,10 +73,13 @@ int wattn_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, i
 int wattn_fwd_mfma_hd(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
                       float scale, hipStream_t st);
 // 16x16 windows, bf16, 6 heads of dim 10/15/20 (wattn16_mfma.hip); RDST_ENOTSUP otherwise
+// nlse (optional): [B H W][6] floats, the forward's row statistics -(scale2 . max + log2 sum); o / ldo / nlse (optional, all
+// or none): the forward's output rows and statistics — with them the backward runs its streaming first pass (round 5)
 int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
-                     float scale, hipStream_t st);
+                     float scale, hipStream_t st, float* nlse = nullptr);
 int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
-                     int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st);
+                     int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st,
+                     const void* o = nullptr, int64_t ldo = 0, const float* nlse = nullptr);
 // 16x16 windows in exact fp32 on the matrix cores (wattn16_f32.hip); RDST_ENOTSUP otherwise
 int wattn16_fwd_f32(const float* qkv, int64_t ld, const float* table, float* out, int64_t ldo, const WinGeom& g, float scale,
                     hipStream_t st);

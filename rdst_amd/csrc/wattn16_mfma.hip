@@ -30,6 +30,11 @@ struct W16Args {
   float* slab;                        // backward: [window][heads][961] partial d(table)
   WinGeom g;
   float scale;
+  // round 5: the forward can leave its row statistics, nlse[token][head] = -(scale2 . max + log2 sum) (so that
+  // exp2(scale2 . S + nlse) IS the attention weight); with them and the attention output the backward's first pass needs no
+  // row reductions (wattn16_bwd2_kernel)
+  float* nlse_out;                    // forward: [B H W][6] or NULL
+  const float* nlse; const bf16* o; int64_t ldo2;   // backward v2: the statistics and the forward's output rows, or NULL
 };
 
 template <int D>
@@ -65,6 +70,7 @@ __device__ __forceinline__ void w16_locate(int nwin, int& win, int& grp) {
 }
 
 struct W16Ctx {
+  float* lse;               // forward: the lane's slot nlse_out[token][pair's first head], or NULL
   lds_cp Qp, Kp, Vp, Orow;
   const LDS_AS f32x2* tb;   // lane base into the reversed table copy of its parity (head 0 of the pair)
   int h, r;
@@ -174,6 +180,7 @@ __device__ __forceinline__ void w16_head_fwd(const W16Ctx& c) {
     }
   }
   const float inv = __builtin_amdgcn_rcpf(half_swap_sum(l0 + l1));
+  if (c.lse && c.h == 0) c.lse[HL] = nm + __builtin_amdgcn_logf(inv);   // (what pass 1 of the backward would compute)
   store_tile_rows<RL, c_lo, c_hi>(c.Orow, acc, inv, c.h);
 }
 
@@ -271,6 +278,7 @@ __global__ void __launch_bounds__(256, 2) wattn16_fwd_kernel(const W16Args p) {
     c.qt = qt;
     c.Qp = (lds_cp)(Qs + (qt * 32 + r) * ldt + h * 16);
     c.Orow = (lds_cp)(Qs + (qt * 32 + r) * ldt);
+    c.lse = p.nlse_out ? p.nlse_out + win_token16(b, wr, wc, qt * 32 + r, g) * CF::HEADS + grp * 2 : nullptr;
     {
       const int yi = 2 * qt + (r >> 4), xi = r & 15;
       const int u0 = (15 - yi) * CF::TROW + 15 - xi + 4 * h;
@@ -458,6 +466,101 @@ __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
   }
 }
 
+// Pass 1 of the backward WITH the forward's row statistics (round 5): nothing about a query's row has to be known before its
+// key tiles are visited any more — P = exp2(scale2 . S + nlse) tile by tile, dP - delta with -delta = -rowsum(dO o O) as the
+// initial accumulator — so the 8 key tiles are streamed through 16 + 16 registers instead of living in 128: no row maximum,
+// no row sum, no normalisation, no delta pass, dP formed ONCE: 5.5 vector instructions per logit instead of 8.5 and half
+// the matrix instructions.  (nlse, -delta) of the head are read from `stat`, where the prologue put them for pass 2.
+template <int D, int HL, typename PT = float>
+__device__ __forceinline__ void w16_bwd_p1s(const W16BCtx& c, f32x16& dq) {
+  using CF = W16<D>;
+  constexpr int ldt = CF::LDT;
+  constexpr int c_lo = HL * D, c_hi = c_lo + D;
+  constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
+  constexpr int RL = c_lo & ~3;
+  const int h = c.sc.h;
+  const LDS_AS float* st = c.stat + HL * 3 * 256 + c.sc.qt * 32 + c.sc.r;
+  const float nl = st[0], nd = st[256];
+  Pack16 qb[NT], dob[NT];   // Q and dO^T of the lane's query, the head's channels only
+#pragma unroll
+  for (int t = t_lo; t <= t_hi; ++t) {
+    qb[t - t_lo] = lds_pack(c.sc.Qp + t * 32);
+    dob[t - t_lo] = lds_pack(c.dOp + t * 32);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t mA = qmask_bits(t * 16 + 2 * e, c_lo, c_hi), mB = qmask_bits(t * 16 + 8 + 2 * e, c_lo, c_hi);
+      qb[t - t_lo].w[e] &= h ? mB : mA;
+      dob[t - t_lo].w[e] &= h ? mB : mA;
+    }
+  }
+  Pack16 mQ;
+  const int xi = c.sc.r & 15;
+  const int rx = (c.sc.mcol && xi >= c.sc.thr) ? 1 : 0;
+  if (c.sc.masked) onehot4(2 * ((c.sc.mrow && 2 * c.sc.qt + (c.sc.r >> 4) >= c.sc.thr) ? 1 : 0) + rx, c.sc.cbits, h, mQ);
+  const LDS_AS f32x2* tbh = c.sc.tb + HL * (2 * CF::TABF / 2);
+#pragma unroll
+  for (int v = 0; v < 16; ++v) dq[v] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 8; ++kt) {
+    f32x16 X, dp;
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+      const f32x2 b2 = lds_read_f32x2(tbh + ((2 * kt + (v >> 3)) * CF::TROW + 8 * ((v >> 2) & 1) + (v & 3)) / 2);
+      X[v] = b2.x;
+      X[v + 1] = b2.y;
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dp[v] = nd;
+#pragma unroll
+    for (int t = t_lo; t <= t_hi; ++t) {
+      Mma<bf16>::mma(X, lds_pack(c.sc.Kp + kt * 32 * ldt + t * 32), qb[t - t_lo]);
+      Mma<bf16>::mma(dp, lds_pack(c.Vrow + kt * 32 * ldt + t * 32), dob[t - t_lo]);
+    }
+    if (c.sc.masked) {
+      Pack16 mK;
+      onehot4(2 * ((c.sc.mrow && 2 * kt + (c.sc.r >> 4) >= c.sc.thr) ? 1 : 0) + rx, 0x3f80u, h, mK);
+      Mma<bf16>::mma(X, mK, mQ);
+    }
+    float lo[2] = {0.f, 0.f}, hi[2] = {0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const float ds = __builtin_amdgcn_exp2f(__builtin_fmaf(X[v], c.sc.scale2, nl)) * dp[v];
+      dp[v] = ds;
+      const int yl = v >> 3;
+      switch (8 * ((v >> 2) & 1) + (v & 3)) {
+#define RDST_W16_DIAG(XL) case XL: lo[yl] += dpp_row_shr<15 - XL>(ds); hi[yl] += dpp_row_shl<XL + 1>(ds); break;
+        RDST_W16_DIAG(0) RDST_W16_DIAG(1) RDST_W16_DIAG(2) RDST_W16_DIAG(3)
+        RDST_W16_DIAG(8) RDST_W16_DIAG(9) RDST_W16_DIAG(10) RDST_W16_DIAG(11)
+#undef RDST_W16_DIAG
+        default: break;
+      }
+    }
+#pragma unroll
+    for (int yl = 0; yl < 2; ++yl) {   // lane half 1 holds the same row sums 4 columns further right: merge into half 0
+      const float l1 = other_half(lo[yl], h), h1 = other_half(hi[yl], h);
+      const float nlo = lo[yl] + dpp_row_shl<4>(l1) + dpp_row_shr<12>(h1);
+      const float nhi = hi[yl] + dpp_row_shl<4>(h1);
+      if (h == 0) {
+        if constexpr (sizeof(PT) == 4) {
+          c.part[(2 * kt + yl) * 32] = nlo;
+          c.part[(2 * kt + yl) * 32 + 16] = nhi;
+        } else {   // bf16 row sums in the 16-wave kernel: both heads' slots have to fit
+          LDS_AS uint16_t* pt = (LDS_AS uint16_t*)c.part;
+          pt[(2 * kt + yl) * 32] = __builtin_bit_cast(uint16_t, (__bf16)nlo);
+          pt[(2 * kt + yl) * 32 + 16] = __builtin_bit_cast(uint16_t, (__bf16)nhi);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Pack16 pb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pb.w[e] = pack_bf16x2(dp[8 * s + 2 * e], dp[8 * s + 2 * e + 1]);
+      Mma<bf16>::mma(dq, tr_pack(c.Ktr + RL * 2 + (kt * 32 + 16 * s) * ldt, ldt), pb);   // rows = channels (K^T), cols = queries
+    }
+  }
+}
+
 template <int D, int HL>
 __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
   using CF = W16<D>;
@@ -542,7 +645,7 @@ __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
   store_tile_rows<RL, c_lo, c_hi>(c.Vst, dv, 1.0f, h);
 }
 
-template <int D>
+template <int D, bool V2>
 __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using CF = W16<D>;
@@ -641,6 +744,37 @@ __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
   }
   __syncthreads();
 
+  if constexpr (V2) {
+    // (nlse, -delta) of this wave's 32 queries, lane half h = head h of the pair: delta = sum over the head's channels of
+    // dO . O (= sum_j P_ij dP_ij: what pass 1 used to accumulate over all 256 keys), O from the forward's output rows
+    const int q = wv * 32 + r;
+    const int64_t tok = win_token16(b, wr, wc, q, g);
+    const bf16* orow = p.o + tok * p.ldo2 + grp * CF::GC + h * D;
+    const char* drow = dOs + q * ldt + h * D * 2;
+    float dl = 0.f;
+    if constexpr (D % 2 == 0) {
+      uint32_t ov[D / 2];
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) ov[i] = reinterpret_cast<const uint32_t*>(orow)[i];
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) {
+        const uint32_t dv = reinterpret_cast<const uint32_t*>(drow)[i];
+        dl = fmaf(bf16lo(dv), bf16lo(ov[i]), dl);
+        dl = fmaf(bf16hi(dv), bf16hi(ov[i]), dl);
+      }
+    } else {
+      uint16_t ov[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) ov[i] = reinterpret_cast<const uint16_t*>(orow)[i];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const uint16_t dv = reinterpret_cast<const uint16_t*>(drow)[i];
+        dl = fmaf(__uint_as_float((uint32_t)dv << 16), __uint_as_float((uint32_t)ov[i] << 16), dl);
+      }
+    }
+    stat[h * 3 * 256 + q] = p.nlse[tok * CF::HEADS + grp * 2 + h];
+    stat[h * 3 * 256 + 256 + q] = -dl;
+  }
   W16BCtx c;
   c.sc.h = h; c.sc.r = r;
   c.sc.thr = g.ws - g.shift;
@@ -673,13 +807,15 @@ __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
 #pragma unroll
   for (int v = 0; v < 16; ++v) { dq0[v] = 0.f; dq1[v] = 0.f; }
 #else
-  w16_bwd_p1<D, 0>(c, dq0);
+  if constexpr (V2) w16_bwd_p1s<D, 0>(c, dq0);
+  else w16_bwd_p1<D, 0>(c, dq0);
 #endif
   __syncthreads();
   if (!(W16_ABL & 4)) w16_dtable_out(part, slab_row, tid);
   __syncthreads();
 #if !(W16_ABL & 1)
-  w16_bwd_p1<D, 1>(c, dq1);
+  if constexpr (V2) w16_bwd_p1s<D, 1>(c, dq1);
+  else w16_bwd_p1<D, 1>(c, dq1);
 #endif
   __syncthreads();
   if (!(W16_ABL & 4)) w16_dtable_out(part, slab_row + 961, tid);
@@ -719,9 +855,245 @@ __global__ void __launch_bounds__(512, 1) wattn16_bwd_kernel(const W16Args p) {
   }
 }
 
+// ---- round 5: the backward with the forward's statistics as ONE 16-wave workgroup per (window, head pair) -----------------
+// With the streaming first pass (w16_bwd_p1s) a wave needs 125-141 registers instead of 218-232, so both heads of the pair run
+// side by side: wave = (tile, head) in both passes, 4 waves per SIMD where the 8-wave kernel had 2 (its vector ALUs were 31 %
+// busy).  The d(table) row sums of the two heads sit in LDS as bf16 (2 x 16 KB; fp32 would not fit at D = 15 / 20) and are
+// added in fp32 in a fixed order: 2^-9 per slot, 16 slots per entry.
+template <int D>
+struct W16B3 {
+  using CF = W16<D>;
+  static constexpr int SEC = CF::SEC;
+  static constexpr int OFF_TABR = 4 * SEC + 64;
+  static constexpr int OFF_TABN = OFF_TABR + 2 * 2 * CF::TABF * 4;
+  static constexpr int OFF_STAT = OFF_TABN + 2 * 2 * CF::TABF * 4;    // [head][nlse | -delta | (unused)][256]
+  static constexpr int OFF_PART = OFF_STAT + 2 * 3 * 256 * 4;         // [head][yi 16][yj 16][32] bf16
+  static constexpr size_t SMEM = (size_t)OFF_PART + 2 * 16 * 16 * 32 * 2;
+};
+
+template <int D>
+__global__ void __launch_bounds__(1024, 4) wattn16_bwd3_kernel(const W16Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using CF = W16<D>;
+  using BF = W16B3<D>;
+  using CH = typename Chunk<CF::GRAN>::type;
+  constexpr int ldt = CF::LDT, GRAN = CF::GRAN, CPS = CF::CPS, CPR = 3 * CPS, RPI = 64 / CPR, NI = 16 / RPI;
+  constexpr int RPD = 64 / CPS, ND = (16 + RPD - 1) / RPD;
+  static_assert(16 % RPI == 0, "a wave stages 16 token rows");
+  const WinGeom g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = wv & 7, hl = wv >> 3;          // this wave's tile (queries in pass 1, keys in pass 2) and head of the pair
+  char* Qs = smem;
+  char* Ks = Qs + CF::SEC;
+  char* Vs = Ks + CF::SEC;
+  char* dOs = Vs + CF::SEC;
+  float* tabR = reinterpret_cast<float*>(smem + BF::OFF_TABR);
+  float* tabN = reinterpret_cast<float*>(smem + BF::OFF_TABN);
+  float* stat = reinterpret_cast<float*>(smem + BF::OFF_STAT);
+  bf16* part = reinterpret_cast<bf16*>(smem + BF::OFF_PART);
+
+  const int nW = g.nWh * g.nWw, nwin = g.B * nW;
+  int win, grp;
+  w16_locate(nwin, win, grp);
+  const int b = win / nW, wi = win - b * nW, wr = wi / g.nWw, wc = wi - wr * g.nWw;
+
+  // ---- this wave's 16 token rows of qkv and dO -> registers
+  const int lr0 = lane / CPR, ch = lane - lr0 * CPR;
+  const bool act = lr0 < RPI;
+  const int lr = act ? lr0 : RPI - 1;
+  const int sec = ch / CPS, cw = ch - sec * CPS;
+  CH regs[NI], dreg[ND];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int t = wv * 16 + i * RPI + lr;
+    const int64_t tok = win_token16(b, wr, wc, t, g);
+    const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld) + sec * (CF::C * 2) + grp * CF::PB + cw * GRAN;
+    regs[i] = *reinterpret_cast<const CH*>(src);
+  }
+  const int dr0 = lane / CPS, dc = lane - dr0 * CPS;
+  const bool dact0 = dr0 < RPD;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    int rr = i * RPD + (dact0 ? dr0 : RPD - 1);
+    rr = rr < 16 ? rr : 15;
+    const int64_t tok = win_token16(b, wr, wc, wv * 16 + rr, g);
+    const char* src = reinterpret_cast<const char*>(p.dout + tok * p.ldd) + grp * CF::PB + dc * GRAN;
+    dreg[i] = *reinterpret_cast<const CH*>(src);
+  }
+  // (nlse, -delta) of query tile tl for head hl: lane r = query, both lane halves compute the same
+  const int qown = tl * 32 + r;
+  const int64_t tokq = win_token16(b, wr, wc, qown, g);
+  float dl = 0.f;
+  const float nl_own = p.nlse[tokq * CF::HEADS + grp * 2 + hl];
+  {
+    const bf16* orow = p.o + tokq * p.ldo2 + grp * CF::GC + hl * D;
+    const bf16* drow = p.dout + tokq * p.ldd + grp * CF::GC + hl * D;
+    if constexpr (D % 2 == 0) {
+      uint32_t ov[D / 2], dv[D / 2];
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) { ov[i] = reinterpret_cast<const uint32_t*>(orow)[i]; dv[i] = reinterpret_cast<const uint32_t*>(drow)[i]; }
+#pragma unroll
+      for (int i = 0; i < D / 2; ++i) {
+        dl = fmaf(bf16lo(dv[i]), bf16lo(ov[i]), dl);
+        dl = fmaf(bf16hi(dv[i]), bf16hi(ov[i]), dl);
+      }
+    } else {
+      uint16_t ov[D], dv[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) { ov[i] = reinterpret_cast<const uint16_t*>(orow)[i]; dv[i] = reinterpret_cast<const uint16_t*>(drow)[i]; }
+#pragma unroll
+      for (int i = 0; i < D; ++i) dl = fmaf(__uint_as_float((uint32_t)dv[i] << 16), __uint_as_float((uint32_t)ov[i] << 16), dl);
+    }
+  }
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float rscale = 1.0f / p.scale;
+  {  // the pair's bias tables / scale: reversed (pass 1) and natural (pass 2), each with a copy shifted by one float
+    constexpr int NSRC = 2 * 961, NLD = (NSRC + 1023) / 1024;
+    float tv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int j = tid + 1024 * k;
+      const int jj = j < NSRC ? j : NSRC - 1;
+      const int h2 = jj >= 961 ? 1 : 0, rel = jj - 961 * h2;
+      tv[k] = p.table[rel * CF::HEADS + grp * 2 + h2];
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int j = tid + 1024 * k;
+      if (j < NSRC) {
+        const int h2 = j >= 961 ? 1 : 0, rel = j - 961 * h2;
+        const int ry = rel / 31, rx = rel - ry * 31;
+        const float v = tv[k] * rscale;
+        const int ir = (30 - ry) * CF::TROW + (30 - rx), in = ry * CF::TROW + rx;
+        float* A = tabR + h2 * 2 * CF::TABF;
+        A[ir] = v;
+        if (ir >= 1) A[CF::TABF + ir - 1] = v;
+        float* N = tabN + h2 * 2 * CF::TABF;
+        N[in] = v;
+        if (in >= 1) N[CF::TABF + in - 1] = v;
+      }
+    }
+  }
+  if (tid < 16) *reinterpret_cast<uint32_t*>(dOs + CF::SEC + 4 * tid) = 0u;   // guard behind the last dO row
+  if constexpr (ldt > CF::PB) {   // zero the pad bytes of every staged row
+    constexpr int padw = (ldt - CF::PB) / 4;
+    for (int idx = tid; idx < 4 * 256 * padw; idx += 1024) {
+      const int row = idx / padw, w = idx - row * padw;
+      *reinterpret_cast<uint32_t*>(Qs + (size_t)row * ldt + CF::PB + 4 * w) = 0u;
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = wv * 16 + i * RPI + lr;
+      chunk_to_lds<CH>(smem + sec * CF::SEC + t * ldt + cw * GRAN, regs[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int rr = i * RPD + dr0;
+    if (dact0 && rr < 16) chunk_to_lds<CH>(dOs + (wv * 16 + rr) * ldt + dc * GRAN, dreg[i]);
+  }
+  if (h == 0) {
+    stat[hl * 3 * 256 + qown] = nl_own;
+    stat[hl * 3 * 256 + 256 + qown] = -dl;
+  }
+  __syncthreads();
+
+  W16BCtx c;
+  c.sc.h = h; c.sc.r = r;
+  c.sc.thr = g.ws - g.shift;
+  c.sc.mrow = g.shift > 0 && wr == g.nWh - 1;
+  c.sc.mcol = g.shift > 0 && wc == g.nWw - 1;
+  c.sc.masked = c.sc.mrow || c.sc.mcol;
+  c.sc.cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
+  c.sc.scale2 = p.scale * LOG2E;
+  c.scale = p.scale;
+  c.stat = (LDS_AS float*)stat;
+  const int trofs = (4 * h + ((lane & 15) >> 2)) * ldt + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int y0 = 2 * tl + (r >> 4), x0 = r & 15;
+  const int u0 = (15 - y0) * CF::TROW + 15 - x0 + 4 * h;
+  {  // pass 1: wave = (query tile tl, head hl)
+    c.sc.qt = tl;
+    c.sc.Qp = (lds_cp)(Qs + (tl * 32 + r) * ldt + h * 16);
+    c.sc.Kp = (lds_cp)(Ks + r * ldt + h * 16);
+    c.sc.tb = (const LDS_AS f32x2*)((u0 & 1) ? tabR + CF::TABF + (u0 - 1) : tabR + u0);
+    c.dOp = (lds_cp)(dOs + (tl * 32 + r) * ldt + h * 16);
+    c.Vrow = (lds_cp)(Vs + r * ldt + h * 16);
+    c.Ktr = (lds_cp)(Ks + trofs);
+    c.part = (LDS_AS float*)(part + hl * 16 * 16 * 32 + (2 * tl + (r >> 4)) * 16 * 32 + (r & 15));
+  }
+  f32x16 dq;
+  if (hl == 0) w16_bwd_p1s<D, 0, bf16>(c, dq);
+  else w16_bwd_p1s<D, 1, bf16>(c, dq);
+  __syncthreads();
+  {  // d(table) of both heads: one thread per entry adds its <= 16 slots in fixed order
+    float* slab_row = p.slab + ((int64_t)win * CF::HEADS + grp * 2) * 961;
+    for (int idx = tid; idx < 2 * 961; idx += 1024) {
+      const int h2 = idx >= 961 ? 1 : 0, e = idx - 961 * h2;
+      const int ry = e / 31, rx = e - ry * 31;
+      const bf16* ph = part + h2 * 16 * 16 * 32;
+      float sum = 0.f;
+      for (int yi = 0; yi < 16; ++yi) {
+        const int yj = yi + 15 - ry;
+        if (yj >= 0 && yj < 16) sum += __bfloat162float(ph[(yi * 16 + yj) * 32 + rx]);
+      }
+      slab_row[idx] = sum;
+    }
+  }
+  {  // pass 2: wave = (key tile tl, head hl)
+    c.kt = tl;
+    c.QA = (lds_cp)(Qs + r * ldt + h * 16);
+    c.dOA = (lds_cp)(dOs + r * ldt + h * 16);
+    c.Qtr = (lds_cp)(Qs + trofs);
+    c.dOtr = (lds_cp)(dOs + trofs);
+    c.Kown = (lds_cp)(Ks + (tl * 32 + r) * ldt + h * 16);
+    c.Vown = (lds_cp)(Vs + (tl * 32 + r) * ldt + h * 16);
+    c.Kst = (lds_cp)(Ks + (tl * 32 + r) * ldt);
+    c.Vst = (lds_cp)(Vs + (tl * 32 + r) * ldt);
+    c.tb2 = (const LDS_AS f32x2*)((u0 & 1) ? tabN + CF::TABF + (u0 - 1) : tabN + u0);
+  }
+  // pass 2 reads K / V of the wave's own key rows into registers at its start and stores dK / dV over them at its end.  The
+  // other head's wave of the same tile reads the same rows, but only its own channels count (its packs are masked with
+  // compile-time constants) and only this wave's channels are written: no ordering between the two is needed.
+  if (hl == 0) w16_bwd_p2<D, 0>(c);
+  else w16_bwd_p2<D, 1>(c);
+  __syncthreads();   // every wave is done with Q as an operand: the wave's own (tile, head) piece of the query rows takes dQ
+  {
+    const lds_cp qrow = (lds_cp)(Qs + (tl * 32 + r) * ldt);
+    if (hl == 0) store_tile_rows<0, 0, D>(qrow, dq, p.scale, h);
+    else store_tile_rows<(D & ~3), D, 2 * D>(qrow, dq, p.scale, h);
+  }
+  __syncthreads();
+  // dQ | dK | dV (in place of Q / K / V) -> global rows of this wave's 16 tokens
+#pragma unroll 1
+  for (int idx = lane; idx < 16 * CPR; idx += 64) {
+    const int row = idx / CPR, k3 = idx - row * CPR;
+    const int s3 = k3 / CPS, k = k3 - s3 * CPS;
+    const int t = wv * 16 + row;
+    const int64_t tok = win_token16(b, wr, wc, t, g);
+    char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq) + s3 * (CF::C * 2) + grp * CF::PB + k * GRAN;
+    const char* src = smem + s3 * CF::SEC + (size_t)t * ldt + k * GRAN;
+    *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(src);
+  }
+}
+
+#ifndef W16_BWD3
+#define W16_BWD3 1   // with the forward's statistics: 1 = the 16-wave kernel (both heads of the pair side by side), 0 = the 8-wave kernel with
+#endif               // the streaming first pass
 template <int D>
 int launch_bwd16(const W16Args& p, hipStream_t st) {
-  auto kern = wattn16_bwd_kernel<D>;
+  if (W16_BWD3 && p.nlse && p.o) {
+    auto k3 = wattn16_bwd3_kernel<D>;
+    constexpr size_t smem3 = W16B3<D>::SMEM;
+    static_assert(smem3 <= 160 * 1024, "LDS");
+    (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+    const int64_t nwin3 = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
+    hipLaunchKernelGGL(k3, dim3((unsigned)(3 * nwin3)), dim3(1024), smem3, st, p);
+    return rdst_launch_status("wattn16_bwd3");
+  }
+  auto kern = (p.nlse && p.o) ? wattn16_bwd_kernel<D, true> : wattn16_bwd_kernel<D, false>;
   constexpr size_t smem = W16B<D>::SMEM;
   static_assert(smem <= 160 * 1024, "LDS");
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -736,11 +1108,12 @@ bool al(const void* a, int64_t lda_bytes, int gsz) { return (uintptr_t)a % gsz =
 
 // bf16, ws 16, 6 heads of dim 10 / 15 / 20, no explicit mask, scale > 0; RDST_ENOTSUP otherwise
 int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out, int64_t ldo, const WinGeom& g,
-                     float scale, hipStream_t st) {
+                     float scale, hipStream_t st, float* nlse) {
   if (g.ws != 16 || g.heads != 6 || g.mask || !(scale > 0.f) || g.C % 6) return RDST_ENOTSUP;
   if ((int64_t)g.B * g.nWh * g.nWw * 3 > 0x7fffffff) return RDST_ENOTSUP;
   W16Args p{};
   p.qkv = (const bf16*)qkv; p.ld = ld; p.table = table; p.out = (bf16*)out; p.ldo = ldo; p.g = g; p.scale = scale;
+  p.nlse_out = nlse;
   const int d = g.C / 6;
   if (d == 10 && al(qkv, ld * 2, 8) && al(out, ldo * 2, 8)) return launch_fwd16<10>(p, st);
   if (d == 15 && al(qkv, ld * 2, 4) && al(out, ldo * 2, 4)) return launch_fwd16<15>(p, st);
@@ -750,13 +1123,16 @@ int wattn16_fwd_mfma(const void* qkv, int64_t ld, const float* table, void* out,
 
 // slab: [windows][6][961] partial d(table), one row per window (*nslab = windows)
 int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void* dout, int64_t ldd, void* dqkv,
-                     int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st) {
+                     int64_t ldq, float* slab, int slab_rows, const WinGeom& g, float scale, int* nslab, hipStream_t st,
+                     const void* o, int64_t ldo, const float* nlse) {
   if (g.ws != 16 || g.heads != 6 || g.mask || !(scale > 0.f) || g.C % 6) return RDST_ENOTSUP;
   const int64_t nwin = (int64_t)g.B * g.nWh * g.nWw;
   if (nwin * 3 > 0x7fffffff || slab_rows < nwin) return RDST_ENOTSUP;
   W16Args p{};
   p.qkv = (const bf16*)qkv; p.ld = ld; p.table = table; p.dout = (const bf16*)dout; p.ldd = ldd;
   p.dqkv = (bf16*)dqkv; p.ldq = ldq; p.slab = slab; p.g = g; p.scale = scale;
+  p.o = (const bf16*)o; p.ldo2 = ldo; p.nlse = nlse;
+  if (o && (ldo & 1)) return RDST_ENOTSUP;
   *nslab = (int)nwin;
   const int d = g.C / 6;
   const int a = d == 10 ? 8 : d == 15 ? 4 : 16;

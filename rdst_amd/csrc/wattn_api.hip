@@ -5,7 +5,7 @@
 
 thread_local char g_rdst_err[256] = {0};
 
-extern "C" int rdst_abi_version(void) { return 9; }
+extern "C" int rdst_abi_version(void) { return 10; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {
@@ -100,6 +100,45 @@ extern "C" int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w
   if (!prepacked && workspace_bytes < swinattn_pack_bytes(C)) return rdst_fail(RDST_EINVAL, "rdst_swin_attn_fwd: workspace too small");
   return swinattn_fwd_bf16((const bf16*)X, ld_x, ln_w, ln_b, Wqkv, bqkv, table, Wproj, bproj, (bf16*)qkv, ld_qkv, (bf16*)a, ld_a,
                            (bf16*)x1, ld_x1, stats, workspace, prepacked, g, scale, (hipStream_t)stream);
+}
+
+// ---- window attention with the forward's row statistics kept for the backward (window 16, bf16: wattn16_mfma.hip) ---------------
+// nlse[token][head] = -(scale log2e max_j S'_ij + log2 sum_j exp(...)): with it and the forward's output the backward's first pass
+// streams its key tiles (no row maximum / sum / normalisation / delta pass).  RDST_ENOTSUP for every shape the plain entry points
+// serve with other kernels: the caller then uses rdst_wattn_fwd / rdst_wattn_bwd.
+extern "C" int rdst_wattn_fwd_lse(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out, float* nlse,
+                                  int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype, void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, nullptr, 0, "rdst_wattn_fwd_lse")) return rc;
+  if (!qkv || !table || !out || !nlse) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_lse: null pointer");
+  if (ld_qkv < 3 * C || ld_out < C) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_lse: leading dimension too small");
+  if (dtype != RDST_BF16) return RDST_ENOTSUP;
+  return wattn16_fwd_mfma(qkv, ld_qkv, table, out, ld_out, g, scale, (hipStream_t)stream, nlse);
+}
+
+extern "C" int rdst_wattn_bwd_lse(const void* qkv, int64_t ld_qkv, const float* table, const void* dout, int64_t ld_dout,
+                                  const void* out, int64_t ld_out, const float* nlse, void* dqkv, int64_t ld_dqkv, float* dtable,
+                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
+                                  int shift, float scale, int dtype, void* stream) {
+  WinGeom g;
+  if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, nullptr, 0, "rdst_wattn_bwd_lse")) return rc;
+  if (!qkv || !table || !dout || !out || !nlse || !dqkv || !dtable || !workspace)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_lse: null pointer");
+  if (ld_qkv < 3 * C || ld_dqkv < 3 * C || ld_dout < C || ld_out < C)
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_lse: leading dimension too small");
+  if (workspace_bytes < rdst_wattn_bwd_workspace(B, H, W, C, heads, ws))
+    return rdst_fail(RDST_EINVAL, "rdst_wattn_bwd_lse: workspace too small");
+  if (dtype != RDST_BF16) return RDST_ENOTSUP;
+  hipStream_t st = (hipStream_t)stream;
+  float* slab = (float*)workspace;
+  int nslab = 0;
+  const int nwin = B * g.nWh * g.nWw;
+  if (int rc = wattn16_bwd_mfma(qkv, ld_qkv, table, dout, ld_dout, dqkv, ld_dqkv, slab, nwin, g, scale, &nslab, st, out, ld_out, nlse))
+    return rc;
+  rbatch::SumJob sj{};
+  sj.slab = slab; sj.nwg = nslab; sj.stride = (int64_t)heads * g.T; sj.tot = heads * g.T; sj.map = rbatch::MAP_DTABLE;
+  sj.out = dtable; sj.a = heads; sj.b = g.T;
+  return rbatch::sum(sj, st);
 }
 
 // ---- attention dropout (WindowAttention.attn_drop > 0 in training, swin_transformer_sr.py:102,136): the generic kernels with

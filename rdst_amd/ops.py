@@ -271,6 +271,7 @@ def _packed_workspace(kind, w, lw, lb, b, N, K, s, nbytes, device):
 _side_streams: dict = {}
 TWO_STREAM_BACKWARD = os.environ.get("RDST_TWO_STREAM", "0") != "0"   # env switch: profiling with clean kernel durations
 MLP_FUSED = os.environ.get("RDST_MLP_FUSED", "1") != "0"   # K7 (fused Mlp kernels) on/off
+ATTN_LSE = os.environ.get("RDST_ATTN_LSE", "1") != "0"       # window 16: keep the forward's row statistics for the backward (rdst_wattn_*_lse)
 ATTN_FUSED = os.environ.get("RDST_ATTN_FUSED", "1") != "0"   # K8 (LayerNorm + qkv -> attention -> proj + shortcut in one launch) on/off
 
 
@@ -710,10 +711,21 @@ class _SwinBlock(torch.autograd.Function):
                 fused_attn = False
             else:
                 _lib.check(rc, "rdst_swin_attn_fwd")
+        nlse = None
         if not fused_attn:
             lin(x_r.data_ptr(), ldx, n1w_, n1b_, ACT_NONE, qkvw_, qkvb_, None, 0, qkv, 3 * C, stats1, C)
-            _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
-                                          heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
+            if ATTN_LSE and ws == 16 and code == BF16:
+                # window 16: keep the row statistics, the backward's first pass then streams its key tiles (rdst_wattn_bwd_lse)
+                nlse = torch.empty((M, heads), dtype=torch.float32, device=dev)
+                rc = lib.rdst_wattn_fwd_lse(qkv.data_ptr(), 3 * C, tab_.data_ptr(), a.data_ptr(), C, nlse.data_ptr(), B, H, W, C,
+                                            heads, ws, shift, float(scale), code, _stream())
+                if rc == _lib.ENOTSUP:
+                    nlse = None
+                else:
+                    _lib.check(rc, "rdst_wattn_fwd_lse")
+            if nlse is None:
+                _lib.check(lib.rdst_wattn_fwd(qkv.data_ptr(), 3 * C, tab_.data_ptr(), None, 0, a.data_ptr(), C, B, H, W, C,
+                                              heads, ws, shift, float(scale), code, _stream()), "rdst_wattn_fwd")
             lin(a.data_ptr(), C, None, None, ACT_NONE, projw_, projb_, x_r.data_ptr(), ldx, x1, C, None, C)
         stats2 = torch.empty((M, 2), dtype=torch.float32, device=dev) if n2w_ is not None else None
         y = torch.empty(lead + (C,), dtype=dt, device=dev)
@@ -743,13 +755,13 @@ class _SwinBlock(torch.autograd.Function):
             h = torch.empty(lead + (hid,), dtype=dt, device=dev)
             lin(x1.data_ptr(), C, n2w_, n2b_, ACT_NONE, fc1w_, fc1b_, None, 0, h, hid, stats2, C)
             lin(h.data_ptr(), hid, None, None, ACT_GELU, fc2w_, fc2b_, x1.data_ptr(), C, y, C, None, hid)
-        ctx.save_for_backward(x_r, stats1, qkv, a, x1, stats2, h, *P)
+        ctx.save_for_backward(x_r, stats1, qkv, a, x1, stats2, h, nlse, *P)
         ctx.meta = (M, B, H, W, C, hid, heads, ws, shift, float(scale), ldx, code)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, stats1, qkv, a, x1, stats2, h, n1w, n1b, qkvw, qkvb, tab, projw, projb, n2w, n2b, fc1w, fc1b, fc2w,
+        (x, stats1, qkv, a, x1, stats2, h, nlse, n1w, n1b, qkvw, qkvb, tab, projw, projb, n2w, n2b, fc1w, fc1b, fc2w,
          fc2b) = ctx.saved_tensors
         M, B, H, W, C, hid, heads, ws, shift, scale, ldx, code = ctx.meta
         lib = _lib.load()
@@ -787,7 +799,7 @@ class _SwinBlock(torch.autograd.Function):
     @staticmethod
     def _backward_body(ctx, lib, dy_r, lddy, need, keep, dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b, dfc1w, dfc1b,
                        dfc2w, dfc2b):
-        (x, stats1, qkv, a, x1, stats2, h, n1w, n1b, qkvw, qkvb, tab, projw, projb, n2w, n2b, fc1w, fc1b, fc2w,
+        (x, stats1, qkv, a, x1, stats2, h, nlse, n1w, n1b, qkvw, qkvb, tab, projw, projb, n2w, n2b, fc1w, fc1b, fc2w,
          fc2b) = ctx.saved_tensors
         M, B, H, W, C, hid, heads, ws, shift, scale, ldx, code = ctx.meta
         dev, dt = x.device, x.dtype
@@ -845,9 +857,17 @@ class _SwinBlock(torch.autograd.Function):
         nbytes = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
         wsp = _workspace(nbytes, dev)
         keep.append(wsp)
-        _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), 3 * C, tab.data_ptr(), None, 0, da.data_ptr(), C,
-                                      dqkv.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
-                                      heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
+        rc = _lib.ENOTSUP
+        if nlse is not None:   # window 16 with the forward's row statistics: the streaming first pass
+            rc = lib.rdst_wattn_bwd_lse(qkv.data_ptr(), 3 * C, tab.data_ptr(), da.data_ptr(), C, a.data_ptr(), C, nlse.data_ptr(),
+                                        dqkv.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C, heads, ws,
+                                        shift, scale, code, _stream())
+            if rc != _lib.ENOTSUP:
+                _lib.check(rc, "rdst_wattn_bwd_lse")
+        if rc == _lib.ENOTSUP:
+            _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), 3 * C, tab.data_ptr(), None, 0, da.data_ptr(), C,
+                                          dqkv.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nbytes, B, H, W, C,
+                                          heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
         # LN1 + qkv, plus the residual fan-out of x:  dx = dx1 + LN1'(dqkv Wqkv)
         dx = torch.empty(x.shape, dtype=dt, device=dev) if need[0] else None
         extra = ctx.sink.take() if ctx.sink is not None else None   # the dense join's gradient slice for x (GradSink)

@@ -264,3 +264,76 @@ def test_k2_pair_equals_the_strided_row_fallback(C):
     dq = (res[0][0] - res[2][0]).abs().max().item()
     assert dq <= 2 ** -7 * max(1.0, res[0][0].abs().max().item()), dq                       # one bf16 ulp of the largest gradient
     assert (res[0][1] - res[2][1]).norm().item() <= 8e-3 * res[0][1].norm().item()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Window 16 with the forward's row statistics kept (rdst_wattn_fwd_lse / rdst_wattn_bwd_lse, round 5): the backward's first
+# pass streams its key tiles; delta = rowsum(dO o O) from the forward's output
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [60, 90, 120])
+@pytest.mark.parametrize("B,H,W,shift", [(1, 16, 16, 0), (2, 32, 48, 8), (1, 48, 32, 5), (3, 32, 32, 0)])
+def test_wattn16_lse_path_vs_oracle_and_plain_path(C, B, H, W, shift):
+    from rdst_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    heads, ws = 6, 16
+    scale = (C // heads) ** -0.5
+    M = B * H * W
+    qkv = _rand((B, H, W, 3 * C), 5 + C + shift).bfloat16()
+    table = _rand(((2 * ws - 1) ** 2, heads), 6 + C, 0.5)
+    gout = _rand((B, H, W, C), 7 + C).bfloat16()
+    q_ref = qkv.float().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout.float())
+
+    qg, tg, gg = qkv.to(dev), table.to(dev), gout.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    out0 = torch.empty_like(out)
+    nlse = torch.full((M, heads), float("nan"), device=dev)
+    _lib.check(lib.rdst_wattn_fwd_lse(qg.data_ptr(), 3 * C, tg.data_ptr(), out.data_ptr(), C, nlse.data_ptr(), B, H, W, C, heads, ws,
+                                      shift, scale, _lib.BF16, st), "fwd_lse")
+    _lib.check(lib.rdst_wattn_fwd(qg.data_ptr(), 3 * C, tg.data_ptr(), None, 0, out0.data_ptr(), C, B, H, W, C, heads, ws, shift, scale,
+                                  _lib.BF16, st), "fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(out, out0)                                   # the same forward, plus the statistics
+    assert torch.isfinite(nlse).all()
+    assert (out.float().cpu().reshape(o_ref.shape) - o_ref.detach()).abs().max().item() <= 2e-2
+
+    nb = lib.rdst_wattn_bwd_workspace(B, H, W, C, heads, ws)
+    res = []
+    for which in ("lse", "lse", "plain"):
+        dq = torch.full((M, 3 * C), float("nan"), dtype=torch.bfloat16, device=dev)
+        dt = torch.full_like(tg, float("nan"))
+        wsp = torch.empty(nb, dtype=torch.uint8, device=dev)
+        if which == "lse":
+            _lib.check(lib.rdst_wattn_bwd_lse(qg.data_ptr(), 3 * C, tg.data_ptr(), gg.data_ptr(), C, out.data_ptr(), C, nlse.data_ptr(),
+                                              dq.data_ptr(), 3 * C, dt.data_ptr(), wsp.data_ptr(), nb, B, H, W, C, heads, ws, shift,
+                                              scale, _lib.BF16, st), "bwd_lse")
+        else:
+            _lib.check(lib.rdst_wattn_bwd(qg.data_ptr(), 3 * C, tg.data_ptr(), None, 0, gg.data_ptr(), C, dq.data_ptr(), 3 * C,
+                                          dt.data_ptr(), wsp.data_ptr(), nb, B, H, W, C, heads, ws, shift, scale, _lib.BF16, st), "bwd")
+        torch.cuda.synchronize()
+        res.append((dq.float().cpu().reshape(q_ref.shape), dt.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])        # bit-deterministic run to run
+    for name, (dq, dt) in (("lse", res[0]), ("plain", res[2])):
+        assert torch.isfinite(dq).all() and torch.isfinite(dt).all(), name
+        rel_q = (dq - q_ref.grad).norm().item() / q_ref.grad.norm().item()
+        rel_t = (dt - t_ref.grad).norm().item() / t_ref.grad.norm().item()
+        assert (dq - q_ref.grad).abs().max().item() <= 6e-2 and rel_q <= 1.2e-2 and rel_t <= 2e-2, (name, rel_q, rel_t)
+
+
+def test_wattn_lse_entry_points_refuse_other_shapes():
+    from rdst_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    C, heads = 60, 6
+    qkv = torch.zeros(1, 16, 16, 3 * C, dtype=torch.bfloat16, device=dev)
+    table = torch.zeros(225, heads, device=dev)
+    out = torch.empty(256, C, dtype=torch.bfloat16, device=dev)
+    nlse = torch.empty(256, heads, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.rdst_wattn_fwd_lse(qkv.data_ptr(), 3 * C, table.data_ptr(), out.data_ptr(), C, nlse.data_ptr(), 1, 16, 16, C, heads, 8, 0,
+                                0.3, _lib.BF16, st)
+    assert rc == _lib.ENOTSUP            # window 8 is served by other kernels: the caller uses rdst_wattn_fwd

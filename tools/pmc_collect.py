@@ -45,6 +45,7 @@ KERNELS = {
     "mlp3_fwd_kernel": ("mlp3_fwd_kernel", ["mlp3_mfma.hip"]),
     "wattn16_fwd_kernel": ("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "wattn16_bwd_kernel": ("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
+    "wattn16_bwd3_kernel": ("wattn16_bwd3_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "uconv_halo_kernel": ("uconv_halo_kernel", ["uconv_mfma.hip"]),
     "uconv_kernel": ("uconv_kernel", ["uconv_mfma.hip"]),
 }

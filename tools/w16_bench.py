@@ -37,4 +37,12 @@ for C in [int(c) for c in sys.argv[1:]] or [60, 90, 120]:
         _lib.check(lib.rdst_wattn_bwd(q.data_ptr(), 3 * C, table.data_ptr(), None, 0, g.data_ptr(), C, d.data_ptr(), 3 * C,
                                       dtab.data_ptr(), wsp.data_ptr(), nws, B, H, W, C, heads, ws, 8, sc, _lib.BF16, st),
                    "rdst_wattn_bwd")
-    print(f"C={C}: fwd {timed(fwd):7.1f} us   bwd {timed(bwd):7.1f} us", flush=True)
+    nlse = torch.empty(B * H * W, heads, device=dev)
+    def fwd2():
+        _lib.check(lib.rdst_wattn_fwd_lse(q.data_ptr(), 3 * C, table.data_ptr(), o.data_ptr(), C, nlse.data_ptr(), B, H, W, C, heads,
+                                          ws, 8, sc, _lib.BF16, st), "rdst_wattn_fwd_lse")
+    def bwd2():
+        _lib.check(lib.rdst_wattn_bwd_lse(q.data_ptr(), 3 * C, table.data_ptr(), g.data_ptr(), C, o.data_ptr(), C, nlse.data_ptr(),
+                                          d.data_ptr(), 3 * C, dtab.data_ptr(), wsp.data_ptr(), nws, B, H, W, C, heads, ws, 8, sc,
+                                          _lib.BF16, st), "rdst_wattn_bwd_lse")
+    print(f"C={C}: fwd {timed(fwd):7.1f} us   bwd {timed(bwd):7.1f} us   |  with statistics: fwd {timed(fwd2):7.1f} us   bwd {timed(bwd2):7.1f} us", flush=True)
