@@ -1132,7 +1132,8 @@ int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void
   p.qkv = (const bf16*)qkv; p.ld = ld; p.table = table; p.dout = (const bf16*)dout; p.ldd = ldd;
   p.dqkv = (bf16*)dqkv; p.ldq = ldq; p.slab = slab; p.g = g; p.scale = scale;
   p.o = (const bf16*)o; p.ldo2 = ldo; p.nlse = nlse;
-  if (o && (ldo & 1)) return RDST_ENOTSUP;
+  if (o && !al(o, ldo * 2, 4)) return RDST_ENOTSUP;   // (delta reads the head's piece of the output row with dword loads)
+  if ((o == nullptr) != (nlse == nullptr)) return RDST_ENOTSUP;
   *nslab = (int)nwin;
   const int d = g.C / 6;
   const int a = d == 10 ? 8 : d == 15 ? 4 : 16;
