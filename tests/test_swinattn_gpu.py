@@ -185,3 +185,34 @@ def test_block_through_autograd_fused_on_and_off_agree(C, monkeypatch):
         res[on] = [y.detach().clone(), x.grad.clone()] + [t.grad.clone() for t in leaves]
     for i, (u, v) in enumerate(zip(res[True], res[False])):
         assert torch.equal(u, v), i
+
+
+def test_network_eval_nonsquare_through_k8_equals_the_three_call_path(monkeypatch):
+    """The whole RDST-E1 network in eval mode on a non-square whole slice (40 x 72: 45 windows per image, not a multiple of
+    anything), bf16: with K8 and with the three-call composition the SR image is bit-identical (K8 runs the same arithmetic),
+    and so is a training step's loss and every parameter gradient."""
+    import torch.nn.functional as F2
+    from rdst_amd import ops
+    from util import build_net
+    cfg = O.CFG_E1
+    sd = O.make_weights(cfg, 5)
+    x = rand((2, 1, 40, 72), 3).abs().clamp(0, 1)
+    tgt = rand((2, 1, 160, 288), 4).abs().clamp(0, 1)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "ATTN_FUSED", on)
+        net = build_net(cfg)
+        net.load_state_dict(sd, strict=True)
+        net.to(DEV).set_compute_dtype(torch.bfloat16)
+        net.eval()
+        with torch.no_grad():
+            y_eval = net(x.to(DEV)).clone()
+        net.train()
+        loss = F2.l1_loss(net(x.to(DEV)), tgt.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        res[on] = (y_eval, loss.detach().clone(), [p.grad.clone() for p in net.parameters() if p.requires_grad])
+    assert torch.isfinite(res[True][0]).all()
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    assert len(res[True][2]) == 750 and all(torch.equal(a, b) for a, b in zip(res[True][2], res[False][2]))
