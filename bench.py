@@ -341,7 +341,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="patches per GPU (default 32; 8 for --config ws16)")
     ap.add_argument("--config", default="e1", choices=sorted(CONFIGS), help="e1 = the BASELINE.json metric (default)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp32x3"],
+                    help="bf16 = the BASELINE.json mode; fp32 = exact parity mode; fp32x3 = fp32 tensors, split-bf16 GEMMs (the fast parity mode)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--unet-dtype", default=None, choices=["fp32", "fp32x3", "bf16"],
                     help="arithmetic of the seg-UNet loss network (e1_unetf / e1_hrl); default fp32x3: fp32 activations, 3-term bf16 "
@@ -386,7 +387,7 @@ def main():
     if args.force_pg:
         dp.FORCE_COLLECTIVES = True
     from rdst_amd.trainer import DPTrainStep
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.bfloat16 if args.dtype == "bf16" else ("fp32x3" if args.dtype == "fp32x3" else torch.float32)
     cfg, lr_size, in_ch, sr, cfg_name = CONFIGS[args.config]
     if args.batch is None:
         args.batch = 8 if args.config == "ws16" else 32

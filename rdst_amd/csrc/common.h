@@ -66,6 +66,20 @@ static inline int rdst_launch_status(const char* what) {
   return 0;
 }
 
+// RDST_F32X3 on the network entry points: fp32 tensors, GEMMs in the split arithmetic of mfma.h (Mma<float, true>).
+// The entry point opens a SplitScope, which turns the dtype into RDST_F32 for everything below it and leaves the mode in
+// a thread-local that the launchers of the converted kernels read (kernels without a split form run exact fp32).
+extern thread_local int g_rdst_split;
+struct SplitScope {
+  int prev;
+  explicit SplitScope(int& dtype) : prev(g_rdst_split) {
+    g_rdst_split = dtype == RDST_F32X3 || (prev && dtype == RDST_F32);   // (an entry point that forwards to another one keeps the mode)
+    if (dtype == RDST_F32X3) dtype = RDST_F32;
+  }
+  ~SplitScope() { g_rdst_split = prev; }
+};
+static inline bool rdst_split() { return g_rdst_split != 0; }
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return __bfloat162float(v); }

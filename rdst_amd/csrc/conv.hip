@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(256) rows_to_nchw_kernel(const T* __restrict__
 }  // namespace
 
 extern "C" int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_r, int has_residual, int in_act, int dtype) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (dtype != RDST_BF16 || ksize != 3 || in_act) return 0;
   return (Cin == 150 && Cout == 60 && shuffle_r == 1) || (Cin == 60 && Cout == 60 && shuffle_r == 1) ||
          (Cin == 60 && Cout == 240 && shuffle_r == 2 && !has_residual);
@@ -259,6 +260,7 @@ extern "C" size_t rdst_conv_fwd_workspace(int Cin, int Cout, int ksize) {
 extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const float* bias, const void* R,
                              int64_t ld_r, void* Y, int64_t ld_y, void* workspace, size_t workspace_bytes, int B, int H, int W,
                              int Cin, int Cout, int ksize, float out_scale, int shuffle_r, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   ConvGeom g;
   if (int rc = make_geom(g, B, H, W, Cin, Cout, ksize, shuffle_r, "rdst_conv_fwd")) return rc;
   if (!X || !Wc || !Y) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: null pointer");
@@ -285,6 +287,7 @@ extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const floa
                              void* workspace,
                              size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int ksize, float out_scale,
                              int shuffle_r, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   ConvGeom g;
   if (int rc = make_geom(g, B, H, W, Cin, Cout, ksize, shuffle_r, "rdst_conv_bwd")) return rc;
   if (!X || !Wc || !dY || !workspace) return rdst_fail(RDST_EINVAL, "rdst_conv_bwd: null pointer");
@@ -299,6 +302,7 @@ extern "C" int rdst_conv_bwd(const void* X, int64_t ld_x, int in_act, const floa
 }
 
 extern "C" int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int B, int C, int H, int W, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (!nchw || !rows || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return rdst_fail(RDST_EINVAL, "rdst_nchw_to_rows: bad arguments");
   const int64_t n = (int64_t)B * C * H * W;
   const dim3 grid((unsigned)((n + 255) / 256));
@@ -310,6 +314,7 @@ extern "C" int rdst_nchw_to_rows(const float* nchw, void* rows, int64_t ld, int 
 }
 
 extern "C" int rdst_rows_to_nchw(const void* rows, int64_t ld, float* nchw, int B, int C, int H, int W, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (!nchw || !rows || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ld < C) return rdst_fail(RDST_EINVAL, "rdst_rows_to_nchw: bad arguments");
   const int64_t n = (int64_t)B * C * H * W;
   const dim3 grid((unsigned)((n + 255) / 256));

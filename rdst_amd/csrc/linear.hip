@@ -599,6 +599,7 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
 }  // namespace
 
 extern "C" int rdst_ln_linear_fwd_packable(int K, int N, int has_ln, int has_residual, int in_act, int dtype) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (dtype != RDST_BF16 || in_act || !(K == 60 || K == 90 || K == 120)) return 0;
   return (has_ln && !has_residual && (N == 3 * K || N == 30)) || (!has_ln && has_residual && N == K);
 }
@@ -612,6 +613,7 @@ extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w
                                   const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y, int64_t ld_y,
                                   float* stats, void* workspace, size_t workspace_bytes, int64_t M, int K, int N,
                                   float out_scale, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (!X || !Y) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: null pointer");
   if (M < 0 || K <= 0 || N <= 0) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: bad dimensions");
   if ((ln_w == nullptr) != (ln_b == nullptr)) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_fwd: ln_w/ln_b must come together");
@@ -644,6 +646,7 @@ extern "C" int rdst_ln_linear_bwd2(const void* X, int64_t ld_x, const float* ln_
                                   void* workspace,
                                   size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
                                   void* stream, const void* dX_add2, int64_t ld_dx_add2) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (!X || !dY || !workspace) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: null pointer");
   if (M < 0 || K <= 0 || N <= 0) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: bad dimensions");
   if (ln_w && !stats) return rdst_fail(RDST_EINVAL, "rdst_ln_linear_bwd: LayerNorm needs the forward's stats");
@@ -671,6 +674,7 @@ extern "C" int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w
                                   const void* dX_add, int64_t ld_dx_add, float* dW, float* dbias, float* dln_w, float* dln_b,
                                   void* workspace, size_t workspace_bytes, int64_t M, int K, int N, float out_scale, int dtype,
                                   void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   return rdst_ln_linear_bwd2(X, ld_x, ln_w, ln_b, stats, in_act, Wt, dY, ld_dy, dX, ld_dx, dX_add, ld_dx_add, dW, dbias, dln_w, dln_b,
                              workspace, workspace_bytes, M, K, N, out_scale, dtype, stream, nullptr, 0);
 }

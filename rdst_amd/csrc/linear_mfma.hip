@@ -59,10 +59,10 @@ struct LinArgs {
 // residual / activation-gradient / accumulate operands are read with the same 16-B row chunks and
 // added in fp32 before the single rounding.  The bias is the initial accumulator.  The next slab's
 // fragments are prefetched while the current one is multiplied.
-template <typename T, int TMAX, int MODE>
+template <typename T, int TMAX, int MODE, bool SP = false>
 __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;   // SP: the split arithmetic of RDST_F32X3 (mfma.h) — the weights are split as they are staged, a slab's fragments once
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
               f[4 * q] = __uint_as_float(v[u][q].x); f[4 * q + 1] = __uint_as_float(v[u][q].y);
               f[4 * q + 2] = __uint_as_float(v[u][q].z); f[4 * q + 3] = __uint_as_float(v[u][q].w);
             }
-            *reinterpret_cast<Pack16*>(Ws + (size_t)n * p.ldw + ph * 16) = MM::pack(f);
+            *reinterpret_cast<Pack16*>(Ws + (size_t)n * p.ldw + ph * 16) = MM::pack_op(f);
           }
         }
       }
@@ -247,6 +247,15 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
       lds_zero16(Ws, ((p.nch & 31) ? nc : ncp) * p.ldw, tid, 512);   // (a tight chunk ends with its last row: see launch_lin)
       __syncthreads();
       stage_scatter<T>(p.Wt + n0, p.Kc, nc, (int64_t)p.wK, tid, 512, Ws, [&](int k, int n) { return n * p.ldw + k * (int)sizeof(T); });
+      if constexpr (MM::SPLIT) {   // the scattered image holds floats: split it in place, pack by pack
+        __syncthreads();
+        const int rows = (p.nch & 31) ? nc : ncp, ppr = 2 * Tn;
+        for (int i = tid; i < rows * ppr; i += 512) {
+          const int n = i / ppr, ph = i - n * ppr;
+          Pack16* q = reinterpret_cast<Pack16*>(Ws + (size_t)n * p.ldw + ph * 16);
+          *q = MM::op(*q);
+        }
+      }
     }
     if (n0 == 0) {
       if (has_ln && tid < Tn * KP) { gam[tid] = pre_g; bet[tid] = pre_b; }
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
                 }
 #pragma unroll
                 for (int e = 0; e < HP; ++e) f[t][e] = fmaf(f[t][e] * rstd, gq[e], bq[e]);   // gamma = beta = 0 past Kc
-                a[t] = MM::pack(f[t]);
+                a[t] = MM::pack_op(f[t]);
               }
           } else {
             float sum = 0.f;
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
                 const int k0 = t * KP + h * HP;
 #pragma unroll
                 for (int e = 0; e < HP; ++e) f[e] = fmaf((f[e] - mean) * rstd, gam[k0 + e], bet[k0 + e]);
-                a[t] = MM::pack(f);
+                a[t] = MM::pack_op(f);
               }
           }
         } else if (p.in_act) {
@@ -371,8 +380,15 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
               MM::unpack(a[t], f);
 #pragma unroll
               for (int e = 0; e < HP; ++e) f[e] = apply_act<BF>(f[e], p.in_act);
-              a[t] = MM::pack(f);
+              a[t] = MM::pack_op(f);
             }
+        }
+      }
+      if constexpr (MM::SPLIT) {   // (the LayerNorm / activation passes above leave operands already)
+        if (!(MODE == MODE_FWD && (has_ln || p.in_act))) {
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) a[t] = MM::op(a[t]);
         }
       }
       for (int ct = 0; ct < ((RDST_DBGV(p.dbg) & 4) ? 0 : nct); ++ct) {
@@ -392,7 +408,8 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
         for (int t = 0; t < TMAX; ++t)
           if (t < Tn) {
             const Pack16 wa = *reinterpret_cast<const Pack16*>(wrow + t * 32);
-            MM::mma(acc, wa, a[t]);   // rows = output columns, cols = tokens
+            if constexpr (TMAX > 16) MM::mma_da(acc, wa, a[t]);   // (split mode: the duplicated halves of 32 fragments would not fit)
+            else MM::mma(acc, wa, a[t]);   // rows = output columns, cols = tokens
           }
         // epilogue: two pairs of register groups -> two runs of 8 consecutive columns of the lane's row
 #pragma unroll
@@ -736,6 +753,8 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
 #define RDST_LIN_LAUNCH(TM)                                                                                          \
   {                                                                                                                  \
     auto kern = lin_mfma_kernel<T, TM, MODE>;                                                                        \
+    if constexpr (sizeof(T) == 4)                                                                                    \
+      if (rdst_split()) kern = lin_mfma_kernel<T, TM, MODE, true>;                                                   \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);                                          \
   }
@@ -770,10 +789,10 @@ int launch_lin(LinArgs<T>& p, hipStream_t st, const char* what) {
 //   dX = rstd * (gamma dA - s1/K - xhat s2/K) (+ dX_add)
 // leaves as 16-B row stores.  No LDS bounce, no second pass over the MFMAs.  dY streams in coalesced
 // 128-B column chunks through the wave's LDS tile (next chunk prefetched while this one is multiplied).
-template <typename T, int NCT>
+template <typename T, int NCT, bool SP = false>
 __global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int ABUF_LD = 144;
@@ -808,6 +827,15 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T>
   stage_scatter<T>(p.Wt, p.N, K, (int64_t)K, tid, 512, Ws, [&](int n, int k) { return k * p.ldw + n * (int)sizeof(T); });
   for (int i = tid; i < kpad; i += 512) gamL[i] = i < K ? p.gamma[i] : 0.f;
   __syncthreads();
+  if constexpr (MM::SPLIT) {   // the scattered image holds floats: split it in place, pack by pack
+    const int ppr = 2 * Tn;
+    for (int i = tid; i < kpad * ppr; i += 512) {
+      const int k = i / ppr, ph = i - k * ppr;
+      Pack16* q = reinterpret_cast<Pack16*>(Ws + (size_t)k * p.ldw + ph * 16);
+      *q = MM::op(*q);
+    }
+    __syncthreads();
+  }
   const float invK = 1.0f / (float)K;
 
   for (int64_t slab = slab0; slab < nslabs; slab += sstep) {
@@ -845,6 +873,7 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T>
               a = MM::pack(f);
             }
           }
+          a = MM::op(a);
 #pragma unroll
           for (int c = 0; c < NCT; ++c) {
             const Pack16 wa = *reinterpret_cast<const Pack16*>(Ws + (size_t)(c * 32 + r) * p.ldw + t * 32 + h * 16);
@@ -981,10 +1010,14 @@ struct WgradArgs {
 //     4 x-hat = (x - mean) * rstd only (the affine part and d(gamma)/d(beta) are finished by the reduction)
 // SZ: staging-plan size — 0: up to 384 x 256 columns, 2 stripes in flight; 1: N <= 256, K+1 <= 128, 3 stripes;
 //     2: N <= 128, K+1 <= 128, 5 stripes (narrow layers are bound by bytes in flight, not by bandwidth)
-template <typename T, int PFX, int XF, int SZ = 0>
+// SP (fp32 rows only): the split arithmetic of RDST_F32X3.  stash() splits every staged pack into its bf16 hi and lo terms and
+// keeps them as two bf16 planes of the tile row ([hi: 32 NT][lo: 32 NT] elements), so multiply() reads both operands TRANSPOSED
+// with ds_read_b64_tr_b16 like the bf16 kernel: a k-step is 8 tokens (4 per lane half: hi in slots 0-3, lo in 4-7), two MFMAs.
+template <typename T, int PFX, int XF, int SZ = 0, bool SP = false>
 __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;
+  constexpr bool SPL = MM::SPLIT;
   constexpr int HP = MM::HP;
   constexpr int ES = (int)sizeof(T);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
@@ -1028,7 +1061,7 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
     const int row = idx / npk, pk = idx - row * npk;
     int k0 = pk * HP;
     dy_row[i] = row;
-    dy_lds[i] = row * p.ldn + pk * 16;
+    dy_lds[i] = row * p.ldn + pk * (SPL ? 8 : 16);
     if (k0 >= p.N) k0 = 0;  // slot entirely past the row: any in-row pack will do (feeds unstored rows)
     dy_sh[i] = (k0 + HP > p.N) ? (k0 + HP - p.N) * ES : 0;
     dy_col[i] = k0 * ES - dy_sh[i];
@@ -1039,7 +1072,7 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
     const int row = idx / kpk, pk = idx - row * kpk;
     const int k0 = pk * HP;
     x_row[i] = row;
-    x_lds[i] = WG_STRIPE * p.ldn + row * p.ldk + pk * 16;
+    x_lds[i] = WG_STRIPE * p.ldn + row * p.ldk + pk * (SPL ? 8 : 16);
     x_k0[i] = k0;
     const int kl = k0 < p.K ? k0 : 0;
     x_sh[i] = (kl + HP > p.K) ? (kl + HP - p.K) * ES : 0;
@@ -1096,7 +1129,13 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
       {
         Pack16 q = rdy[set][i];
         if (dy_sh[i]) shift_pack(q, dy_sh[i]);
-        *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
+        if constexpr (SPL) {
+          const Pack16 sp = MM::op(q);
+          *reinterpret_cast<uint2*>(tile + dy_lds[i]) = make_uint2(sp.w[0], sp.w[1]);
+          *reinterpret_cast<uint2*>(tile + dy_lds[i] + p.NT * 64) = make_uint2(sp.w[2], sp.w[3]);
+        } else {
+          *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
+        }
       }
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
@@ -1141,55 +1180,68 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
           }
           q = MM::pack(f);
         }
-        *reinterpret_cast<Pack16*>(tile + x_lds[i]) = q;
+        if constexpr (SPL) {
+          const Pack16 sp = MM::op(q);
+          *reinterpret_cast<uint2*>(tile + x_lds[i]) = make_uint2(sp.w[0], sp.w[1]);
+          *reinterpret_cast<uint2*>(tile + x_lds[i] + p.KT * 64) = make_uint2(sp.w[2], sp.w[3]);
+        } else {
+          *reinterpret_cast<Pack16*>(tile + x_lds[i]) = q;
+        }
       }
   };
   // per-wave tile list and per-lane fragment offsets (loop invariant)
   int tA[WG_MAXT], tB[WG_MAXT];
   {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int laneA = sizeof(T) == 2 ? (8 * h + q) * p.ldn + (16 * (g & 1) + 4 * pp) * 2 : h * p.ldn + r * 4;
-    const int laneB = sizeof(T) == 2 ? (8 * h + q) * p.ldk + (16 * (g & 1) + 4 * pp) * 2 : h * p.ldk + r * 4;
+    constexpr bool TR = sizeof(T) == 2 || SPL;       // transposed 16-bit reads
+    constexpr int RH = SPL ? 4 : 8;                  // token rows per lane half and k-step
+    const int laneA = TR ? (RH * h + q) * p.ldn + (16 * (g & 1) + 4 * pp) * 2 : h * p.ldn + r * 4;
+    const int laneB = TR ? (RH * h + q) * p.ldk + (16 * (g & 1) + 4 * pp) * 2 : h * p.ldk + r * 4;
 #pragma unroll
     for (int j = 0; j < WG_MAXT; ++j) {
       const int ti = wave + WG_WAVES * j;
       const int nt = ti / p.KT, kt = ti - nt * p.KT;
-      tA[j] = laneA + nt * 32 * ES;
-      tB[j] = WG_STRIPE * p.ldn + laneB + kt * 32 * ES;
+      tA[j] = laneA + nt * 32 * (TR ? 2 : ES);
+      tB[j] = WG_STRIPE * p.ldn + laneB + kt * 32 * (TR ? 2 : ES);
     }
   }
   // number of tiles of this wave (tiles wave, wave+8, ...): a wave-uniform count keeps the tile guards scalar
   const int my_tiles = __builtin_amdgcn_readfirstlane(ntiles > wave ? (ntiles - wave + WG_WAVES - 1) / WG_WAVES : 0);
   auto multiply = [&](int b) {
     const char* tile = smem + b * buf_bytes;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 || SPL) {
       // transposed fragment reads (a 16-lane group covers 16 columns, 4 token rows per read), software
       // pipelined: the next tile's fragments are in flight while this tile's MFMAs issue
+      // (split mode: the second read of a pack is the SAME 4 token rows in the lo plane, a k-step is 8 rows)
       typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-      constexpr int NMS = WG_STRIPE / 16;
-      Pack16 fa[2][NMS], fb[2][NMS];
+      constexpr int KR = SPL ? 8 : 16;
+      constexpr int NMS = WG_STRIPE / KR;
+      const int offA = SPL ? p.NT * 64 : 4 * p.ldn, offB = SPL ? p.KT * 64 : 4 * p.ldk;
+      constexpr int NB = SPL ? 1 : 2;   // (split mode: 4 k-steps per stripe — a second fragment set would not fit the registers)
+      Pack16 fa[NB][NMS], fb[NB][NMS];
       auto frags = [&](int j, Pack16 (&A)[NMS], Pack16 (&B)[NMS]) {
 #pragma unroll
         for (int ms = 0; ms < NMS; ++ms) {
-          const char* ta = tile + ms * 16 * p.ldn;  // wave uniform
-          const char* tb = tile + ms * 16 * p.ldk;
+          const char* ta = tile + ms * KR * p.ldn;  // wave uniform
+          const char* tb = tile + ms * KR * p.ldk;
           const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + tA[j]));
-          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + 4 * p.ldn + tA[j]));
+          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + offA + tA[j]));
           const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + tB[j]));
-          const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + 4 * p.ldk + tB[j]));
+          const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + offB + tB[j]));
           const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
           const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
           A[ms].w[0] = ua0.x; A[ms].w[1] = ua0.y; A[ms].w[2] = ua1.x; A[ms].w[3] = ua1.y;
           B[ms].w[0] = ub0.x; B[ms].w[1] = ub0.y; B[ms].w[2] = ub1.x; B[ms].w[3] = ub1.y;
         }
       };
-      if (my_tiles > 0) frags(0, fa[0], fb[0]);
+      if (NB == 2 && my_tiles > 0) frags(0, fa[0], fb[0]);
 #pragma unroll
       for (int j = 0; j < WG_MAXT; ++j) {
         if (j < my_tiles) {
-          if (j + 1 < WG_MAXT && j + 1 < my_tiles) frags(j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+          if (NB == 1) frags(j, fa[0], fb[0]);
+          else if (j + 1 < WG_MAXT && j + 1 < my_tiles) frags(j + 1, fa[(j + 1) & (NB - 1)], fb[(j + 1) & (NB - 1)]);
 #pragma unroll
-          for (int ms = 0; ms < NMS; ++ms) MM::mma(acc[j], fa[j & 1][ms], fb[j & 1][ms]);
+          for (int ms = 0; ms < NMS; ++ms) MM::mma(acc[j], fa[j & (NB - 1)][ms], fb[j & (NB - 1)][ms]);
         }
       }
     } else {
@@ -1352,9 +1404,11 @@ int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, co
   // LDS row strides: bf16 rows are read by ds_read_b64_tr_b16 (4 token rows x 64 B per 32 lanes):
   // stride = 64 (mod 256) bytes puts the 4 rows on disjoint bank ranges; fp32 rows are read 32
   // consecutive floats at a time, any stride works.
-  auto stride = [](int elems) {
+  bool split = false;
+  if constexpr (sizeof(T) == 4) split = rdst_split();
+  auto stride = [split](int elems) {   // (split mode: two bf16 planes in the bytes of the fp32 row, read like bf16 rows)
     const int b = elems * (int)sizeof(T);
-    if (sizeof(T) == 4) return b;
+    if (sizeof(T) == 4 && !split) return b;
     return b <= 64 ? 64 : ((b - 64 + 255) / 256) * 256 + 64;
   };
   p.ldn = stride(p.NT * 32);
@@ -1373,6 +1427,8 @@ int wgrad_impl(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, co
   {                                                                                                                  \
     auto kern = sz == 2 ? lin_wgrad_mfma_kernel<T, PF, XF, 2> : sz == 1 ? lin_wgrad_mfma_kernel<T, PF, XF, 1>        \
                                                                          : lin_wgrad_mfma_kernel<T, PF, XF, 0>;      \
+    if constexpr (sizeof(T) == 4)                                                                                    \
+      if (split) kern = lin_wgrad_mfma_kernel<T, PF, XF, 0, true>;                                                   \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WG_THREADS), smem, st, p);                                    \
   }
@@ -1438,6 +1494,8 @@ int linear_dgrad_ln2_mfma(const T* X, int64_t ldx, const float* stats, const flo
 #define RDST_LND2_LAUNCH(NC)                                                                                          \
   {                                                                                                                  \
     auto kern = lin_dgrad_ln2_kernel<T, NC>;                                                                         \
+    if constexpr (sizeof(T) == 4)                                                                                    \
+      if (rdst_split()) kern = lin_dgrad_ln2_kernel<T, NC, true>;                                                    \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);                                          \
   }

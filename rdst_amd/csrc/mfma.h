@@ -33,16 +33,24 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <typename E> struct Mma;
+// SP (float only): the SPLIT arithmetic of the RDST_F32X3 mode — fp32 rows in memory, a matrix operand is a pack of
+// [4 bf16 hi | 4 bf16 lo] (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits, same 16 bytes as the 4 floats); see Mma<float, true>.
+// pack() / unpack() always speak the MEMORY format; op() turns a memory pack into an MFMA operand (identity without SP),
+// pack_op() = op(pack()).  Every operand of mma() must have gone through op() / pack_op() exactly once.
+template <typename E, bool SP = false> struct Mma;
 
-template <> struct Mma<float> {
+template <> struct Mma<float, false> {
   static constexpr int KP = 8;  // k elements per k-step (both lane halves)
   static constexpr int HP = 4;  // elements per lane pack
+  static constexpr bool SPLIT = false;
+  static __device__ __forceinline__ Pack16 op(const Pack16& p) { return p; }
+  static __device__ __forceinline__ Pack16 pack_op(const float* f) { return pack(f); }
   static __device__ __forceinline__ void mma(f32x16& acc, const Pack16& a, const Pack16& b) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w[e]), __uint_as_float(b.w[e]), acc, 0, 0, 0);
   }
+  static __device__ __forceinline__ void mma_da(f32x16& acc, const Pack16& a, const Pack16& b) { mma(acc, a, b); }
   static __device__ __forceinline__ void unpack(const Pack16& p, float* f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) f[e] = __uint_as_float(p.w[e]);
@@ -55,13 +63,17 @@ template <> struct Mma<float> {
   }
 };
 
-template <> struct Mma<bf16> {
+template <> struct Mma<bf16, false> {
   static constexpr int KP = 16;
   static constexpr int HP = 8;
+  static constexpr bool SPLIT = false;
+  static __device__ __forceinline__ Pack16 op(const Pack16& p) { return p; }
+  static __device__ __forceinline__ Pack16 pack_op(const float* f) { return pack(f); }
   static __device__ __forceinline__ void mma(f32x16& acc, const Pack16& a, const Pack16& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
                                                   0, 0, 0);
   }
+  static __device__ __forceinline__ void mma_da(f32x16& acc, const Pack16& a, const Pack16& b) { mma(acc, a, b); }
   static __device__ __forceinline__ void unpack(const Pack16& p, float* f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -74,6 +86,43 @@ template <> struct Mma<bf16> {
 #pragma unroll
     for (int e = 0; e < 4; ++e) p.w[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
     return p;
+  }
+};
+
+// RDST_F32X3 on the network's GEMMs.  With A = [a_hi | a_lo] in the 8 k-slots of a lane and B = [b_hi | b_hi] resp. [b_lo | b_lo],
+// two v_mfma_f32_32x32x16_bf16 add up all four partial products (a_hi + a_lo)(b_hi + b_lo) of 4 k per lane half, i.e. the
+// 8 k of one fp32 k-step: 64 cycles of the matrix pipe where 4 x v_mfma_f32_32x32x2_f32 take 256.  The only error is the
+// 16-bit representation of each operand (<= 2^-17 relative, against 2^-9 of a bf16 operand); accumulation stays fp32.
+__device__ __forceinline__ Pack16 split_pack4(const float* f) {
+  Pack16 p;
+  p.w[0] = pack_bf16x2(f[0], f[1]);
+  p.w[1] = pack_bf16x2(f[2], f[3]);
+  p.w[2] = pack_bf16x2(f[0] - bf16lo(p.w[0]), f[1] - bf16hi(p.w[0]));
+  p.w[3] = pack_bf16x2(f[2] - bf16lo(p.w[1]), f[3] - bf16hi(p.w[1]));
+  return p;
+}
+template <> struct Mma<float, true> : Mma<float, false> {
+  static constexpr bool SPLIT = true;
+  static __device__ __forceinline__ Pack16 op(const Pack16& p) {
+    float f[4];
+    unpack(p, f);
+    return split_pack4(f);
+  }
+  static __device__ __forceinline__ Pack16 pack_op(const float* f) { return split_pack4(f); }
+  static __device__ __forceinline__ void mma(f32x16& acc, const Pack16& a, const Pack16& b) {
+    Pack16 bh, bl;
+    bh.w[0] = b.w[0]; bh.w[1] = b.w[1]; bh.w[2] = b.w[0]; bh.w[3] = b.w[1];
+    bl.w[0] = b.w[2]; bl.w[1] = b.w[3]; bl.w[2] = b.w[2]; bl.w[3] = b.w[3];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bl), acc, 0, 0, 0);
+  }
+  // the same with the FIRST operand duplicated (for call sites whose second operand is the one re-read per tile)
+  static __device__ __forceinline__ void mma_da(f32x16& acc, const Pack16& a, const Pack16& b) {
+    Pack16 ah, al;
+    ah.w[0] = a.w[0]; ah.w[1] = a.w[1]; ah.w[2] = a.w[0]; ah.w[3] = a.w[1];
+    al.w[0] = a.w[2]; al.w[1] = a.w[3]; al.w[2] = a.w[2]; al.w[3] = a.w[3];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
   }
 };
 

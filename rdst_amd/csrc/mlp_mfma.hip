@@ -1234,6 +1234,7 @@ int wgrad_ln_finish_launch(const float* G, const float* Wt, const float* ln_w, c
                            float* dW, float* dbias, float* dln_w, float* dln_b, hipStream_t st);
 
 extern "C" int rdst_mlp_fused_supported(int C, int hid, int dtype) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   static int off = -1;
   if (off < 0) {
     const char* e = rdst_dbg_getenv("RDST_MLP_V1");
@@ -1253,6 +1254,7 @@ extern "C" int rdst_mlp_bwd(const void* X, int64_t ld_x, const float* ln_w, cons
                             const float* W1, const float* b1, const float* W2, const void* dY, int64_t ld_dy, void* dX,
                             int64_t ld_dx, float* dW1, float* db1, float* dW2, float* db2, float* dln_w, float* dln_b,
                             void* workspace, size_t workspace_bytes, int64_t M, int C, int hid, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (!X || !ln_w || !ln_b || !stats || !W1 || !W2 || !dY || !dX || !dW1 || !db1 || !dW2 || !db2 || !dln_w || !dln_b || !workspace)
     return rdst_fail(RDST_EINVAL, "rdst_mlp_bwd: null pointer");
   if (M < 0 || C <= 0 || hid <= 0 || ld_x < C || ld_dy < C || ld_dx < C) return rdst_fail(RDST_EINVAL, "rdst_mlp_bwd: bad dimensions");
@@ -1334,12 +1336,14 @@ extern "C" size_t rdst_mlp_fwd_workspace(int C, int hid) {
   return mlp3_pack_bytes(C, hid);
 }
 extern "C" int rdst_mlp_fwd_packable(int C, int hid, int dtype) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   return dtype == RDST_BF16 && hid == 2 * C && (C == 60 || C == 90 || C == 120);
 }
 
 extern "C" int rdst_mlp_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, const float* W1, const float* b1,
                             const float* W2, const float* b2, void* Y, int64_t ld_y, float* stats, void* workspace,
                             size_t workspace_bytes, int64_t M, int C, int hid, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (!X || !ln_w || !ln_b || !W1 || !W2 || !Y || !stats) return rdst_fail(RDST_EINVAL, "rdst_mlp_fwd: null pointer");
   if (M < 0 || C <= 0 || hid <= 0 || ld_x < C || ld_y < C) return rdst_fail(RDST_EINVAL, "rdst_mlp_fwd: bad dimensions");
   if (!rdst_mlp_fused_supported(C, hid, dtype)) return RDST_ENOTSUP;

@@ -75,6 +75,7 @@ int check(const char* who, const void* a, const void* b, int64_t lda, int64_t ld
 
 extern "C" int rdst_upsample2_fwd(const void* x, int64_t ld_x, void* y, int64_t ld_y, int B, int H, int W, int C, int dtype,
                                   void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (int rc = check("rdst_upsample2_fwd", x, y, ld_x, ld_y, B, H, W, C, dtype)) return rc;
   return dtype == RDST_F32 ? launch<float>(true, x, ld_x, y, ld_y, B, H, W, C, (hipStream_t)stream)
                            : launch<bf16>(true, x, ld_x, y, ld_y, B, H, W, C, (hipStream_t)stream);
@@ -82,6 +83,7 @@ extern "C" int rdst_upsample2_fwd(const void* x, int64_t ld_x, void* y, int64_t 
 
 extern "C" int rdst_upsample2_bwd(const void* dy, int64_t ld_dy, void* dx, int64_t ld_dx, int B, int H, int W, int C, int dtype,
                                   void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   if (int rc = check("rdst_upsample2_bwd", dy, dx, ld_dy, ld_dx, B, H, W, C, dtype)) return rc;
   return dtype == RDST_F32 ? launch<float>(false, dy, ld_dy, dx, ld_dx, B, H, W, C, (hipStream_t)stream)
                            : launch<bf16>(false, dy, ld_dy, dx, ld_dx, B, H, W, C, (hipStream_t)stream);

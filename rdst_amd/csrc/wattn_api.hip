@@ -4,6 +4,7 @@
 #include "reduce_batch.h"
 
 thread_local char g_rdst_err[256] = {0};
+thread_local int g_rdst_split = 0;
 
 extern "C" int rdst_abi_version(void) { return 10; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
@@ -31,6 +32,7 @@ int make_geom(WinGeom& g, int B, int H, int W, int C, int heads, int ws, int shi
 extern "C" int rdst_wattn_fwd(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
                               void* out, int64_t ld_out, int B, int H, int W, int C, int heads, int ws, int shift,
                               float scale, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_fwd")) return rc;
   if (!qkv || !table || !out) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd: null pointer");
@@ -53,6 +55,7 @@ extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* tabl
                               const void* dout, int64_t ld_dout, void* dqkv, int64_t ld_dqkv, float* dtable,
                               void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
                               int shift, float scale, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_bwd")) return rc;
   if (!qkv || !table || !dout || !dqkv || !dtable || !workspace)
@@ -81,6 +84,7 @@ extern "C" int rdst_wattn_bwd(const void* qkv, int64_t ld_qkv, const float* tabl
 
 // ---- K8: the attention half of a Swin block in one launch (swinattn_fwd.hip) ---------------------------------------------------
 extern "C" int rdst_swin_attn_fwd_supported(int C, int heads, int ws, int dtype) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   return (dtype == RDST_BF16 && swinattn_supported(C, heads, ws)) ? 1 : 0;
 }
 extern "C" size_t rdst_swin_attn_fwd_workspace(int C) { return C > 0 ? swinattn_pack_bytes(C) : 0; }
@@ -89,6 +93,7 @@ extern "C" int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w
                                   int64_t ld_qkv, void* a, int64_t ld_a, void* x1, int64_t ld_x1, float* stats, void* workspace,
                                   size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws, int shift, float scale,
                                   int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, nullptr, 0, "rdst_swin_attn_fwd")) return rc;
   if (!X || !ln_w || !ln_b || !Wqkv || !table || !Wproj || !qkv || !a || !x1 || !stats || !workspace)
@@ -108,6 +113,7 @@ extern "C" int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w
 // serve with other kernels: the caller then uses rdst_wattn_fwd / rdst_wattn_bwd.
 extern "C" int rdst_wattn_fwd_lse(const void* qkv, int64_t ld_qkv, const float* table, void* out, int64_t ld_out, float* nlse,
                                   int B, int H, int W, int C, int heads, int ws, int shift, float scale, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, nullptr, 0, "rdst_wattn_fwd_lse")) return rc;
   if (!qkv || !table || !out || !nlse) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_lse: null pointer");
@@ -120,6 +126,7 @@ extern "C" int rdst_wattn_bwd_lse(const void* qkv, int64_t ld_qkv, const float* 
                                   const void* out, int64_t ld_out, const float* nlse, void* dqkv, int64_t ld_dqkv, float* dtable,
                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
                                   int shift, float scale, int dtype, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, nullptr, 0, "rdst_wattn_bwd_lse")) return rc;
   if (!qkv || !table || !dout || !out || !nlse || !dqkv || !dtable || !workspace)
@@ -157,6 +164,7 @@ int drop_args(WinGeom& g, float attn_drop, const unsigned long long* seed, const
 extern "C" int rdst_wattn_fwd_drop(const void* qkv, int64_t ld_qkv, const float* table, const float* mask, int mask_nw,
                                    void* out, int64_t ld_out, int B, int H, int W, int C, int heads, int ws, int shift,
                                    float scale, int dtype, float attn_drop, const unsigned long long* seed, void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_fwd_drop")) return rc;
   if (!qkv || !table || !out) return rdst_fail(RDST_EINVAL, "rdst_wattn_fwd_drop: null pointer");
@@ -171,6 +179,7 @@ extern "C" int rdst_wattn_bwd_drop(const void* qkv, int64_t ld_qkv, const float*
                                    void* workspace, size_t workspace_bytes, int B, int H, int W, int C, int heads, int ws,
                                    int shift, float scale, int dtype, float attn_drop, const unsigned long long* seed,
                                    void* stream) {
+  SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
   WinGeom g;
   if (int rc = make_geom(g, B, H, W, C, heads, ws, shift, mask, mask_nw, "rdst_wattn_bwd_drop")) return rc;
   if (!qkv || !table || !dout || !dqkv || !dtable || !workspace)

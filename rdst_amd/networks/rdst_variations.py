@@ -337,8 +337,16 @@ class RDSTSR(nn.Module):
     def set_compute_dtype(self, dtype):
         """torch.float32 = parity mode (default); torch.bfloat16 = throughput mode (bf16 activations,
         fp32 accumulation, fp32 parameters and gradients)."""
+        if dtype == "fp32x3":      # fp32 tensors, split-bf16 GEMMs (ops.F32_SPLIT: a per-process switch)
+            ops.set_f32_split(True)
+            dtype = torch.float32
+        elif dtype in ("fp32", torch.float32):
+            ops.set_f32_split(False)
+            dtype = torch.float32
+        elif dtype == "bf16":
+            dtype = torch.bfloat16
         if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+            raise ValueError("compute dtype must be torch.float32 ('fp32'), 'fp32x3' or torch.bfloat16 ('bf16')")
         self.compute_dtype = dtype
         return self
 

@@ -532,6 +532,14 @@ class SwinIR(nn.Module):
         return {'relative_position_bias_table'}
 
     def set_compute_dtype(self, dtype):
+        if dtype == "fp32x3":      # fp32 tensors, split-bf16 GEMMs (ops.F32_SPLIT: a per-process switch)
+            ops.set_f32_split(True)
+            dtype = torch.float32
+        elif dtype in ("fp32", torch.float32):
+            ops.set_f32_split(False)
+            dtype = torch.float32
+        elif dtype == "bf16":
+            dtype = torch.bfloat16
         self.compute_dtype = dtype
         return self
 

@@ -22,9 +22,21 @@ from . import _lib
 from ._lib import ACT_GELU, ACT_LEAKY001, ACT_LEAKY02, ACT_NONE, BF16, F32  # noqa: F401
 
 
+# The "fp32x3" compute mode (set_compute_dtype("fp32x3") on a network): fp32 tensors everywhere, but the GEMM-shaped kernels
+# take their operands as two bf16 terms (16 mantissa bits) and run on the bf16 matrix cores (RDST_F32X3, csrc/mfma.h:
+# Mma<float, true>) — the parity mode that holds the 4-decimal PSNR bar at a third of the exact-fp32 cost.  The switch is
+# per process (the mode of a step must not change between its forward and its backward); F32_SPLIT = False is exact fp32.
+F32_SPLIT = False
+
+
+def set_f32_split(on: bool) -> None:
+    global F32_SPLIT
+    F32_SPLIT = bool(on)
+
+
 def _dtype_code(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
-        return F32
+        return _lib.F32X3 if F32_SPLIT else F32
     if t.dtype == torch.bfloat16:
         return BF16
     raise TypeError(f"rdst_amd: unsupported activation dtype {t.dtype} (float32 or bfloat16)")

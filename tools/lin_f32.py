@@ -5,6 +5,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rdst_amd import ops
 dev = torch.device("cuda:0"); M = 131072; dt = torch.float32
+ops.set_f32_split(len(sys.argv) > 1 and sys.argv[1] == "x3")   # python tools/lin_f32.py x3: the split-bf16 arithmetic
 
 
 def timed(fn, n=6):
