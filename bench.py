@@ -28,6 +28,7 @@ Extra objects on the line (N = 1, rank 0):
   kernels      — the six most expensive C-ABI ops of the step: launches, average us, algorithmic bytes / FLOPs,
                  fraction of the bounding peak, all measured live by the same replay.
   fp32_mode    — throughput of the fp32 parity mode (the mode that carries the 4-decimal PSNR claim).
+  parity_mode  — the same step in the fp32x3 mode (fp32 tensors, split-bf16 GEMMs): the fast mode that holds the 4-decimal bar.
   cpu_baseline — the CPU oracle (oracle/rdst_oracle.py, a port) timed on the host cores on a bounded
                  sample (batch 4) of the same workload.
   configs      — (default run only: --config e1, N = 1) the OTHER BASELINE.json configurations on the same line, 5 timed
@@ -514,6 +515,10 @@ def main():
                 out["fp32_mode"] = fp32_line(device, x, tgt, B, lib)
             except Exception as e:  # noqa: BLE001
                 out["fp32_mode"] = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
+            try:   # the fast parity mode: fp32 tensors, split-bf16 GEMMs (tests/test_fp32x3_gpu.py holds its |dPSNR| < 5e-5 assert)
+                out["parity_mode"] = fp32_line(device, x, tgt, B, lib, split=True)
+            except Exception as e:  # noqa: BLE001
+                out["parity_mode"] = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
         if want_configs:
             tr = net = bucket = loss_obj = None
             rec.calls = recorded = []
@@ -622,10 +627,19 @@ def _fp32_step_line(device, cfg, x, tgt, B, steps):
             "hip_graph": bool(ok), "dtype": "fp32", "loss": round(float(t32._loss_buf.item()), 6)}
 
 
-def fp32_line(device, x, tgt, B, lib):
-    """The same step in the fp32 parity mode, graph-captured like the bf16 one, with its own per-op table."""
+def fp32_line(device, x, tgt, B, lib, split=False):
+    """The same step in the fp32 parity mode (split: the fp32x3 mode), graph-captured like the bf16 one, with its own per-op table."""
+    from rdst_amd import ops
     from rdst_amd.trainer import DPTrainStep
-    net32 = build_net(device, torch.float32)
+    net32 = build_net(device, "fp32x3" if split else torch.float32)
+    try:
+        return _fp32_line(device, x, tgt, B, lib, split, net32)
+    finally:
+        ops.set_f32_split(False)
+
+
+def _fp32_line(device, x, tgt, B, lib, split, net32):
+    from rdst_amd.trainer import DPTrainStep
     t32 = DPTrainStep(net32, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0, graph=False)
     for _ in range(2):
         t32.step(x, tgt)
@@ -645,10 +659,14 @@ def fp32_line(device, x, tgt, B, lib):
     torch.cuda.synchronize()
     d32 = (time.perf_counter() - t0) / n
     line = {"value": round(B / d32, 3), "unit": "patches/s", "ms_per_step": round(1e3 * d32, 3), "steps": n,
-            "hip_graph": t32.graph is not None,
-            "note": "fp32 activations + exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode, same step and graph capture as the bf16 line"}
+            "hip_graph": t32.graph is not None, "dtype": "fp32x3" if split else "fp32",
+            "note": ("fp32 activations, every GEMM operand as two bf16 terms (16 mantissa bits) on v_mfma_f32_32x32x16_bf16, fp32 "
+                     "accumulation, softmax / LayerNorm / GELU in fp32: |dPSNR| vs the oracle 3e-6 dB at this shape "
+                     "(tests/test_fp32x3_gpu.py asserts < 5e-5), same step and graph capture as the bf16 line") if split else
+                    "fp32 activations + exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): the parity mode, same step and graph capture as the bf16 line"}
     if t32.graph is not None and rec.calls:
-        tab = _op_table(lib, rec.calls, 4, 2, MFMA_PEAK_TFLOPS["fp32"] * 1e12)
+        # (split: two bf16 MFMAs per fp32 product -> half the dense bf16 peak is this mode's matrix-core ceiling)
+        tab = _op_table(lib, rec.calls, 4, 2, (MFMA_PEAK_TFLOPS["bf16"] / 2 if split else MFMA_PEAK_TFLOPS["fp32"]) * 1e12)
         line["kernels"] = tab[:6]
     return line
 

@@ -12,8 +12,11 @@
  *     calls are graph-capturable and re-entrant across streams;
  *   - activations are token-major rows: element (row, c) lives at base[row*ld + c], `ld` in
  *     ELEMENTS (this is how the dense concat buffer of an RDSTB is addressed in place);
- *   - `dtype` selects the activation element type: RDST_F32 (parity mode, fp32 I/O and math) or
- *     RDST_BF16 (throughput mode: bf16 I/O, fp32 accumulation).  Parameters and parameter
+ *   - `dtype` selects the activation element type: RDST_F32 (parity mode, fp32 I/O and math),
+ *     RDST_BF16 (throughput mode: bf16 I/O, fp32 accumulation) or RDST_F32X3 (fast parity mode: fp32
+ *     I/O exactly as RDST_F32, but every GEMM-shaped product takes its operands as TWO bf16 terms —
+ *     16 mantissa bits — on the bf16 matrix cores with fp32 accumulation; LayerNorm, softmax, GELU and
+ *     every sum stay fp32; entry points without GEMMs treat it as RDST_F32).  Parameters and parameter
  *     gradients are ALWAYS fp32;
  *   - return value: 0 on success, a negative hipError_t from the launch, or RDST_EINVAL /
  *     RDST_ENOTSUP for bad or unsupported arguments.  Never throws.  rdst_last_error() returns a
@@ -31,8 +34,9 @@ extern "C" {
 
 #define RDST_F32 0
 #define RDST_BF16 1
-#define RDST_F32X3 2   /* rdst_u_* only: fp32 rows; convolutions as a 3-term bf16 split (hi.hi + hi.lo + lo.hi) on the matrix
-                          cores, ~1e-5 relative; every other rdst_u_* entry point treats it as RDST_F32 */
+#define RDST_F32X3 2   /* fp32 rows, split-bf16 products (~4e-6 relative per product): the network entry points (rdst_ln_linear_*,
+                          rdst_wattn_* with 8x8 windows, rdst_conv_*) run all four partial products of (a_hi + a_lo)(b_hi + b_lo) in two
+                          v_mfma_f32_32x32x16_bf16; rdst_u_conv runs three (hi.hi + hi.lo + lo.hi, ~1e-5); everything else = RDST_F32 */
 
 #define RDST_EINVAL (-10001)
 #define RDST_ENOTSUP (-10002)

@@ -51,10 +51,10 @@ struct ConvArgs {
   int dbg;   // RDST_CONV_DEBUG ablation: 1 skip tile loads, 2 skip MFMAs, 4 skip stores, 8 skip the slab loop
 };
 
-template <typename T, int TMAX, int MODE>
+template <typename T, int TMAX, int MODE, bool SP = false>
 __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;   // SP: RDST_F32X3 (mfma.h) — weights split as they are staged, a pixel row's fragments once per tap
   constexpr int KP = MM::KP, HP = MM::HP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int Tn = p.Tn;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
     const int nc = (p.Nout - n0 < p.nch) ? p.Nout - n0 : p.nch;
     const int ncp = ((nc + 31) / 32) * 32;
     // stage W[tap][col][ci-pack] for this chunk
-    stage_packs_batched<T, 4>(ntap * ncp * 2 * Tn, p.CA, MODE == CMODE_FWD ? (int64_t)ntap : (int64_t)g.Cin * ntap, tid, 512,
+    stage_packs_batched<T, 4, SP>(ntap * ncp * 2 * Tn, p.CA, MODE == CMODE_FWD ? (int64_t)ntap : (int64_t)g.Cin * ntap, tid, 512,
                               [&](int idx, const float*& src, int& k0, char*& dst, bool& ok) {
                                 const int ph = idx % (2 * Tn);
                                 const int rest = idx / (2 * Tn);
@@ -116,6 +116,11 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
               a[t] = MM::pack(f);
             }
         }
+        if constexpr (MM::SPLIT) {
+#pragma unroll
+          for (int t = 0; t < TMAX; ++t)
+            if (t < Tn) a[t] = MM::op(a[t]);
+        }
         const char* wtap = smem + ((size_t)tap * ncp + r) * p.ldw + h * 16;
 #pragma unroll
         for (int c = 0; c < CV_MAXCT; ++c)
@@ -125,7 +130,7 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
             for (int t = 0; t < TMAX; ++t)
               if (t < Tn) {
                 const Pack16 bb = *reinterpret_cast<const Pack16*>(wrow + t * 32);
-                MM::mma(acc[c], a[t], bb);
+                MM::mma_da(acc[c], a[t], bb);   // (split mode: the pixel fragment is the one kept across the column tiles)
               }
           }
       }
@@ -188,10 +193,10 @@ __global__ void __launch_bounds__(512) conv_mfma_kernel(const ConvArgs<T> p) {
 // PixelShuffle(2) the four sub-pixels of a lane are 8-B runs of 4 consecutive output channels.
 // The next tile's chunks are prefetched while the current one is multiplied.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE, int PF>
+template <typename T, int MODE, int PF, bool SP = false>
 __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;   // SP: RDST_F32X3 — the scattered weight image is split in place, a tile fragment when it is read
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int TLD = 144;          // tile row: 128 B of the pixel's channels + 16 B pad (odd 16-B slots)
@@ -254,6 +259,16 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
       });
     }
     __syncthreads();
+    if constexpr (MM::SPLIT) {
+      const int ppr = 2 * Tn;
+      for (int i = tid; i < 9 * ncp * ppr; i += 512) {
+        const int ph = i % ppr, rest = i / ppr;
+        const int n = rest % ncp, tap = rest / ncp;
+        Pack16* q = reinterpret_cast<Pack16*>(smem + (size_t)tap * tapst + (size_t)n * p.ldw + ph * 16);
+        *q = MM::op(*q);
+      }
+      __syncthreads();
+    }
     const int nct = ncp / 32;
 
     for (int64_t slab = (int64_t)blockIdx.x * 8 + wave; slab < ((RDST_DBGV(p.dbg) & 8) ? 0 : nslabs); slab += (int64_t)gridDim.x * 8) {
@@ -338,6 +353,7 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
                     a = MM::pack(f);
                   }
                 }
+                a = MM::op(a);
                 const char* wrow = smem + (size_t)tap * tapst + (size_t)r * p.ldw + t * 32 + h * 16;
 #pragma unroll
                 for (int c = 0; c < CV_MAXCT; ++c)
@@ -483,6 +499,8 @@ int launch_conv_rows(ConvArgs<T>& p, hipStream_t st, const char* what) {
   static int pf = -1;
   if (pf < 0) { const char* e = rdst_dbg_getenv("RDST_CONV_PF"); pf = e ? atoi(e) : 3; }
   auto kern = pf == 1 ? conv_rows_kernel<T, MODE, 1> : pf == 2 ? conv_rows_kernel<T, MODE, 2> : conv_rows_kernel<T, MODE, 3>;
+  if constexpr (sizeof(T) == 4)
+    if (rdst_split()) kern = pf == 1 ? conv_rows_kernel<T, MODE, 1, true> : pf == 2 ? conv_rows_kernel<T, MODE, 2, true> : conv_rows_kernel<T, MODE, 3, true>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);
   return rdst_launch_status(what);
@@ -518,6 +536,8 @@ int launch_conv(ConvArgs<T>& p, hipStream_t st, const char* what) {
 #define RDST_CONV_LAUNCH(TM)                                                                                         \
   {                                                                                                                  \
     auto kern = conv_mfma_kernel<T, TM, MODE>;                                                                       \
+    if constexpr (sizeof(T) == 4)                                                                                    \
+      if (rdst_split()) kern = conv_mfma_kernel<T, TM, MODE, true>;                                                  \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), smem, st, p);                                          \
   }
@@ -719,10 +739,13 @@ __global__ void __launch_bounds__(512) conv_wgrad_mfma_kernel(const ConvWgradArg
 // ------------------------------------------------------------------------------------------------
 
 // SL = pixels per stripe (32, or 128 for shapes with at most 2x2 tiles per tap: fewer barriers per byte)
-template <typename T, int PF, int XF, int SL>
+// SP (fp32 rows): RDST_F32X3, as in the Linear weight gradient (linear_mfma.hip): stash() keeps the bf16 hi and lo terms of a
+// staged pack as two planes of the tile row, multiply() reads both operands transposed; a k-step is 8 pixels, two MFMAs.
+template <typename T, int PF, int XF, int SL, bool SP = false>
 __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArgs<T> p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;
+  constexpr bool SPL = MM::SPLIT;
   constexpr int HP = MM::HP;
   constexpr int ES = (int)sizeof(T);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
@@ -752,7 +775,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArg
     const int row = idx / npk, pk = idx - row * npk;
     int k0 = pk * HP;
     dy_row[i] = (!small_n && idx < SL * npk) ? row : -1;
-    dy_lds[i] = row * p.ldn + pk * 16;
+    dy_lds[i] = row * p.ldn + pk * (SPL ? 8 : 16);
     if (k0 >= g.Cout) k0 = 0;
     dy_sh[i] = (k0 + HP > g.Cout) ? (k0 + HP - g.Cout) * ES : 0;
     dy_col[i] = k0 * ES - dy_sh[i];
@@ -763,7 +786,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArg
     const int row = idx / kpk, pk = idx - row * kpk;
     const int k0 = pk * HP;
     x_row[i] = idx < XR * kpk ? row : -1;
-    x_lds[i] = SL * p.ldn + row * p.ldk + pk * 16;
+    x_lds[i] = SL * p.ldn + row * p.ldk + pk * (SPL ? 8 : 16);
     x_k0[i] = k0;
     const int kl = k0 < g.Cin ? k0 : 0;
     x_sh[i] = (kl + HP > g.Cin) ? (kl + HP - g.Cin) * ES : 0;
@@ -839,7 +862,13 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArg
         Pack16 q = rdy[set][i];
         if (dy_sh[i]) shift_pack(q, dy_sh[i]);
         if (dy_row[i] >= s.left) { q.w[0] = 0u; q.w[1] = 0u; q.w[2] = 0u; q.w[3] = 0u; }   // pixels past the range add nothing
-        *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
+        if constexpr (SPL) {
+          const Pack16 sp = MM::op(q);
+          *reinterpret_cast<uint2*>(tile + dy_lds[i]) = make_uint2(sp.w[0], sp.w[1]);
+          *reinterpret_cast<uint2*>(tile + dy_lds[i] + p.NT * 64) = make_uint2(sp.w[2], sp.w[3]);
+        } else {
+          *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
+        }
       }
     if (sm_act) *reinterpret_cast<T*>(tile + sm_row * p.ldn + sm_col * ES) = rsm[set];
 #pragma unroll
@@ -863,23 +892,31 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArg
           }
           q = MM::pack(f);
         }
-        *reinterpret_cast<Pack16*>(tile + x_lds[i]) = q;
+        if constexpr (SPL) {
+          const Pack16 sp = MM::op(q);
+          *reinterpret_cast<uint2*>(tile + x_lds[i]) = make_uint2(sp.w[0], sp.w[1]);
+          *reinterpret_cast<uint2*>(tile + x_lds[i] + p.KT * 64) = make_uint2(sp.w[2], sp.w[3]);
+        } else {
+          *reinterpret_cast<Pack16*>(tile + x_lds[i]) = q;
+        }
       }
   };
   // per-wave tile list and per-lane fragment offsets (loop invariant); tile = (nt, kx, kt)
   int tA[CW_MAXT], tB[CW_MAXT];
   {
     const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int laneA = sizeof(T) == 2 ? (8 * h + q) * p.ldn + (16 * (gq & 1) + 4 * pp) * 2 : h * p.ldn + r * 4;
-    const int laneB = sizeof(T) == 2 ? (8 * h + q) * p.ldk + (16 * (gq & 1) + 4 * pp) * 2 : h * p.ldk + r * 4;
+    constexpr bool TR = sizeof(T) == 2 || SPL;   // transposed 16-bit reads
+    constexpr int RH = SPL ? 4 : 8;              // pixel rows per lane half and k-step
+    const int laneA = TR ? (RH * h + q) * p.ldn + (16 * (gq & 1) + 4 * pp) * 2 : h * p.ldn + r * 4;
+    const int laneB = TR ? (RH * h + q) * p.ldk + (16 * (gq & 1) + 4 * pp) * 2 : h * p.ldk + r * 4;
 #pragma unroll
     for (int j = 0; j < CW_MAXT; ++j) {
       const int ti = wave + 8 * j;
       const int nt = ti / (3 * p.KT);
       const int rem = ti - nt * (3 * p.KT);
       const int kx = rem / p.KT, kt = rem - kx * p.KT;
-      tA[j] = laneA + nt * 32 * ES;
-      tB[j] = SL * p.ldn + laneB + kx * p.ldk + kt * 32 * ES;   // tap = row offset into the 34-row tile
+      tA[j] = laneA + nt * 32 * (TR ? 2 : ES);
+      tB[j] = SL * p.ldn + laneB + kx * p.ldk + kt * 32 * (TR ? 2 : ES);   // tap = row offset into the 34-row tile
     }
   }
   const int my_tiles = __builtin_amdgcn_readfirstlane(ntiles > wave ? (ntiles - wave + 7) / 8 : 0);
@@ -888,32 +925,36 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArg
     for (int sub = 0; sub < SL / 32; ++sub) {
       const char* tile = smem + b * buf_bytes;
       const int offA = sub * 32 * p.ldn, offB = sub * 32 * p.ldk;
-      if constexpr (sizeof(T) == 2) {
+      if constexpr (sizeof(T) == 2 || SPL) {
         typedef __attribute__((address_space(3))) s16x4_t* lds_p;
-        constexpr int NMS = 2;
-        Pack16 fa[2][NMS], fb[2][NMS];
+        constexpr int KR = SPL ? 8 : 16;   // pixel rows per k-step (split mode: the second read is the lo plane of the same rows)
+        constexpr int NMS = 32 / KR;
+        constexpr int NB = SPL ? 1 : 2;
+        const int o2A = SPL ? p.NT * 64 : 4 * p.ldn, o2B = SPL ? p.KT * 64 : 4 * p.ldk;
+        Pack16 fa[NB][NMS], fb[NB][NMS];
         auto frags = [&](int j, Pack16 (&A)[NMS], Pack16 (&B)[NMS]) {
 #pragma unroll
           for (int ms = 0; ms < NMS; ++ms) {
-            const char* ta = tile + offA + ms * 16 * p.ldn;
-            const char* tb = tile + offB + ms * 16 * p.ldk;
+            const char* ta = tile + offA + ms * KR * p.ldn;
+            const char* tb = tile + offB + ms * KR * p.ldk;
             const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + tA[j]));
-            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + 4 * p.ldn + tA[j]));
+            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(ta + o2A + tA[j]));
             const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + tB[j]));
-            const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + 4 * p.ldk + tB[j]));
+            const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tb + o2B + tB[j]));
             const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
             const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
             A[ms].w[0] = ua0.x; A[ms].w[1] = ua0.y; A[ms].w[2] = ua1.x; A[ms].w[3] = ua1.y;
             B[ms].w[0] = ub0.x; B[ms].w[1] = ub0.y; B[ms].w[2] = ub1.x; B[ms].w[3] = ub1.y;
           }
         };
-        if (my_tiles > 0) frags(0, fa[0], fb[0]);
+        if (NB == 2 && my_tiles > 0) frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int j = 0; j < CW_MAXT; ++j) {
           if (j < my_tiles) {
-            if (j + 1 < CW_MAXT && j + 1 < my_tiles) frags(j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+            if (NB == 1) frags(j, fa[0], fb[0]);
+            else if (j + 1 < CW_MAXT && j + 1 < my_tiles) frags(j + 1, fa[(j + 1) & (NB - 1)], fb[(j + 1) & (NB - 1)]);
 #pragma unroll
-            for (int ms = 0; ms < NMS; ++ms) MM::mma(acc[j], fa[j & 1][ms], fb[j & 1][ms]);
+            for (int ms = 0; ms < NMS; ++ms) MM::mma(acc[j], fa[j & (NB - 1)][ms], fb[j & (NB - 1)][ms]);
           }
         }
       } else {
@@ -1094,9 +1135,13 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
   p.CinP = p.KT * 32;
   p.ones_col = g.Cin;
   if (p.NT * g.ks * p.KT > 8 * CW_MAXT) return RDST_ENOTSUP;
-  auto stride = [](int elems) {
+  // RDST_F32X3: the pipelined kernel's split form (not for dY rows shorter than a pack: the 60 -> 1 tail conv stays exact)
+  bool split = false;
+  if constexpr (sizeof(T) == 4)
+    split = rdst_split() && g.Cout >= Mma<T>::HP && g.ks == 3 && g.pad == 1 && g.W % CW_STRIPE == 0;
+  auto stride = [split](int elems) {   // (split mode: two bf16 planes in the bytes of the fp32 row, read like bf16 rows)
     const int b = elems * (int)sizeof(T);
-    if (sizeof(T) == 4) return b;
+    if (sizeof(T) == 4 && !split) return b;
     return b <= 64 ? 64 : ((b - 64 + 255) / 256) * 256 + 64;
   };
   p.ldn = stride(p.NT * 32);
@@ -1122,6 +1167,8 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
 #define RDST_CR_LAUNCH(XF)                                                                                            \
       {                                                                                                              \
         auto kern = long_stripes ? conv_wgrad_rows_kernel<T, PF, XF, 128> : conv_wgrad_rows_kernel<T, PF, XF, 32>;  \
+        if constexpr (sizeof(T) == 4)                                                                                \
+          if (split) kern = long_stripes ? conv_wgrad_rows_kernel<T, PF, XF, 128, true> : conv_wgrad_rows_kernel<T, PF, XF, 32, true>; \
         if (smem2 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); \
         hipLaunchKernelGGL(kern, dim3((unsigned)nm, 3u), dim3(512), smem2, st, p);                                   \
       }

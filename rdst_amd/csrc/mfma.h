@@ -159,7 +159,7 @@ __device__ __forceinline__ Pack16 pack_from_f32(const float* __restrict__ src, i
 //   item idx -> addr(idx, base, dst, ok):  base = pointer of element 0 of the item's pack (k0 = first k),
 //   element e of the pack is base[e * stride]; elements with k0 + e >= K (or !ok) are zero.
 // F: void(int idx, const float*& base, int& k0, char*& dst, bool& ok)
-template <typename T, int U, class F>
+template <typename T, int U, bool SP = false, class F>
 __device__ __forceinline__ void stage_packs_batched(int total, int K, int64_t stride, int tid, int nthreads, F addr, int rot = 0) {
   constexpr int HP = Mma<T>::HP;
   // `rot` rotates the item order per workgroup: every workgroup stages the SAME parameters at the same moment, and
@@ -193,7 +193,7 @@ __device__ __forceinline__ void stage_packs_batched(int total, int K, int64_t st
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (dst[u]) *reinterpret_cast<Pack16*>(dst[u]) = Mma<T>::pack(f[u]);
+      if (dst[u]) *reinterpret_cast<Pack16*>(dst[u]) = Mma<T, SP>::pack_op(f[u]);
   }
 }
 

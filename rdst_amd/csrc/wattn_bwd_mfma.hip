@@ -50,10 +50,13 @@ __device__ __forceinline__ uint32_t mask_bits_bf16(int c0, int lo, int hi) {
   return ((c0 >= lo && c0 < hi) ? 0x0000ffffu : 0u) | ((c0 + 1 >= lo && c0 + 1 < hi) ? 0xffff0000u : 0u);
 }
 
-template <typename T>
+template <typename T, bool SP = false>
 __device__ __forceinline__ Pack16 masked_pack(const char* base, int c0, int c_lo, int c_hi) {
   Pack16 p = *reinterpret_cast<const Pack16*>(base + (size_t)c0 * sizeof(T));
-  if (sizeof(T) == 2) {
+  if (SP) {   // [4 bf16 hi | 4 bf16 lo] of channels c0 .. c0 + 3
+    const uint32_t m0 = mask_bits_bf16(c0, c_lo, c_hi), m1 = mask_bits_bf16(c0 + 2, c_lo, c_hi);
+    p.w[0] &= m0; p.w[1] &= m1; p.w[2] &= m0; p.w[3] &= m1;
+  } else if (sizeof(T) == 2) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) p.w[e] &= mask_bits_bf16(c0 + 2 * e, c_lo, c_hi);
   } else {
@@ -66,11 +69,33 @@ __device__ __forceinline__ Pack16 masked_pack(const char* base, int c0, int c_lo
 // acc (32 x 32, rows = tokens of tile `rt`, cols = channel tile ct) += X^T . Bsec
 //   X[kk][v]: accumulator tiles whose ROW index (tokens of tile kk) is contracted; Bsec rows = those tokens;
 //   col0 = first of the 32 columns (bf16: a multiple of 32 — the transposed reads want aligned chunks; fp32: any).
-template <typename T>
+template <typename T, bool SP = false>
 __device__ __forceinline__ void acc_xt_b(f32x16& acc, const f32x16 (&X)[2], const char* Bsec, int ldt, int col0, bool colin,
                                          int lane) {
   const int r = lane & 31, h = lane >> 5;
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (SP) {
+    // split mode: the section rows are packs [4 hi | 4 lo] of 4 channels (16 B); a transposed read takes the hi (or, 8 bytes
+    // on, the lo) halves of 4 token rows x 16 channels; a k-step is 8 token rows: accumulator registers 4s .. 4s + 3 of both halves
+    const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int colB = col0 + 16 * (gq & 1) + 4 * pp;   // a multiple of 4 (col0 is a multiple of 32)
+    const uint32_t cm = colin ? 0xffffffffu : 0u;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        float f[4] = {X[kk][4 * s4], X[kk][4 * s4 + 1], X[kk][4 * s4 + 2], X[kk][4 * s4 + 3]};
+        const Pack16 a = split_pack4(f);
+        const int rowb = kk * 32 + 8 * s4 + 4 * h + q;
+        const char* bp = Bsec + (size_t)rowb * ldt + colB * 4;
+        const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)bp);
+        const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(bp + 8));
+        const uint2 u0 = __builtin_bit_cast(uint2, b0), u1 = __builtin_bit_cast(uint2, b1);
+        Pack16 bb;
+        bb.w[0] = u0.x & cm; bb.w[1] = u0.y & cm; bb.w[2] = u1.x & cm; bb.w[3] = u1.y & cm;
+        Mma<float, true>::mma(acc, a, bb);
+      }
+  } else if constexpr (sizeof(T) == 2) {
     const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int colB = col0 + 16 * (gq & 1) + 4 * pp;
     const uint32_t cm = colin ? 0xffffffffu : 0u;
@@ -114,19 +139,20 @@ template <typename T> constexpr int wb_ldt(int C) {
   int ldt = ((C * (int)sizeof(T) + 31) / 32) * 32;
   return (ldt / 16) % 2 == 0 ? ldt + 16 : ldt;
 }
-template <typename T, int GRAN, int ITERS, int NWAVES, int CT>
+template <typename T, int GRAN, int ITERS, int NWAVES, int CT, bool SP = false>
 __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArgs<T> p) {
   constexpr int NTHREADS = 64 * NWAVES;
   constexpr int MAXR = (64 + NWAVES - 1) / NWAVES;   // token rows staged per wave
   constexpr int NU = (NUNITS + NWAVES - 1) / NWAVES;  // units per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;   // SP: RDST_F32X3 — the four sections are split pack by pack after they are staged (mfma.h)
   using CH = typename Chunk<GRAN>::type;
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
   // fp32: the 32-column window of the accumulate products starts at the head's first channel (one window per head; with
   // windows at multiples of 32 half of the heads of C = 90 / 120 straddle two: 32 more MFMAs per product)
-  constexpr bool HEADCOL = !BF;
+  // (split mode: windows at multiples of 32 — the transposed reads take whole 4-channel packs)
+  constexpr bool HEADCOL = !BF && !SP;
   const WinGeom g = p.g;
   const int C = CT > 0 ? CT : g.C, d = CT > 0 ? CT / HEADS : p.d, ldt = CT > 0 ? wb_ldt<T>(CT) : p.ldt;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -253,6 +279,19 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
       }
     }
     __syncthreads();
+    if constexpr (SP) {
+      const int ppr = (C + 3) / 4;   // packs per row; the channels past C inside the last one are zeroed (they held lo halves)
+      for (int i = tid; i < 4 * 64 * ppr; i += NTHREADS) {
+        const int row = i / ppr, pk = i - row * ppr;
+        Pack16* q = reinterpret_cast<Pack16*>(smw + (size_t)row * ldt + pk * 16);
+        float f[4];
+        MM::unpack(*q, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = (4 * pk + e < C) ? f[e] : 0.f;
+        *q = MM::pack_op(f);
+      }
+      __syncthreads();
+    }
 
     const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
@@ -282,8 +321,8 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
         }
       for (int ts = t_lo; ts <= t_hi; ++ts) {
         const int c0 = ts * KP + h * HP;
-        const Pack16 qb = masked_pack<T>(Qs + (size_t)(t * 32 + r) * ldt, c0, c_lo, c_hi);
-        const Pack16 ob = masked_pack<T>(Os + (size_t)(t * 32 + r) * ldt, c0, c_lo, c_hi);
+        const Pack16 qb = masked_pack<T, SP>(Qs + (size_t)(t * 32 + r) * ldt, c0, c_lo, c_hi);
+        const Pack16 ob = masked_pack<T, SP>(Os + (size_t)(t * 32 + r) * ldt, c0, c_lo, c_hi);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           const Pack16 ka = *reinterpret_cast<const Pack16*>(Ks + (size_t)(kt * 32 + r) * ldt + (size_t)c0 * sizeof(T));
@@ -345,7 +384,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
         const int col0 = HEADCOL ? c_lo : (ct_lo + ci) * 32;
         const int col = col0 + r;
         const bool colin = col >= c_lo && col < c_hi;
-        acc_xt_b<T>(acc, D, Ks, ldt, col0, colin, lane);
+        acc_xt_b<T, SP>(acc, D, Ks, ldt, col0, colin, lane);
         if (colin) {
 #pragma unroll
           for (int v = 0; v < 16; ++v)
@@ -376,8 +415,8 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
         const Pack16 vb = *reinterpret_cast<const Pack16*>(Vs + (size_t)(t * 32 + r) * ldt + (size_t)c0 * sizeof(T));
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const Pack16 qa = masked_pack<T>(Qs + (size_t)(it * 32 + r) * ldt, c0, c_lo, c_hi);
-          const Pack16 oa = masked_pack<T>(Os + (size_t)(it * 32 + r) * ldt, c0, c_lo, c_hi);
+          const Pack16 qa = masked_pack<T, SP>(Qs + (size_t)(it * 32 + r) * ldt, c0, c_lo, c_hi);
+          const Pack16 oa = masked_pack<T, SP>(Os + (size_t)(it * 32 + r) * ldt, c0, c_lo, c_hi);
           MM::mma(Y[it], qa, kb);
           MM::mma(E[it], oa, vb);
         }
@@ -410,7 +449,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
           f32x16 av;
 #pragma unroll
           for (int v = 0; v < 16; ++v) av[v] = 0.f;
-          acc_xt_b<T>(av, Y, Os, ldt, col0, colin, lane);   // dV_h = P^T dO_h
+          acc_xt_b<T, SP>(av, Y, Os, ldt, col0, colin, lane);   // dV_h = P^T dO_h
           if (colin) {
 #pragma unroll
             for (int v = 0; v < 16; ++v)
@@ -421,7 +460,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
           f32x16 ak;
 #pragma unroll
           for (int v = 0; v < 16; ++v) ak[v] = 0.f;
-          acc_xt_b<T>(ak, E, Qs, ldt, col0, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
+          acc_xt_b<T, SP>(ak, E, Qs, ldt, col0, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
           if (colin) {
 #pragma unroll
             for (int v = 0; v < 16; ++v)
@@ -493,6 +532,8 @@ int launch_bwd(const T* qkv, int64_t ld, const float* table, const T* dout, int6
 #define RDST_WB_LAUNCH(GR, IT, CT)                                                                                   \
   {                                                                                                                  \
     auto kern = wattn_bwd_mfma_kernel<T, GR, IT, NWV, CT>;                                                                 \
+    if constexpr (sizeof(T) == 4)                                                                                    \
+      if (rdst_split()) kern = wattn_bwd_mfma_kernel<T, GR, IT, NWV, CT, true>;                                      \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWV), smem, st, p);                                        \
   }

@@ -56,13 +56,16 @@ template <> struct Chunk<4> { typedef uint32_t type; };
 // NW waves: wave w owns query tile w & 1 and the heads (w >> 1), + NW / 2, ...  NW = 4 with up to three workgroups per
 // CU; NW = 8 where only one workgroup fits the LDS (fp32, C = 90 / 120: four waves were ONE wave per SIMD, every LDS
 // and matrix-core latency exposed).
-template <typename T, int GRAN, int ITERS, int NW>
+// SP (fp32 rows): RDST_F32X3.  The K and V sections are split pack by pack after they are staged ([4 bf16 hi | 4 bf16 lo] per
+// 4 channels, mfma.h); the Q section stays fp32 — finished heads write their output over their dead Q channels, which would
+// tear the packs that straddle two heads — and a Q fragment is split when it is read (once per head and k-step).
+template <typename T, int GRAN, int ITERS, int NW, bool SP = false>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 1) wattn_fwd_mfma_kernel(const WaArgs<T> p) {
   constexpr int NT = 64 * NW;      // threads
   constexpr int RW = 64 / NW;      // token rows a wave stages and copies out
-  constexpr bool HEADCOL = sizeof(T) == 4;   // fp32: the 32-column window of P.V starts at the head's first channel
+  constexpr bool HEADCOL = sizeof(T) == 4 && !SP;   // fp32: the 32-column window of P.V starts at the head's first channel
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using MM = Mma<T>;
+  using MM = Mma<T, SP>;
   using CH = typename Chunk<GRAN>::type;
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
@@ -166,6 +169,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
       }
     }
     __syncthreads();
+    if constexpr (SP) {
+      const int ppr = (C + 3) / 4;   // packs per row; the channels past C inside the last one are zeroed (they held lo halves)
+      for (int i = tid; i < 2 * 64 * ppr; i += NT) {
+        const int row = i / ppr, pk = i - row * ppr;
+        Pack16* q = reinterpret_cast<Pack16*>(Ks + (size_t)row * ldt + pk * 16);
+        float f[4];
+        MM::unpack(*q, f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = (4 * pk + e < C) ? f[e] : 0.f;
+        *q = MM::pack_op(f);
+      }
+      __syncthreads();
+    }
 
     const bool mrow = g.shift > 0 && wr == g.nWh - 1, mcol = g.shift > 0 && wc == g.nWw - 1;
     const bool masked = __builtin_amdgcn_readfirstlane((int)(mrow || mcol)) != 0;
@@ -188,6 +204,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
 #pragma unroll
           for (int e = 0; e < 4; ++e) qb.w[e] = (c0 + e >= c_lo && c0 + e < c_hi) ? qb.w[e] : 0u;
         }
+        qb = MM::op(qb);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
           const Pack16 ka = *reinterpret_cast<const Pack16*>(Ks + (size_t)(kt * 32 + r) * ldt + (size_t)c0 * sizeof(T));
@@ -251,7 +268,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
         const int col = (HEADCOL ? c_lo : ct * 32) + r;
         const bool colin = col >= c_lo && col < c_hi;
         const uint32_t cmask = colin ? 0xffffffffu : 0u;
-        if constexpr (BF) {
+        if constexpr (SP) {
+          // the V rows are packs [4 hi | 4 lo] of 4 channels: a transposed read takes the hi (8 bytes on: the lo) halves of
+          // 4 key rows x 16 channels; a k-step is 8 keys: accumulator registers 4s .. 4s + 3 of both lane halves
+          const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+          const int colB = ct * 32 + 16 * (gq & 1) + 4 * pp;
+          typedef __attribute__((address_space(3))) s16x4_t* lds_p;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const float f[4] = {X[kt][4 * s4], X[kt][4 * s4 + 1], X[kt][4 * s4 + 2], X[kt][4 * s4 + 3]};
+              const Pack16 a = split_pack4(f);
+              const char* bp = Vs + (size_t)(kt * 32 + 8 * s4 + 4 * h + q) * ldt + colB * 4;
+              const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)bp);
+              const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(bp + 8));
+              const uint2 u0 = __builtin_bit_cast(uint2, b0), u1 = __builtin_bit_cast(uint2, b1);
+              Pack16 bb;
+              bb.w[0] = u0.x & cmask; bb.w[1] = u0.y & cmask; bb.w[2] = u1.x & cmask; bb.w[3] = u1.y & cmask;
+              MM::mma(acc, a, bb);
+            }
+        } else if constexpr (BF) {
           const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
           const int colB = ct * 32 + 16 * (gq & 1) + 4 * pp;
 #pragma unroll
@@ -351,6 +388,8 @@ int launch_fwd(const T* qkv, int64_t ld, const float* table, T* out, int64_t ldo
 #define RDST_WA_LAUNCH1(GR, KM, NWV)                                                                                  \
   {                                                                                                                  \
     auto kern = wattn_fwd_mfma_kernel<T, GR, KM, NWV>;                                                               \
+    if constexpr (sizeof(T) == 4)                                                                                    \
+      if (rdst_split()) kern = wattn_fwd_mfma_kernel<T, GR, KM, NWV, true>;                                          \
     if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NWV), smem, st, p);                                     \
   }

@@ -38,8 +38,9 @@ def _e1_step(mode, B=4, seed=11):
 
 def test_e1_fp32x3_bench_shape_psnr_equal_to_4_decimals():
     """RDST-E1 x4 on 1x64x64 LR patches (B = 4 of BASELINE configs[1]'s 32: the oracle is a CPU pass), forward + L1 + backward in the
-    fp32x3 mode against the oracle: |dPSNR| < 5e-5 dB (border 4 as trans_sr_tester.py:155 passes it), loss to 2e-6, every gradient
-    to 2e-3 relative L2 and the total gradient to 2e-4 (operands carry 16 mantissa bits; measured values are printed with -s)."""
+    fp32x3 mode against the oracle: |dPSNR| < 5e-5 dB (border 4 as trans_sr_tester.py:155 passes it; measured 3e-6), loss to 2e-6,
+    every gradient to 4e-3 relative L2 (measured worst 1.6e-3: the first block's relative-position table, a 225 x 6 tensor whose
+    gradient is a difference of large sums; the exact mode has 1e-3 there) and the total gradient to 2e-4 (measured 9e-5)."""
     cfg, sd, net, x, tgt, yc, loss = _e1_step("fp32x3")
     assert ops.F32_SPLIT
     params = dict(net.named_parameters())
@@ -59,7 +60,7 @@ def test_e1_fp32x3_bench_shape_psnr_equal_to_4_decimals():
           f"({worst[1]})  total gradient {total:.2e}")
     assert abs(p_hip - p_ref) < 5e-5
     assert abs(loss - oloss.item()) <= 2e-6
-    assert worst[0] <= 2e-3, worst
+    assert worst[0] <= 4e-3, worst
     assert total <= 2e-4
 
 
@@ -73,3 +74,123 @@ def test_fp32x3_differs_from_exact_fp32_and_stays_close():
     print(f"\nfp32x3 vs exact fp32: out max|d| {d:.2e}, loss {l3:.7f} vs {l1:.7f}")
     assert 0.0 < d <= 2e-4
     assert abs(l3 - l1) <= 2e-6
+
+
+def _rand(shape, seed, scale=1.0):
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * rng.standard_normal(shape)).astype("float32"))
+
+
+WATTN_CASES = [
+    # B, H, W, C, heads, ws, shift  (8x8 windows: the split forms of wattn_mfma.hip / wattn_bwd_mfma.hip)
+    (2, 16, 16, 60, 6, 8, 0),
+    (2, 16, 16, 60, 6, 8, 4),
+    (1, 16, 24, 90, 6, 8, 4),     # head dim 15: rows of 360 bytes, heads cut through the 4-channel packs
+    (1, 24, 16, 120, 6, 8, 3),    # head dim 20, odd shift
+    (8, 64, 64, 120, 6, 8, 4),    # 512 windows: two per workgroup of the persistent grid
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,heads,ws,shift", WATTN_CASES)
+def test_wattn_fp32x3_vs_oracle(B, H, W, C, heads, ws, shift):
+    """Window attention forward + backward with split-bf16 operands against the oracle (swin_transformer_sr.py:110-141): the
+    operands carry 16 mantissa bits, so the gates are 2e-4 absolute on O(1) outputs / gradients (exact fp32: 2e-5 / 5e-5) and
+    1e-4 relative on d(table) (1e-5)."""
+    ops.set_f32_split(True)
+    dev = torch.device(DEV)
+    scale = (C // heads) ** -0.5
+    qkv = _rand((B, H, W, 3 * C), 1)
+    table = _rand(((2 * ws - 1) ** 2, heads), 2, 0.5)
+    gout = _rand((B, H, W, C), 3)
+    q_ref = qkv.clone().requires_grad_(True)
+    t_ref = table.clone().requires_grad_(True)
+    o_ref = O.window_attention_core(q_ref, t_ref, heads, ws, shift, scale)
+    o_ref.backward(gout)
+    q = qkv.to(dev).requires_grad_(True)
+    t = table.to(dev).requires_grad_(True)
+    o = ops.window_attention(q, t, H, W, heads, ws, shift, scale)
+    o.backward(gout.to(dev))
+    torch.cuda.synchronize()
+    do = (o.cpu() - o_ref).abs().max().item()
+    dq = (q.grad.cpu() - q_ref.grad).abs().max().item()
+    rel = (t.grad.cpu() - t_ref.grad).norm().item() / t_ref.grad.norm().item()
+    print(f"\nwattn fp32x3 C={C} shift={shift}: out {do:.2e}  dqkv {dq:.2e}  dtable rel {rel:.2e}")
+    assert 0 < do <= 2e-4
+    assert dq <= 2e-4
+    assert rel <= 1e-4, rel
+
+
+@pytest.mark.parametrize("K,N,ln,act,res", [(60, 180, 1, 0, 0), (90, 270, 1, 0, 0), (120, 360, 1, 0, 0), (120, 120, 0, 0, 1),
+                                            (240, 120, 0, 1, 1), (120, 30, 1, 0, 0), (94, 50, 0, 2, 1)])
+def test_ln_linear_fp32x3_vs_torch(K, N, ln, act, res):
+    """LayerNorm / activation -> Linear -> residual, forward + every gradient, split-bf16 operands against fp32 torch on the CPU
+    (nn.LayerNorm, nn.GELU / LeakyReLU(0.2), nn.Linear as rdst_variations.py:335-341 composes them): relative L2 <= 3e-5."""
+    ops.set_f32_split(True)
+    dev = torch.device(DEV)
+    M = 4099     # ragged: the last 32-row slab has 3 rows
+    x = _rand((M, K), 1)
+    w = _rand((N, K), 2, K ** -0.5)
+    b = _rand((N,), 3, 0.1)
+    lw = (1 + _rand((K,), 4, 0.1)) if ln else None
+    lb = _rand((K,), 5, 0.1) if ln else None
+    r = _rand((M, N), 6) if res else None
+    gy = _rand((M, N), 7)
+
+    def run(device, fn):
+        ts = [t.clone().to(device).requires_grad_(True) if t is not None else None for t in (x, w, b, lw, lb)]
+        y = fn(*ts, r.to(device) if r is not None else None)
+        y.backward(gy.to(device))
+        return [y.detach().cpu()] + [t.grad.cpu() for t in ts if t is not None]
+
+    def ref(x_, w_, b_, lw_, lb_, r_):
+        h = F.layer_norm(x_, (K,), lw_, lb_, 1e-5) if ln else x_
+        h = F.gelu(h) if act == 1 else (F.leaky_relu(h, 0.2) if act == 2 else h)
+        y = F.linear(h, w_, b_)
+        return y + r_ if r_ is not None else y
+
+    def hip(x_, w_, b_, lw_, lb_, r_):
+        return ops.ln_linear(x_, lw_, lb_, w_, b_, in_act=act, residual=r_)
+
+    got, want = run(dev, hip), run("cpu", ref)
+    rels = [(g - w_).norm().item() / max(w_.norm().item(), 1e-12) for g, w_ in zip(got, want)]
+    print(f"\nln_linear fp32x3 K={K} N={N}: rel L2 (y, dx, dW, db[, dgamma, dbeta]) " + " ".join(f"{v:.1e}" for v in rels))
+    assert max(rels) <= 3e-5, rels
+    assert rels[0] > 0
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,act,res,r", [
+    (2, 32, 32, 60, 60, 3, 0, 1, 1),      # conv_after_body / RDB convs: the row-stripe forward, data and weight gradient
+    (1, 64, 64, 150, 60, 3, 0, 0, 1),     # the dense fusion conv (Cin = 150: a row's last 16 bytes overlap the chunk before)
+    (1, 32, 32, 60, 240, 3, 0, 0, 2),     # upsampler conv + PixelShuffle(2): data gradient in two slices of the output channels
+    (2, 24, 24, 60, 60, 3, 2, 1, 1),      # W % 32 != 0: the generic implicit-GEMM kernel; LeakyReLU(0.2) on the way in ('3conv')
+    (1, 32, 32, 60, 1, 3, 0, 0, 1),       # the 60 -> 1 tail: dY rows shorter than a pack (weight gradient stays exact fp32)
+    (2, 16, 16, 90, 30, 1, 0, 0, 1),      # 1x1
+])
+def test_conv_fp32x3_vs_torch(B, H, W, Cin, Cout, k, act, res, r):
+    """k x k convolution (+ LeakyReLU in front, residual, PixelShuffle) forward and every gradient with split-bf16 operands against
+    fp32 torch on the CPU (nn.Conv2d / nn.PixelShuffle as common.py:125-136 composes them): relative L2 <= 3e-5."""
+    ops.set_f32_split(True)
+    x = _rand((B, H, W, Cin), 1)
+    w = _rand((Cout, Cin, k, k), 2, (Cin * k * k) ** -0.5)
+    b = _rand((Cout,), 3, 0.1)
+    cy = Cout // (r * r)
+    rr = _rand((B, H * r, W * r, cy), 4) if res else None
+    gy = _rand((B, H * r, W * r, cy), 5)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    h = xr.permute(0, 3, 1, 2)
+    if act == 2:
+        h = F.leaky_relu(h, 0.2)
+    h = F.conv2d(h, wr, br, padding=k // 2)
+    if r > 1:
+        h = F.pixel_shuffle(h, r)
+    yr = h.permute(0, 2, 3, 1) + (rr if res else 0)
+    yr.backward(gy)
+    xg, wg, bg = (t.clone().to(DEV).requires_grad_(True) for t in (x, w, b))
+    yg = ops.conv_rows(xg, wg, bg, in_act=act, residual=rr.to(DEV) if res else None, shuffle=r)
+    yg.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    pairs = [(yg.detach().cpu(), yr.detach()), (xg.grad.cpu(), xr.grad), (wg.grad.cpu(), wr.grad), (bg.grad.cpu(), br.grad)]
+    rels = [(g - w_).norm().item() / max(w_.norm().item(), 1e-12) for g, w_ in pairs]
+    print(f"\nconv fp32x3 {Cin}->{Cout} k{k} {H}x{W}: rel L2 (y, dx, dW, db) " + " ".join(f"{v:.1e}" for v in rels))
+    assert max(rels) <= 3e-5, rels
