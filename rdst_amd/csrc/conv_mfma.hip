@@ -870,7 +870,17 @@ __global__ void __launch_bounds__(512) conv_wgrad_rows_kernel(const ConvWgradArg
           *reinterpret_cast<Pack16*>(tile + dy_lds[i]) = q;
         }
       }
-    if (sm_act) *reinterpret_cast<T*>(tile + sm_row * p.ldn + sm_col * ES) = rsm[set];
+    if (sm_act) {
+      if constexpr (SPL) {   // one element: its hi and lo terms into the two planes
+        const float f = to_f32<T>(rsm[set]);
+        const uint32_t hi = pack_bf16x2(f, 0.f);
+        const uint32_t lo = pack_bf16x2(f - bf16lo(hi), 0.f);
+        *reinterpret_cast<uint16_t*>(tile + sm_row * p.ldn + sm_col * 2) = (uint16_t)hi;
+        *reinterpret_cast<uint16_t*>(tile + sm_row * p.ldn + p.NT * 64 + sm_col * 2) = (uint16_t)lo;
+      } else {
+        *reinterpret_cast<T*>(tile + sm_row * p.ldn + sm_col * ES) = rsm[set];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < XMAX; ++i)
       if (x_row[i] >= 0) {
@@ -1135,10 +1145,10 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
   p.CinP = p.KT * 32;
   p.ones_col = g.Cin;
   if (p.NT * g.ks * p.KT > 8 * CW_MAXT) return RDST_ENOTSUP;
-  // RDST_F32X3: the pipelined kernel's split form (not for dY rows shorter than a pack: the 60 -> 1 tail conv stays exact)
+  // RDST_F32X3: the pipelined kernel's split form
   bool split = false;
   if constexpr (sizeof(T) == 4)
-    split = rdst_split() && g.Cout >= Mma<T>::HP && g.ks == 3 && g.pad == 1 && g.W % CW_STRIPE == 0;
+    split = rdst_split() && g.ks == 3 && g.pad == 1 && g.W % CW_STRIPE == 0;
   auto stride = [split](int elems) {   // (split mode: two bf16 planes in the bytes of the fp32 row, read like bf16 rows)
     const int b = elems * (int)sizeof(T);
     if (sizeof(T) == 4 && !split) return b;
@@ -1150,7 +1160,8 @@ int conv_wgrad_mfma(const T* X, int64_t ldx, int in_act, const T* dYp, int64_t l
   {  // the pipelined kernel: 3x3 / pad 1, rows of 32-pixel stripes, packs loaded whole (dword-aligned rows)
     constexpr int HP = Mma<T>::HP;
     const bool small_n = g.Cout < HP;
-    const bool long_stripes = p.NT <= 2 && p.KT <= 2 && g.W % 128 == 0;
+    bool long_stripes = p.NT <= 2 && p.KT <= 2 && g.W % 128 == 0;
+    if (long_stripes && (size_t)2 * (128 * p.ldn + 130 * p.ldk) > 160 * 1024) long_stripes = false;   // (the split mode's padded rows)
     const int SLr = long_stripes ? 128 : CW_STRIPE;
     const size_t smem2 = (size_t)2 * (SLr * p.ldn + (SLr + 2) * p.ldk);
     const bool ok = g.ks == 3 && g.pad == 1 && g.W % CW_STRIPE == 0 && p.NT <= 8 && p.KT <= 8 && g.Cin >= HP &&

@@ -164,7 +164,8 @@ def test_ln_linear_fp32x3_vs_torch(K, N, ln, act, res):
     (1, 64, 64, 150, 60, 3, 0, 0, 1),     # the dense fusion conv (Cin = 150: a row's last 16 bytes overlap the chunk before)
     (1, 32, 32, 60, 240, 3, 0, 0, 2),     # upsampler conv + PixelShuffle(2): data gradient in two slices of the output channels
     (2, 24, 24, 60, 60, 3, 2, 1, 1),      # W % 32 != 0: the generic implicit-GEMM kernel; LeakyReLU(0.2) on the way in ('3conv')
-    (1, 32, 32, 60, 1, 3, 0, 0, 1),       # the 60 -> 1 tail: dY rows shorter than a pack (weight gradient stays exact fp32)
+    (1, 32, 32, 60, 1, 3, 0, 0, 1),       # the 60 -> 1 tail: dY rows shorter than a pack (single elements into the hi / lo planes)
+    (1, 128, 128, 60, 1, 3, 0, 0, 1),     # ... with 128-pixel stripes
     (2, 16, 16, 90, 30, 1, 0, 0, 1),      # 1x1
 ])
 def test_conv_fp32x3_vs_torch(B, H, W, Cin, Cout, k, act, res, r):
