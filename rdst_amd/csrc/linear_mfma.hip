@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
               float f[HP];
               MM::unpack(a[t], f);
 #pragma unroll
-              for (int e = 0; e < HP; ++e) f[e] = apply_act<BF>(f[e], p.in_act);
+              for (int e = 0; e < HP; ++e) f[e] = apply_act<BF || SP>(f[e], p.in_act);   // (split mode: the fast GELU, |err| 1.5e-7)
               a[t] = MM::pack_op(f);
             }
         }
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
               float g8[8];
               chunk8(p.Xa + row * p.ldxa, xa_vec, g8);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) c8[e] *= act_grad<BF>(g8[e], p.in_act);
+              for (int e = 0; e < 8; ++e) c8[e] *= act_grad<BF || SP>(g8[e], p.in_act);
             }
             if (p.Acc) {
               float g8[8];
@@ -1166,7 +1166,7 @@ __global__ void __launch_bounds__(WG_THREADS) lin_wgrad_mfma_kernel(const WgradA
             for (int e = 0; e < HP; ++e) f[e] = (f[e] - mu) * rs;
           } else if (XF == 2) {
 #pragma unroll
-            for (int e = 0; e < HP; ++e) f[e] = sizeof(T) == 2 ? gelu_fast(f[e]) : gelu_erf(f[e]);
+            for (int e = 0; e < HP; ++e) f[e] = (sizeof(T) == 2 || SPL) ? gelu_fast(f[e]) : gelu_erf(f[e]);
           } else if (XF == 3) {
 #pragma unroll
             for (int e = 0; e < HP; ++e) f[e] = apply_act(f[e], p.in_act);

@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
   using CH = typename Chunk<GRAN>::type;
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
+  constexpr bool L2D = BF || SP;   // softmax in the log2 domain on the hardware exp2 (the split mode is not bit-exact fp32 anyway; exact fp32 keeps expf)
   // fp32: the 32-column window of the accumulate products starts at the head's first channel (one window per head; with
   // windows at multiples of 32 half of the heads of C = 90 / 120 straddle two: 32 more MFMAs per product)
   // (split mode: windows at multiples of 32 — the transposed reads take whole 4-channel packs)
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
   // then float4 stats[HEADS][64] {m, 1/l, delta, -}
 
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-  const float tabscale = BF ? LOG2E : 1.0f;
+  const float tabscale = L2D ? LOG2E : 1.0f;
   const float qscale = p.scale * tabscale;
   const int nW = g.nWh * g.nWw;
   const int nwin = g.B * nW;
@@ -352,7 +353,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-          const float e = BF ? __builtin_amdgcn_exp2f(X[kt][v] - m) : expf(X[kt][v] - m);
+          const float e = L2D ? __builtin_amdgcn_exp2f(X[kt][v] - m) : expf(X[kt][v] - m);
           X[kt][v] = e;
           l += e;
         }
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           const float4 st = stats[hd * 64 + it * 32 + acc_row(v, h)];
-          const float pr = (BF ? __builtin_amdgcn_exp2f(Y[it][v] - st.x) : expf(Y[it][v] - st.x)) * st.y;  // P
+          const float pr = (L2D ? __builtin_amdgcn_exp2f(Y[it][v] - st.x) : expf(Y[it][v] - st.x)) * st.y;  // P
           Y[it][v] = pr;
           E[it][v] = pr * (E[it][v] - st.z);                                                                // dS
         }
@@ -444,7 +445,7 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
         const int col0 = HEADCOL ? c_lo : (ct_lo + ci) * 32;
         const int col = col0 + r;
         const bool colin = col >= c_lo && col < c_hi;
-        const float kfix = BF ? LN2 : 1.0f;
+        const float kfix = L2D ? LN2 : 1.0f;
         {
           f32x16 av;
 #pragma unroll

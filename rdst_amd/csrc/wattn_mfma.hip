@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
   using CH = typename Chunk<GRAN>::type;
   constexpr int KP = MM::KP, HP = MM::HP;
   constexpr bool BF = sizeof(T) == 2;
+  constexpr bool L2D = BF || SP;   // softmax in the log2 domain on the hardware exp2 (the split mode is not bit-exact fp32 anyway; exact fp32 keeps expf)
   const WinGeom g = p.g;
   const int C = g.C, heads = g.heads, d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
   float* tabL = reinterpret_cast<float*>(Vs + 64 * ldt);  // [heads][15][TS]
 
   constexpr float LOG2E = 1.4426950408889634f;
-  const float tabscale = BF ? LOG2E : 1.0f;
+  const float tabscale = L2D ? LOG2E : 1.0f;
   const int nW = g.nWh * g.nWw;
   const int nwin = g.B * nW;
 
@@ -238,8 +239,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
           f32x2 x2 = {X[kt][v], X[kt][v + 1]};
           x2 -= m2;                                   // v_pk_add_f32
           f32x2 e2;
-          e2.x = BF ? __builtin_amdgcn_exp2f(x2.x) : expf(x2.x);
-          e2.y = BF ? __builtin_amdgcn_exp2f(x2.y) : expf(x2.y);
+          e2.x = L2D ? __builtin_amdgcn_exp2f(x2.x) : expf(x2.x);
+          e2.y = L2D ? __builtin_amdgcn_exp2f(x2.y) : expf(x2.y);
           l2 += e2;
           X[kt][v] = e2.x;
           X[kt][v + 1] = e2.y;
