@@ -195,3 +195,43 @@ def test_conv_fp32x3_vs_torch(B, H, W, Cin, Cout, k, act, res, r):
     rels = [(g - w_).norm().item() / max(w_.norm().item(), 1e-12) for g, w_ in pairs]
     print(f"\nconv fp32x3 {Cin}->{Cout} k{k} {H}x{W}: rel L2 (y, dx, dW, db) " + " ".join(f"{v:.1e}" for v in rels))
     assert max(rels) <= 3e-5, rels
+
+
+@pytest.mark.parametrize("name", ["net_tiny_64", "net_tiny_b4", "net_e1_16", "net_ws16_32", "net_3conv_x3"])
+def test_network_fp32x3_vs_reference_fixture(name):
+    """The five training-step fixtures GENERATED FROM THE REFERENCE (tests/golden/make_golden.py) in the fp32x3 mode: the shapes
+    outside the E1 set run the shape-generic split kernels (48 channels: head dim 8; window 16 keeps the exact window-16 kernels
+    between split Linears; '3conv' x3 with LeakyReLU on the convolutions' way in; MeanShift).  Gates: PSNR equal to the
+    reference's to < 5e-5 dB, outputs to 2e-4 (exact mode: 1e-4), loss to 2e-6, every gradient's norm to 1e-3
+    relative and every stored gradient to 5e-3 relative L2 (exact mode: 1e-3; the operands carry 16 mantissa bits)."""
+    import numpy as np
+    from util import NET_CASES, load_golden
+    cfg, seed = NET_CASES[name]
+    g = load_golden(name)
+    mean = g["mean"].tolist() if "mean" in g else None
+    std = g["std"].tolist() if "std" in g else None
+    net = build_net(cfg, mean, std)
+    net.load_state_dict(O.make_weights(cfg, seed, mean, std), strict=True)
+    net.to(DEV).train().set_compute_dtype("fp32x3")
+    y = net(torch.from_numpy(g["x"]).to(DEV))
+    tgt = torch.from_numpy(g["target"]).to(DEV)
+    loss = F.l1_loss(y, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    yc = y.detach().cpu()
+    dy = np.abs(yc.numpy() - g["y"]).max()
+    dp = abs(O.psnr(tgt.cpu(), yc, border=cfg["sr_scale"]) - float(g["psnr"]))
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k in g:
+        if k.startswith("grad::"):
+            ref = g[k]
+            got = params[k[6:]].grad.cpu().numpy()
+            worst = max(worst, np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12))
+    print(f"\n{name} fp32x3: out max|d| {dy:.2e}  |dPSNR| {dp:.2e}  loss {loss.item():.7f} vs {float(g['loss']):.7f}  worst stored gradient {worst:.2e}")
+    assert 0 < dy <= 2e-4
+    assert dp < 5e-5
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6
+    for k, l2 in zip([str(k) for k in g["grad_keys"]], g["grad_l2"]):
+        assert abs(params[k].grad.double().norm().item() - l2) <= 1e-3 * max(l2, 1e-9), k
+    assert worst <= 5e-3
