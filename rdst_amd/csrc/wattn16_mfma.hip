@@ -17,6 +17,10 @@
 #include "wattn_hd.h"
 #include "wattn16.h"
 
+namespace wahd {
+template <> struct Chunk<4> { typedef uint32_t type; };   // one head of dim 10: 20-byte pieces, rows only dword aligned
+}
+
 namespace {
 using namespace wahd;
 using namespace w16c;
@@ -37,15 +41,17 @@ struct W16Args {
   const float* nlse; const bf16* o; int64_t ldo2;   // backward v2: the statistics and the forward's output rows, or NULL
 };
 
-template <int D>
+// HPG_ = 2: a workgroup owns a head PAIR (every kernel but wattn16_bwd1_kernel); HPG_ = 1: a single head (D = 10 / 20 only: the
+// pieces of a head of dim 15 start on 2-byte boundaries)
+template <int D, int HPG_ = 2>
 struct W16 {
-  static constexpr int HEADS = 6, HPG = 2, NG = 3;
+  static constexpr int HEADS = 6, HPG = HPG_, NG = HEADS / HPG;
   static constexpr int C = HEADS * D;
-  static constexpr int GC = HPG * D;                 // channels of a head pair
-  static constexpr int PB = GC * 2;                  // bytes of its piece of a row section: 40 / 60 / 80
-  static constexpr int GRAN = D == 10 ? 8 : D == 15 ? 12 : 16;  // chunk size (D = 15: 12-B chunks, dword aligned)
+  static constexpr int GC = HPG * D;                 // channels of a head pair (of the head)
+  static constexpr int PB = GC * 2;                  // bytes of its piece of a row section: 40 / 60 / 80 (20 / 40)
+  static constexpr int GRAN = HPG == 2 ? (D == 10 ? 8 : D == 15 ? 12 : 16) : (D == 10 ? 4 : 8);  // chunk size (D = 15: 12-B chunks, dword aligned)
   static constexpr int CPS = PB / GRAN;              // chunks per piece
-  static constexpr int LDT = D == 10 ? 48 : 80;      // LDS row stride: odd number of 16-B slots
+  static constexpr int LDT = HPG == 2 ? (D == 10 ? 48 : 80) : (D == 10 ? 32 : 48);   // LDS row stride (pairs: odd number of 16-B slots)
   static constexpr int SEC = 256 * LDT;              // bytes of one staged section
   static constexpr int TROW = 32;                    // floats per staged table row (31 used)
   // floats per head and copy: 31 rows + 16 floats of padding, so that the copies lie 16 banks apart (mod 64).  A 32-lane
@@ -471,9 +477,9 @@ __device__ __forceinline__ void w16_bwd_p1(const W16BCtx& c, f32x16& dq) {
 // initial accumulator — so the 8 key tiles are streamed through 16 + 16 registers instead of living in 128: no row maximum,
 // no row sum, no normalisation, no delta pass, dP formed ONCE: 5.5 vector instructions per logit instead of 8.5 and half
 // the matrix instructions.  (nlse, -delta) of the head are read from `stat`, where the prologue put them for pass 2.
-template <int D, int HL, typename PT = float>
+template <int D, int HL, typename PT = float, int HPG = 2>
 __device__ __forceinline__ void w16_bwd_p1s(const W16BCtx& c, f32x16& dq) {
-  using CF = W16<D>;
+  using CF = W16<D, HPG>;
   constexpr int ldt = CF::LDT;
   constexpr int c_lo = HL * D, c_hi = c_lo + D;
   constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
@@ -561,9 +567,9 @@ __device__ __forceinline__ void w16_bwd_p1s(const W16BCtx& c, f32x16& dq) {
   }
 }
 
-template <int D, int HL>
+template <int D, int HL, int HPG = 2>
 __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
-  using CF = W16<D>;
+  using CF = W16<D, HPG>;
   constexpr int ldt = CF::LDT;
   constexpr int c_lo = HL * D, c_hi = c_lo + D;
   constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
@@ -1079,11 +1085,265 @@ __global__ void __launch_bounds__(1024, 4) wattn16_bwd3_kernel(const W16Args p) 
   }
 }
 
+
+#ifndef W16_ABL1
+#define W16_ABL1 0   // ablations of wattn16_bwd1_kernel (tools/abl_build.sh): 1 no pass 1, 2 no pass 2, 4 no table images / row-sum reduce, 8 no global stores
+#endif
+// ---- ONE head per workgroup, two workgroups per CU (D = 10 / 20) ---------------------------------------
+// wattn16_bwd3_kernel loads, computes and stores in sequence and holds 119-150 KB of LDS: one workgroup per CU, nothing overlaps
+// its load / stage / store skeleton (40 % of its time).  With a single head the staged pieces are 20 / 40 B
+// per row (LDS rows of 32 / 48 B: one / two k-steps per product where the pair's masked packs take two / three), the tables,
+// statistics and d(table) row sums of one head: 67 / 75 KB, so TWO 8-wave workgroups share a CU and one's skeleton runs
+// beside the other's passes.  wave = tile (queries in pass 1, keys in pass 2); the arithmetic is w16_bwd_p1s / w16_bwd_p2 of the
+// pair kernel with the pair's head 0 as the only head.  The natural table (pass 2) is staged over the row sums (pass 1) after
+// they have been reduced: its values wait in two registers per thread from the start.
+// Measured (tools/w16_bench.py, B = 8 of 128 x 128, per call with the table reduce, one box): pair kernel 194 / 206 us -> 181 / 182
+// (D = 10 / 20); with ONE of these workgroups per CU (40 KB of dummy LDS) 244 / 251: the second workgroup is worth 70 us.
+// Ablations (W16_ABL1), D = 10 / 20: whole 181 / 182, no pass 1 118 / 118, no pass 2 124 / 126, neither 64 / 75, and without the
+// table images / row-sum reduce 52 / 65, and without the global stores 33 / 40 — still additive: the passes (121 us) are
+// bound by their vector instructions, so a second workgroup fills their stalls but cannot hide work; an offset between
+// the two workgroups of a CU (s_sleep in the second one of the first round) changed nothing (179-187 us).
+template <int D>
+struct W16B1 {
+  using CF = W16<D, 1>;
+  static constexpr int SEC = CF::SEC;
+  static constexpr int OFF_TABR = 4 * SEC + 64;
+  static constexpr int OFF_STAT = OFF_TABR + 2 * CF::TABF * 4;      // [nlse | -delta | (unused)][256]
+  static constexpr int OFF_PART = OFF_STAT + 3 * 256 * 4;           // [yi 16][yj 16][32] bf16 (pass 1), then the natural table (pass 2)
+  static constexpr size_t SMEM = (size_t)OFF_PART + 16 * 16 * 32 * 2;
+  static_assert(2 * CF::TABF * 4 <= 16 * 16 * 32 * 2, "the natural table lies over the row sums");
+};
+
+template <int D>
+__global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using CF = W16<D, 1>;
+  using BF = W16B1<D>;
+  using CH = typename Chunk<CF::GRAN>::type;
+  constexpr int ldt = CF::LDT, GRAN = CF::GRAN, CPS = CF::CPS, CPR = 3 * CPS, RPI = 64 / CPR, NI = 32 / RPI;
+  constexpr int RPD = 64 / CPS, ND = (32 + RPD - 1) / RPD;
+  static_assert(32 % RPI == 0, "a wave stages the 32 token rows of its tile");
+  static_assert(D % 2 == 0, "single heads of dim 10 / 20");
+  const WinGeom g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int tl = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's tile
+  char* Qs = smem;
+  char* Ks = Qs + CF::SEC;
+  char* Vs = Ks + CF::SEC;
+  char* dOs = Vs + CF::SEC;
+  float* tabR = reinterpret_cast<float*>(smem + BF::OFF_TABR);
+  float* stat = reinterpret_cast<float*>(smem + BF::OFF_STAT);
+  bf16* part = reinterpret_cast<bf16*>(smem + BF::OFF_PART);
+  float* tabN = reinterpret_cast<float*>(smem + BF::OFF_PART);
+
+  const int nW = g.nWh * g.nWw, nwin = g.B * nW;
+  int win, hd;   // the six heads of a window run on the same XCD (blockIdx round-robins over 8 XCDs)
+  if ((nwin & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    hd = slot % 6;
+    win = (slot / 6) * 8 + xcd;
+  } else {
+    hd = blockIdx.x % 6;
+    win = blockIdx.x / 6;
+  }
+  const int b = win / nW, wi = win - b * nW, wr = wi / g.nWw, wc = wi - wr * g.nWw;
+
+  // ---- this wave's 32 token rows of qkv and dO -> registers
+  const int lr0 = lane / CPR, ch = lane - lr0 * CPR;
+  const bool act = lr0 < RPI;
+  const int lr = act ? lr0 : RPI - 1;
+  const int sec = ch / CPS, cw = ch - sec * CPS;
+  CH regs[NI], dreg[ND];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int t = tl * 32 + i * RPI + lr;
+    const int64_t tok = win_token16(b, wr, wc, t, g);
+    const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld) + sec * (CF::C * 2) + hd * CF::PB + cw * GRAN;
+    regs[i] = *reinterpret_cast<const CH*>(src);
+  }
+  const int dr0 = lane / CPS, dc = lane - dr0 * CPS;
+  const bool dact0 = dr0 < RPD;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    int rr = i * RPD + (dact0 ? dr0 : RPD - 1);
+    rr = rr < 32 ? rr : 31;
+    const int64_t tok = win_token16(b, wr, wc, tl * 32 + rr, g);
+    const char* src = reinterpret_cast<const char*>(p.dout + tok * p.ldd) + hd * CF::PB + dc * GRAN;
+    dreg[i] = *reinterpret_cast<const CH*>(src);
+  }
+  // (nlse, -delta) of query tile tl: lane r = query, both lane halves compute the same
+  const int qown = tl * 32 + r;
+  const int64_t tokq = win_token16(b, wr, wc, qown, g);
+  float dl = 0.f;
+  const float nl_own = p.nlse[tokq * CF::HEADS + hd];
+  {
+    const uint32_t* orow = reinterpret_cast<const uint32_t*>(p.o + tokq * p.ldo2 + hd * D);
+    const uint32_t* drow = reinterpret_cast<const uint32_t*>(p.dout + tokq * p.ldd + hd * D);
+    uint32_t ov[D / 2], dv[D / 2];
+#pragma unroll
+    for (int i = 0; i < D / 2; ++i) { ov[i] = orow[i]; dv[i] = drow[i]; }
+#pragma unroll
+    for (int i = 0; i < D / 2; ++i) {
+      dl = fmaf(bf16lo(dv[i]), bf16lo(ov[i]), dl);
+      dl = fmaf(bf16hi(dv[i]), bf16hi(ov[i]), dl);
+    }
+  }
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float rscale = 1.0f / p.scale;
+  // the head's bias table / scale: two entries per thread, the reversed image (pass 1, two copies shifted by one float) now,
+  // the natural one after pass 1
+  constexpr int NLD = (961 + 511) / 512;
+  float tv[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int j = tid + 512 * k;
+    tv[k] = p.table[(j < 961 ? j : 960) * CF::HEADS + hd] * rscale;
+  }
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int j = tid + 512 * k;
+    if (j < 961 && !(W16_ABL1 & 4)) {
+      const int ry = j / 31, rx = j - ry * 31;
+      const int ir = (30 - ry) * CF::TROW + (30 - rx);
+      tabR[ir] = tv[k];
+      if (ir >= 1) tabR[CF::TABF + ir - 1] = tv[k];
+    }
+  }
+  if (tid < 16) *reinterpret_cast<uint32_t*>(dOs + CF::SEC + 4 * tid) = 0u;   // guard behind the last dO row
+  if constexpr (ldt > CF::PB) {   // zero the pad bytes of every staged row
+    constexpr int padw = (ldt - CF::PB) / 4;
+    for (int idx = tid; idx < 4 * 256 * padw; idx += 512) {
+      const int row = idx / padw, w = idx - row * padw;
+      *reinterpret_cast<uint32_t*>(Qs + (size_t)row * ldt + CF::PB + 4 * w) = 0u;
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int t = tl * 32 + i * RPI + lr;
+      chunk_to_lds<CH>(smem + sec * CF::SEC + t * ldt + cw * GRAN, regs[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int rr = i * RPD + dr0;
+    if (dact0 && rr < 32) chunk_to_lds<CH>(dOs + (tl * 32 + rr) * ldt + dc * GRAN, dreg[i]);
+  }
+  if (h == 0) {
+    stat[qown] = nl_own;
+    stat[256 + qown] = -dl;
+  }
+  __syncthreads();
+
+  W16BCtx c;
+  c.sc.h = h; c.sc.r = r;
+  c.sc.thr = g.ws - g.shift;
+  c.sc.mrow = g.shift > 0 && wr == g.nWh - 1;
+  c.sc.mcol = g.shift > 0 && wc == g.nWw - 1;
+  c.sc.masked = c.sc.mrow || c.sc.mcol;
+  c.sc.cbits = (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)(100.0f * rscale));
+  c.sc.scale2 = p.scale * LOG2E;
+  c.scale = p.scale;
+  c.stat = (LDS_AS float*)stat;
+  const int trofs = (4 * h + ((lane & 15) >> 2)) * ldt + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int y0 = 2 * tl + (r >> 4), x0 = r & 15;
+  const int u0 = (15 - y0) * CF::TROW + 15 - x0 + 4 * h;
+  {  // pass 1: wave = query tile tl
+    c.sc.qt = tl;
+    c.sc.Qp = (lds_cp)(Qs + (tl * 32 + r) * ldt + h * 16);
+    c.sc.Kp = (lds_cp)(Ks + r * ldt + h * 16);
+    c.sc.tb = (const LDS_AS f32x2*)((u0 & 1) ? tabR + CF::TABF + (u0 - 1) : tabR + u0);
+    c.dOp = (lds_cp)(dOs + (tl * 32 + r) * ldt + h * 16);
+    c.Vrow = (lds_cp)(Vs + r * ldt + h * 16);
+    c.Ktr = (lds_cp)(Ks + trofs);
+    c.part = (LDS_AS float*)(part + (2 * tl + (r >> 4)) * 16 * 32 + (r & 15));
+  }
+  f32x16 dq;
+  if (W16_ABL1 & 1) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dq[v] = 0.f;
+  } else {
+    w16_bwd_p1s<D, 0, bf16, 1>(c, dq);
+  }
+  __syncthreads();
+  if (!(W16_ABL1 & 4)) {  // d(table): one thread per entry adds its <= 16 slots in fixed order
+    float* slab_row = p.slab + ((int64_t)win * CF::HEADS + hd) * 961;
+    float sums[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int e = tid + 512 * k;
+      const int ee = e < 961 ? e : 960;
+      const int ry = ee / 31, rx = ee - ry * 31;
+      float sum = 0.f;
+      for (int yi = 0; yi < 16; ++yi) {
+        const int yj = yi + 15 - ry;
+        if (yj >= 0 && yj < 16) sum += __bfloat162float(part[(yi * 16 + yj) * 32 + rx]);
+      }
+      sums[k] = sum;
+      if (e < 961) slab_row[e] = sum;
+    }
+    (void)sums;
+  }
+  __syncthreads();   // the row sums have been read: the natural table takes their place
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int j = tid + 512 * k;
+    if (j < 961 && !(W16_ABL1 & 4)) {
+      const int ry = j / 31, rx = j - ry * 31;
+      const int in = ry * CF::TROW + rx;
+      tabN[in] = tv[k];
+      if (in >= 1) tabN[CF::TABF + in - 1] = tv[k];
+    }
+  }
+  __syncthreads();
+  {  // pass 2: wave = key tile tl
+    c.kt = tl;
+    c.QA = (lds_cp)(Qs + r * ldt + h * 16);
+    c.dOA = (lds_cp)(dOs + r * ldt + h * 16);
+    c.Qtr = (lds_cp)(Qs + trofs);
+    c.dOtr = (lds_cp)(dOs + trofs);
+    c.Kown = (lds_cp)(Ks + (tl * 32 + r) * ldt + h * 16);
+    c.Vown = (lds_cp)(Vs + (tl * 32 + r) * ldt + h * 16);
+    c.Kst = (lds_cp)(Ks + (tl * 32 + r) * ldt);
+    c.Vst = (lds_cp)(Vs + (tl * 32 + r) * ldt);
+    c.tb2 = (const LDS_AS f32x2*)((u0 & 1) ? tabN + CF::TABF + (u0 - 1) : tabN + u0);
+  }
+  if (!(W16_ABL1 & 2)) w16_bwd_p2<D, 0, 1>(c);
+  __syncthreads();   // every wave is done with Q as an operand: the wave's own tile of the query rows takes dQ
+  store_tile_rows<0, 0, D>((lds_cp)(Qs + (tl * 32 + r) * ldt), dq, p.scale, h);
+  __syncthreads();
+  // dQ | dK | dV (in place of Q / K / V) -> global rows of this wave's 32 tokens
+#pragma unroll 1
+  for (int idx = lane; idx < 32 * CPR; idx += 64) {
+    const int row = idx / CPR, k3 = idx - row * CPR;
+    const int s3 = k3 / CPS, k = k3 - s3 * CPS;
+    const int t = tl * 32 + row;
+    const int64_t tok = win_token16(b, wr, wc, t, g);
+    char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq) + s3 * (CF::C * 2) + hd * CF::PB + k * GRAN;
+    const char* src = smem + s3 * CF::SEC + (size_t)t * ldt + k * GRAN;
+    if (!(W16_ABL1 & 8)) *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(src);
+  }
+}
+
+#ifndef W16_BWD1
+#define W16_BWD1 1   // with the forward's statistics, D = 10 / 20: 1 = one head per workgroup, two workgroups per CU; 0 = the pair kernel below
+#endif
 #ifndef W16_BWD3
 #define W16_BWD3 1   // with the forward's statistics: 1 = the 16-wave kernel (both heads of the pair side by side), 0 = the 8-wave kernel with
 #endif               // the streaming first pass
 template <int D>
 int launch_bwd16(const W16Args& p, hipStream_t st) {
+  if constexpr (D != 15) {
+    if (W16_BWD1 && p.nlse && p.o) {
+      auto k1 = wattn16_bwd1_kernel<D>;
+      constexpr size_t smem1 = W16B1<D>::SMEM;
+      static_assert(smem1 <= 80 * 1024, "two workgroups per CU");
+      (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
+      const int64_t nwin1 = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
+      hipLaunchKernelGGL(k1, dim3((unsigned)(6 * nwin1)), dim3(512), smem1, st, p);
+      return rdst_launch_status("wattn16_bwd1");
+    }
+  }
   if (W16_BWD3 && p.nlse && p.o) {
     auto k3 = wattn16_bwd3_kernel<D>;
     constexpr size_t smem3 = W16B3<D>::SMEM;
@@ -1127,7 +1387,7 @@ int wattn16_bwd_mfma(const void* qkv, int64_t ld, const float* table, const void
                      const void* o, int64_t ldo, const float* nlse) {
   if (g.ws != 16 || g.heads != 6 || g.mask || !(scale > 0.f) || g.C % 6) return RDST_ENOTSUP;
   const int64_t nwin = (int64_t)g.B * g.nWh * g.nWw;
-  if (nwin * 3 > 0x7fffffff || slab_rows < nwin) return RDST_ENOTSUP;
+  if (nwin * 6 > 0x7fffffff || slab_rows < nwin) return RDST_ENOTSUP;
   W16Args p{};
   p.qkv = (const bf16*)qkv; p.ld = ld; p.table = table; p.dout = (const bf16*)dout; p.ldd = ldd;
   p.dqkv = (bf16*)dqkv; p.ldq = ldq; p.slab = slab; p.g = g; p.scale = scale;

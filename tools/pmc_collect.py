@@ -46,6 +46,7 @@ KERNELS = {
     "wattn16_fwd_kernel": ("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "wattn16_bwd_kernel": ("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "wattn16_bwd3_kernel": ("wattn16_bwd3_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
+    "wattn16_bwd1_kernel": ("wattn16_bwd1_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "uconv_halo_kernel": ("uconv_halo_kernel", ["uconv_mfma.hip"]),
     "uconv_kernel": ("uconv_kernel", ["uconv_mfma.hip"]),
 }
