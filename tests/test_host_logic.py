@@ -295,3 +295,29 @@ def test_dropout_probabilities_are_validated_like_nn_dropout():
             Mlp(60, 120, drop=bad)
         with pytest.raises(ValueError):
             WindowAttention(60, (8, 8), 6, attn_drop=bad)
+
+
+def test_compute_dtype_switch_and_dtype_codes():
+    """set_compute_dtype: torch.float32 / 'fp32' = exact parity mode, 'fp32x3' = fp32 tensors with the split-bf16 GEMMs (the C ABI's
+    RDST_F32X3 for every fp32 tensor of the process), torch.bfloat16 / 'bf16' = throughput mode; anything else is refused."""
+    from rdst_amd import _lib, ops
+    net = build_net(O.CFG_TINY)
+    x32, xbf = torch.zeros(2, 4), torch.zeros(2, 4, dtype=torch.bfloat16)
+    try:
+        assert net.compute_dtype == torch.float32 and not ops.F32_SPLIT
+        assert ops._dtype_code(x32) == _lib.F32 and ops._dtype_code(xbf) == _lib.BF16
+        assert net.set_compute_dtype("fp32x3") is net
+        assert net.compute_dtype == torch.float32 and ops.F32_SPLIT
+        assert ops._dtype_code(x32) == _lib.F32X3 == 2 and ops._dtype_code(xbf) == _lib.BF16
+        net.set_compute_dtype("bf16")
+        assert net.compute_dtype == torch.bfloat16 and ops.F32_SPLIT          # (the switch only concerns fp32 tensors)
+        net.set_compute_dtype(torch.float32)
+        assert net.compute_dtype == torch.float32 and not ops.F32_SPLIT
+        net.set_compute_dtype("fp32x3").set_compute_dtype("fp32")
+        assert not ops.F32_SPLIT
+        with pytest.raises(ValueError):
+            net.set_compute_dtype(torch.float16)
+        with pytest.raises(TypeError):
+            ops._dtype_code(torch.zeros(1, dtype=torch.float16))
+    finally:
+        ops.set_f32_split(False)
