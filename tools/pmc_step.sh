@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage: bash tools/pmc_step.sh <tag>  -> gpurun_out/<tag>_sq.txt: SQ issue counters of every kernel of one eager e1 training step
+# usage: bash tools/pmc_step.sh <tag> [bench.py args, e.g. --dtype fp32x3]  -> gpurun_out/<tag>_sq.txt: SQ issue counters of every kernel of one eager e1 training step
 export PYTHONPATH=$PWD
 T=${1:-sq}
-B="python3 bench.py --steps 1 --warmup 0 --graph 0 --no-roofline --no-cpu-baseline"
+shift
+B="python3 bench.py --steps 1 --warmup 0 --graph 0 --no-roofline --no-cpu-baseline $*"
 python3 tools/pmc_tool.py "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" _kernel -- $B > gpurun_out/${T}_sq1.txt 2>&1
 python3 tools/pmc_tool.py "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE" _kernel -- $B > gpurun_out/${T}_sq2.txt 2>&1
 python3 - "$T" <<'PY'
