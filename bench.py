@@ -59,7 +59,8 @@ E1 = dict(img_size=64, patch_size=1, in_chans=1, sr_scale=4, embed_dim=60, dense
           growth_rate=30, dense_scale=1., dim_modify_mode='tail', rdb_residual_scale=1., global_res_scale=1.,
           resi_connection='1conv', pre_norm=True, feature_last_operation=True)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3,   # dense peaks, MI355X_MICROARCH.md "Chip-level parameters"
+                    "fp32x3": 1250.0}                # two bf16 MFMAs per fp32 product
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -668,6 +669,22 @@ def _fp32_line(device, x, tgt, B, lib, split, net32):
         # (split: two bf16 MFMAs per fp32 product -> half the dense bf16 peak is this mode's matrix-core ceiling)
         tab = _op_table(lib, rec.calls, 4, 2, (MFMA_PEAK_TFLOPS["bf16"] / 2 if split else MFMA_PEAK_TFLOPS["fp32"]) * 1e12)
         line["kernels"] = tab[:6]
+    if split:
+        # measured live, on the trained-for-a-few-steps weights of this run: the SAME network evaluated in both arithmetics
+        # (the oracle-anchored bound is tests/test_fp32x3_gpu.py; this is the run's own check that the split path is what ran)
+        from rdst_amd import metrics, ops
+        net32.eval()
+        with torch.no_grad():
+            ops.set_f32_split(True)
+            y3 = net32(x).float().cpu().numpy()
+            ops.set_f32_split(False)
+            y1 = net32(x).float().cpu().numpy()
+        net32.train()
+        tg = tgt.float().cpu().numpy()
+        line["vs_exact_fp32"] = {"out_max_abs_diff": float(abs(y3 - y1).max()),
+                                 "psnr_db": [round(metrics.psnr(tg, y3), 6), round(metrics.psnr(tg, y1), 6)],
+                                 "abs_dpsnr_db": float(abs(metrics.psnr(tg, y3) - metrics.psnr(tg, y1))),
+                                 "what": "forward of this line's network on the step's batch in fp32x3 and in exact fp32 (eval mode, same weights), PSNR against the synthetic targets"}
     return line
 
 
