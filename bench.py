@@ -764,16 +764,11 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         print(f"bench.py: in-step K1 timing unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     if ws16:
         traffic, tsrc = _pmc_traffic("wattn16_fwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
-        # round 5: head dims 10 / 20 run one head per workgroup (wattn16_bwd1_kernel), 15 the 16-wave pair kernel: launch-weighted mean
-        t1, t1src = _pmc_traffic("wattn16_bwd1_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
-        t3, t3src = _pmc_traffic("wattn16_bwd3_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
-        n15 = sum(1 for n, a in groups["rdst_wattn_bwd"] if _attn_c(n, a) == 90)
-        nall = len(groups["rdst_wattn_bwd"])
-        if t1 is not None and t3 is not None and nall:
-            t2 = int(((nall - n15) * t1 + n15 * t3) / nall)
-            t2src = f"{nall - n15} launches x wattn16_bwd1_kernel ({t1} B) + {n15} x wattn16_bwd3_kernel ({t3} B): {t1src}"
-        else:
-            t2, t2src = None, (t1src if t1 is None else t3src)
+        # round 5: one head per workgroup (wattn16_bwd1_kernel) for every head dim; the pair kernels remain for the calls without the
+        # forward's statistics
+        t2, t2src = _pmc_traffic("wattn16_bwd1_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
+        if t2 is None:
+            t2, t2src = _pmc_traffic("wattn16_bwd3_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
         kname, bound_note = "rdst_wattn_fwd (K1, window 16: wattn16_fwd_kernel)", "vector ALU (256 x 256 x 6 exponentials per window); priced against HBM as north_star asks"
     else:
         if fused:

@@ -48,10 +48,12 @@ struct W16 {
   static constexpr int HEADS = 6, HPG = HPG_, NG = HEADS / HPG;
   static constexpr int C = HEADS * D;
   static constexpr int GC = HPG * D;                 // channels of a head pair (of the head)
-  static constexpr int PB = GC * 2;                  // bytes of its piece of a row section: 40 / 60 / 80 (20 / 40)
-  static constexpr int GRAN = HPG == 2 ? (D == 10 ? 8 : D == 15 ? 12 : 16) : (D == 10 ? 4 : 8);  // chunk size (D = 15: 12-B chunks, dword aligned)
+  // bytes of its piece of a row section: 40 / 60 / 80 (one head: 20 / 32 / 40 — a head of dim 15 starts on a 2-byte boundary when
+  // its index is odd: its piece is the dword-aligned 32-byte window around its 30 bytes, one channel of a neighbour included)
+  static constexpr int PB = (HPG == 1 && D == 15) ? 32 : GC * 2;
+  static constexpr int GRAN = HPG == 2 ? (D == 10 ? 8 : D == 15 ? 12 : 16) : (D == 20 ? 8 : 4);  // chunk size (D = 15: 12-B chunks, dword aligned)
   static constexpr int CPS = PB / GRAN;              // chunks per piece
-  static constexpr int LDT = HPG == 2 ? (D == 10 ? 48 : 80) : (D == 10 ? 32 : 48);   // LDS row stride (pairs: odd number of 16-B slots)
+  static constexpr int LDT = HPG == 2 ? (D == 10 ? 48 : 80) : (D == 20 ? 48 : 32);   // LDS row stride (pairs: odd number of 16-B slots)
   static constexpr int SEC = 256 * LDT;              // bytes of one staged section
   static constexpr int TROW = 32;                    // floats per staged table row (31 used)
   // floats per head and copy: 31 rows + 16 floats of padding, so that the copies lie 16 banks apart (mod 64).  A 32-lane
@@ -481,11 +483,14 @@ template <int D, int HL, typename PT = float, int HPG = 2>
 __device__ __forceinline__ void w16_bwd_p1s(const W16BCtx& c, f32x16& dq) {
   using CF = W16<D, HPG>;
   constexpr int ldt = CF::LDT;
-  constexpr int c_lo = HL * D, c_hi = c_lo + D;
+  // pair kernels: HL = the head of the pair (its channels follow the other head's, its tables / statistics are the second set);
+  // one head per workgroup: one set, and HL = the first channel of the head inside its staged window (1 for an odd head of dim 15)
+  constexpr int HS = HPG == 1 ? 0 : HL;
+  constexpr int c_lo = HPG == 1 ? HL : HL * D, c_hi = c_lo + D;
   constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
   constexpr int RL = c_lo & ~3;
   const int h = c.sc.h;
-  const LDS_AS float* st = c.stat + HL * 3 * 256 + c.sc.qt * 32 + c.sc.r;
+  const LDS_AS float* st = c.stat + HS * 3 * 256 + c.sc.qt * 32 + c.sc.r;
   const float nl = st[0], nd = st[256];
   Pack16 qb[NT], dob[NT];   // Q and dO^T of the lane's query, the head's channels only
 #pragma unroll
@@ -503,7 +508,7 @@ __device__ __forceinline__ void w16_bwd_p1s(const W16BCtx& c, f32x16& dq) {
   const int xi = c.sc.r & 15;
   const int rx = (c.sc.mcol && xi >= c.sc.thr) ? 1 : 0;
   if (c.sc.masked) onehot4(2 * ((c.sc.mrow && 2 * c.sc.qt + (c.sc.r >> 4) >= c.sc.thr) ? 1 : 0) + rx, c.sc.cbits, h, mQ);
-  const LDS_AS f32x2* tbh = c.sc.tb + HL * (2 * CF::TABF / 2);
+  const LDS_AS f32x2* tbh = c.sc.tb + HS * (2 * CF::TABF / 2);
 #pragma unroll
   for (int v = 0; v < 16; ++v) dq[v] = 0.f;
 #pragma unroll
@@ -571,7 +576,8 @@ template <int D, int HL, int HPG = 2>
 __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
   using CF = W16<D, HPG>;
   constexpr int ldt = CF::LDT;
-  constexpr int c_lo = HL * D, c_hi = c_lo + D;
+  constexpr int HS = HPG == 1 ? 0 : HL;   // (see w16_bwd_p1s)
+  constexpr int c_lo = HPG == 1 ? HL : HL * D, c_hi = c_lo + D;
   constexpr int t_lo = c_lo / 16, t_hi = (c_hi - 1) / 16, NT = t_hi - t_lo + 1;
   constexpr int RL = c_lo & ~3;
   const int h = c.sc.h, r = c.sc.r;
@@ -594,8 +600,8 @@ __device__ __forceinline__ void w16_bwd_p2(const W16BCtx& c) {
   f32x16 dk, dv;
 #pragma unroll
   for (int v = 0; v < 16; ++v) { dk[v] = 0.f; dv[v] = 0.f; }
-  const LDS_AS f32x2* tbh = c.tb2 + HL * CF::TABF;
-  const LDS_AS char* stb = (const LDS_AS char*)(c.stat + HL * 3 * 256) + h * 16;
+  const LDS_AS f32x2* tbh = c.tb2 + HS * CF::TABF;
+  const LDS_AS char* stb = (const LDS_AS char*)(c.stat + HS * 3 * 256) + h * 16;
   typedef float f32x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int qt = 0; qt < 8; ++qt) {
@@ -1089,10 +1095,12 @@ __global__ void __launch_bounds__(1024, 4) wattn16_bwd3_kernel(const W16Args p) 
 #ifndef W16_ABL1
 #define W16_ABL1 0   // ablations of wattn16_bwd1_kernel (tools/abl_build.sh): 1 no pass 1, 2 no pass 2, 4 no table images / row-sum reduce, 8 no global stores
 #endif
-// ---- ONE head per workgroup, two workgroups per CU (D = 10 / 20) ---------------------------------------
+// ---- ONE head per workgroup, two workgroups per CU -----------------------------------------------------
 // wattn16_bwd3_kernel loads, computes and stores in sequence and holds 119-150 KB of LDS: one workgroup per CU, nothing overlaps
 // its load / stage / store skeleton (40 % of its time).  With a single head the staged pieces are 20 / 40 B
-// per row (LDS rows of 32 / 48 B: one / two k-steps per product where the pair's masked packs take two / three), the tables,
+// per row (LDS rows of 32 / 48 B: one / two k-steps per product where the pair's masked packs take two / three; head dim 15: the
+// dword-aligned 32-byte window around the head's 30 bytes — an odd head starts on a 2-byte boundary —, the neighbour's channel in it
+// masked out of every product and never stored), the tables,
 // statistics and d(table) row sums of one head: 67 / 75 KB, so TWO 8-wave workgroups share a CU and one's skeleton runs
 // beside the other's passes.  wave = tile (queries in pass 1, keys in pass 2); the arithmetic is w16_bwd_p1s / w16_bwd_p2 of the
 // pair kernel with the pair's head 0 as the only head.  The natural table (pass 2) is staged over the row sums (pass 1) after
@@ -1123,7 +1131,6 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
   constexpr int ldt = CF::LDT, GRAN = CF::GRAN, CPS = CF::CPS, CPR = 3 * CPS, RPI = 64 / CPR, NI = 32 / RPI;
   constexpr int RPD = 64 / CPS, ND = (32 + RPD - 1) / RPD;
   static_assert(32 % RPI == 0, "a wave stages the 32 token rows of its tile");
-  static_assert(D % 2 == 0, "single heads of dim 10 / 20");
   const WinGeom g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int tl = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wave's tile
@@ -1147,6 +1154,9 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
     win = blockIdx.x / 6;
   }
   const int b = win / nW, wi = win - b * nW, wr = wi / g.nWw, wc = wi - wr * g.nWw;
+  // byte offset of the head's piece inside a row section; head dim 15: the 32-byte window that starts 2 bytes early for odd heads
+  const int par = (D & 1) ? (hd & 1) : 0;
+  const int pofs = (D & 1) ? hd * (2 * D) - 2 * par : hd * CF::PB;
 
   // ---- this wave's 32 token rows of qkv and dO -> registers
   const int lr0 = lane / CPR, ch = lane - lr0 * CPR;
@@ -1158,7 +1168,7 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
   for (int i = 0; i < NI; ++i) {
     const int t = tl * 32 + i * RPI + lr;
     const int64_t tok = win_token16(b, wr, wc, t, g);
-    const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld) + sec * (CF::C * 2) + hd * CF::PB + cw * GRAN;
+    const char* src = reinterpret_cast<const char*>(p.qkv + tok * p.ld) + sec * (CF::C * 2) + pofs + cw * GRAN;
     regs[i] = *reinterpret_cast<const CH*>(src);
   }
   const int dr0 = lane / CPS, dc = lane - dr0 * CPS;
@@ -1168,7 +1178,7 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
     int rr = i * RPD + (dact0 ? dr0 : RPD - 1);
     rr = rr < 32 ? rr : 31;
     const int64_t tok = win_token16(b, wr, wc, tl * 32 + rr, g);
-    const char* src = reinterpret_cast<const char*>(p.dout + tok * p.ldd) + hd * CF::PB + dc * GRAN;
+    const char* src = reinterpret_cast<const char*>(p.dout + tok * p.ldd) + pofs + dc * GRAN;
     dreg[i] = *reinterpret_cast<const CH*>(src);
   }
   // (nlse, -delta) of query tile tl: lane r = query, both lane halves compute the same
@@ -1177,16 +1187,19 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
   float dl = 0.f;
   const float nl_own = p.nlse[tokq * CF::HEADS + hd];
   {
-    const uint32_t* orow = reinterpret_cast<const uint32_t*>(p.o + tokq * p.ldo2 + hd * D);
-    const uint32_t* drow = reinterpret_cast<const uint32_t*>(p.dout + tokq * p.ldd + hd * D);
-    uint32_t ov[D / 2], dv[D / 2];
+    constexpr int NDW = (D & 1) ? 8 : D / 2;   // dwords of the head's piece (dim 15: the 16-channel window)
+    const uint32_t* orow = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.o + tokq * p.ldo2) + pofs);
+    const uint32_t* drow = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.dout + tokq * p.ldd) + pofs);
+    uint32_t ov[NDW], dv[NDW];
 #pragma unroll
-    for (int i = 0; i < D / 2; ++i) { ov[i] = orow[i]; dv[i] = drow[i]; }
+    for (int i = 0; i < NDW; ++i) { ov[i] = orow[i]; dv[i] = drow[i]; }
 #pragma unroll
-    for (int i = 0; i < D / 2; ++i) {
+    for (int i = 0; i < NDW; ++i) {
       dl = fmaf(bf16lo(dv[i]), bf16lo(ov[i]), dl);
       dl = fmaf(bf16hi(dv[i]), bf16hi(ov[i]), dl);
     }
+    if constexpr (D & 1)   // the neighbour's channel in the window: the last one of an even head's, the first one of an odd head's
+      dl -= par ? bf16lo(dv[0]) * bf16lo(ov[0]) : bf16hi(dv[NDW - 1]) * bf16hi(ov[NDW - 1]);
   }
   constexpr float LOG2E = 1.4426950408889634f;
   const float rscale = 1.0f / p.scale;
@@ -1263,7 +1276,8 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) dq[v] = 0.f;
   } else {
-    w16_bwd_p1s<D, 0, bf16, 1>(c, dq);
+    if (par) w16_bwd_p1s<D, (D & 1), bf16, 1>(c, dq);
+    else w16_bwd_p1s<D, 0, bf16, 1>(c, dq);
   }
   __syncthreads();
   if (!(W16_ABL1 & 4)) {  // d(table): one thread per entry adds its <= 16 slots in fixed order
@@ -1308,9 +1322,13 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
     c.Vst = (lds_cp)(Vs + (tl * 32 + r) * ldt);
     c.tb2 = (const LDS_AS f32x2*)((u0 & 1) ? tabN + CF::TABF + (u0 - 1) : tabN + u0);
   }
-  if (!(W16_ABL1 & 2)) w16_bwd_p2<D, 0, 1>(c);
+  if (!(W16_ABL1 & 2)) {
+    if (par) w16_bwd_p2<D, (D & 1), 1>(c);
+    else w16_bwd_p2<D, 0, 1>(c);
+  }
   __syncthreads();   // every wave is done with Q as an operand: the wave's own tile of the query rows takes dQ
-  store_tile_rows<0, 0, D>((lds_cp)(Qs + (tl * 32 + r) * ldt), dq, p.scale, h);
+  if (par) store_tile_rows<0, (D & 1), (D & 1) + D>((lds_cp)(Qs + (tl * 32 + r) * ldt), dq, p.scale, h);
+  else store_tile_rows<0, 0, D>((lds_cp)(Qs + (tl * 32 + r) * ldt), dq, p.scale, h);
   __syncthreads();
   // dQ | dK | dV (in place of Q / K / V) -> global rows of this wave's 32 tokens
 #pragma unroll 1
@@ -1319,21 +1337,29 @@ __global__ void __launch_bounds__(512, 4) wattn16_bwd1_kernel(const W16Args p) {
     const int s3 = k3 / CPS, k = k3 - s3 * CPS;
     const int t = tl * 32 + row;
     const int64_t tok = win_token16(b, wr, wc, t, g);
-    char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq) + s3 * (CF::C * 2) + hd * CF::PB + k * GRAN;
+    char* dst = reinterpret_cast<char*>(p.dqkv + tok * p.ldq) + s3 * (CF::C * 2) + pofs + k * GRAN;
     const char* src = smem + s3 * CF::SEC + (size_t)t * ldt + k * GRAN;
-    if (!(W16_ABL1 & 8)) *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(src);
+    if (W16_ABL1 & 8) continue;
+    if constexpr (D & 1) {   // the dword that holds the neighbour's channel leaves as the one 2-byte half that is this head's
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(src);
+      if (k != (par ? 0 : CPS - 1)) *reinterpret_cast<uint32_t*>(dst) = v;
+      else if (par) *reinterpret_cast<uint16_t*>(dst + 2) = (uint16_t)(v >> 16);
+      else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)v;
+    } else {
+      *reinterpret_cast<CH*>(dst) = chunk_from_lds<CH>(src);
+    }
   }
 }
 
 #ifndef W16_BWD1
-#define W16_BWD1 1   // with the forward's statistics, D = 10 / 20: 1 = one head per workgroup, two workgroups per CU; 0 = the pair kernel below
+#define W16_BWD1 1   // with the forward's statistics: 1 = one head per workgroup, two workgroups per CU; 0 = the pair kernel below
 #endif
 #ifndef W16_BWD3
 #define W16_BWD3 1   // with the forward's statistics: 1 = the 16-wave kernel (both heads of the pair side by side), 0 = the 8-wave kernel with
 #endif               // the streaming first pass
 template <int D>
 int launch_bwd16(const W16Args& p, hipStream_t st) {
-  if constexpr (D != 15) {
+  {
     if (W16_BWD1 && p.nlse && p.o) {
       auto k1 = wattn16_bwd1_kernel<D>;
       constexpr size_t smem1 = W16B1<D>::SMEM;
