@@ -594,8 +594,10 @@ def extra_config(name, device, lib, e1_ms, steps=5):
             ms = _replay_calls(lib, calls, 2)
             nbytes = sum(_alg(n, a, 2)[0] for n, a in calls) / len(calls)
             ach = nbytes / (ms * 1e-3) / 1e9
+            tr_b, tr_src = _pmc_traffic("wattn16_fwd_kernel" if key == "roofline" else "wattn16_bwd1_kernel", ["wattn16_mfma.hip", "wattn_hd.h"])
             line[key] = {"kernel": op + " (window 16)", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * ms, 2), "launches": len(calls)}
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * ms, 2), "launches": len(calls),
+                         "traffic": tr_b, "traffic_source": tr_src}
     del tr, net, rec
     torch.cuda.empty_cache()
     if name == "ws16":   # the same configuration in the reference's own arithmetic (exact-fp32 matrix-core kernels, wattn16_f32.hip)
