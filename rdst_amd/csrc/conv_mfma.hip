@@ -393,7 +393,9 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
                   u.x = pack_bf16x2(o0, o1); u.y = pack_bf16x2(o2, o3);
                   *reinterpret_cast<u32x2_a4*>(dst) = u;
                 } else {
-                  dst[0] = from_f32<T>(o0); dst[1] = from_f32<T>(o1); dst[2] = from_f32<T>(o2); dst[3] = from_f32<T>(o3);
+                  u32x4_a4 u;
+                  u.x = __float_as_uint(o0); u.y = __float_as_uint(o1); u.z = __float_as_uint(o2); u.w = __float_as_uint(o3);
+                  *reinterpret_cast<u32x4_a4*>(dst) = u;
                 }
               } else {
                 const float o[4] = {o0, o1, o2, o3};
@@ -427,6 +429,15 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
                 const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb);
                 g8[0] = bf16lo(u.x); g8[1] = bf16hi(u.x); g8[2] = bf16lo(u.y); g8[3] = bf16hi(u.y);
                 g8[4] = bf16lo(u.z); g8[5] = bf16hi(u.z); g8[6] = bf16lo(u.w); g8[7] = bf16hi(u.w);
+              } else if (!BF && cb + 12 <= p.Nout && (reinterpret_cast<uintptr_t>(rowp) & 3) == 0) {
+                // fp32: the lane's two runs of 4 channels as 16-byte chunks of its dword-aligned row (element by element every
+                // load instruction touched 64 cache lines for 4 bytes each)
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                  const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb + 8 * q4);
+                  g8[4 * q4] = __uint_as_float(u.x); g8[4 * q4 + 1] = __uint_as_float(u.y);
+                  g8[4 * q4 + 2] = __uint_as_float(u.z); g8[4 * q4 + 3] = __uint_as_float(u.w);
+                }
               } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g8[e] = colof(e) < p.Nout ? to_f32<T>(rowp[colof(e)]) : 0.f;
@@ -459,6 +470,14 @@ __global__ void __launch_bounds__(512) conv_rows_kernel(const ConvArgs<T> p) {
               u.x = pack_bf16x2(c8[0], c8[1]); u.y = pack_bf16x2(c8[2], c8[3]);
               u.z = pack_bf16x2(c8[4], c8[5]); u.w = pack_bf16x2(c8[6], c8[7]);
               *reinterpret_cast<u32x4_a4*>(yrow + cb) = u;
+            } else if (!BF && cb + 12 <= p.Nout && (reinterpret_cast<uintptr_t>(yrow) & 3) == 0) {
+#pragma unroll
+              for (int q4 = 0; q4 < 2; ++q4) {
+                u32x4_a4 u;
+                u.x = __float_as_uint(c8[4 * q4]); u.y = __float_as_uint(c8[4 * q4 + 1]);
+                u.z = __float_as_uint(c8[4 * q4 + 2]); u.w = __float_as_uint(c8[4 * q4 + 3]);
+                *reinterpret_cast<u32x4_a4*>(yrow + cb + 8 * q4) = u;
+              }
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) if (colof(e) < p.Nout) yrow[colof(e)] = from_f32<T>(c8[e]);

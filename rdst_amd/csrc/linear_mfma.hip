@@ -447,10 +447,19 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
                 for (int e = 0; e < 8; ++e) g8[e] = cb + e < p.Nout ? to_f32<T>(rowp[cb + e]) : 0.f;
               }
             } else {
+              // fp32: the lane's two runs of 4 columns as 16-byte chunks (a lane reading its own row element by element made
+              // every load instruction touch 64 cache lines for 4 bytes each)
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const int c = cb + (e & 3) + 8 * (e >> 2);
-                g8[e] = c < p.Nout ? to_f32<T>(rowp[c]) : 0.f;
+              for (int q4 = 0; q4 < 2; ++q4) {
+                const int c = cb + 8 * q4;
+                if (vec && c + 4 <= p.Nout) {
+                  const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + c);
+                  g8[4 * q4] = __uint_as_float(u.x); g8[4 * q4 + 1] = __uint_as_float(u.y);
+                  g8[4 * q4 + 2] = __uint_as_float(u.z); g8[4 * q4 + 3] = __uint_as_float(u.w);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) g8[4 * q4 + e] = c + e < p.Nout ? to_f32<T>(rowp[c + e]) : 0.f;
+                }
               }
             }
           };
@@ -500,7 +509,7 @@ __global__ void __launch_bounds__(512) lin_mfma_kernel(const LinArgs<T> p) {
 #pragma unroll
             for (int q4 = 0; q4 < 2; ++q4) {
               const int c = cb + 8 * q4;
-              if (c + 4 <= p.Nout && (reinterpret_cast<uintptr_t>(yrow + c) & 15) == 0) {
+              if (c + 4 <= p.Nout && y_vec) {   // (16-byte stores of dword-aligned rows)
                 u32x4_a4 u;
                 u.x = __float_as_uint(c8[4 * q4]); u.y = __float_as_uint(c8[4 * q4 + 1]);
                 u.z = __float_as_uint(c8[4 * q4 + 2]); u.w = __float_as_uint(c8[4 * q4 + 3]);
@@ -897,6 +906,15 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T>
         const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb);
         g8[0] = bf16lo(u.x); g8[1] = bf16hi(u.x); g8[2] = bf16lo(u.y); g8[3] = bf16hi(u.y);
         g8[4] = bf16lo(u.z); g8[5] = bf16hi(u.z); g8[6] = bf16lo(u.w); g8[7] = bf16hi(u.w);
+      } else if (!BF && cb + 12 <= K && (reinterpret_cast<uintptr_t>(rowp) & 3) == 0) {
+        // fp32: the two 4-channel runs of the lane as 16-byte chunks of its dword-aligned row (element by element every load
+        // instruction touched 64 cache lines for 4 bytes each)
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+          const u32x4_a4 u = *reinterpret_cast<const u32x4_a4*>(rowp + cb + 8 * q4);
+          g8[4 * q4] = __uint_as_float(u.x); g8[4 * q4 + 1] = __uint_as_float(u.y);
+          g8[4 * q4 + 2] = __uint_as_float(u.z); g8[4 * q4 + 3] = __uint_as_float(u.w);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -968,6 +986,14 @@ __global__ void __launch_bounds__(512) lin_dgrad_ln2_kernel(const LnDgradArgs<T>
           u.x = pack_bf16x2(o8[0], o8[1]); u.y = pack_bf16x2(o8[2], o8[3]);
           u.z = pack_bf16x2(o8[4], o8[5]); u.w = pack_bf16x2(o8[6], o8[7]);
           *reinterpret_cast<u32x4_a4*>(drow + cb) = u;
+        } else if (!BF && cb + 12 <= K && (reinterpret_cast<uintptr_t>(drow) & 3) == 0) {
+#pragma unroll
+          for (int q4 = 0; q4 < 2; ++q4) {
+            u32x4_a4 u;
+            u.x = __float_as_uint(o8[4 * q4]); u.y = __float_as_uint(o8[4 * q4 + 1]);
+            u.z = __float_as_uint(o8[4 * q4 + 2]); u.w = __float_as_uint(o8[4 * q4 + 3]);
+            *reinterpret_cast<u32x4_a4*>(drow + cb + 8 * q4) = u;
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
