@@ -1165,7 +1165,10 @@ int conv_dgrad_mfma(const T* X, int64_t ldx, int in_act, const float* Wc, const 
   if (mfma_disabled() || !rows_ok<T>(dYp, lddyp) || g.Cout < 8) return RDST_ENOTSUP;
   // fp32, more than 128 output channels (the 60 -> 240 convs of the upsampler): launches over slices of the output
   // channels, the gradient is linear in dY; every launch after the first accumulates onto dX in place
-  const int nsl = sizeof(T) == 4 ? (g.Cout + 127) / 128 : 1;
+  // (slices of <= 64 channels where the image width allows the row-stripe kernel: its nine-tap weight image of a 120-channel slice
+  // does not fit the LDS and the launch fell back to the generic kernel with fragment-shaped global loads: 631 us per launch)
+  const bool rows_form = g.ks == 3 && g.pad == 1 && g.W % 32 == 0;
+  const int nsl = sizeof(T) != 4 ? 1 : (rows_form && g.Cout > 192 && g.Cout % 4 == 0) ? 4 : (g.Cout + 127) / 128;
   if (nsl > 1 && g.Cout % nsl != 0) return RDST_ENOTSUP;
   const int cs = g.Cout / nsl;
   for (int i = 0; i < nsl; ++i) {
