@@ -635,10 +635,7 @@ def fp32_line(device, x, tgt, B, lib, split=False):
     from rdst_amd import ops
     from rdst_amd.trainer import DPTrainStep
     net32 = build_net(device, "fp32x3" if split else torch.float32)
-    try:
-        return _fp32_line(device, x, tgt, B, lib, split, net32)
-    finally:
-        ops.set_f32_split(False)
+    return _fp32_line(device, x, tgt, B, lib, split, net32)
 
 
 def _fp32_line(device, x, tgt, B, lib, split, net32):
@@ -674,13 +671,15 @@ def _fp32_line(device, x, tgt, B, lib, split, net32):
     if split:
         # measured live, on the trained-for-a-few-steps weights of this run: the SAME network evaluated in both arithmetics
         # (the oracle-anchored bound is tests/test_fp32x3_gpu.py; this is the run's own check that the split path is what ran)
-        from rdst_amd import metrics, ops
+        # (the mode is the module's own: an eval COPY in exact fp32 next to the live fp32x3 trainer, no switch flipped)
+        import copy
+        from rdst_amd import metrics
         net32.eval()
+        net_exact = copy.deepcopy(net32).set_compute_dtype("fp32")
         with torch.no_grad():
-            ops.set_f32_split(True)
             y3 = net32(x).float().cpu().numpy()
-            ops.set_f32_split(False)
-            y1 = net32(x).float().cpu().numpy()
+            y1 = net_exact(x).float().cpu().numpy()
+        del net_exact
         net32.train()
         tg = tgt.float().cpu().numpy()
         line["vs_exact_fp32"] = {"out_max_abs_diff": float(abs(y3 - y1).max()),

@@ -434,11 +434,8 @@ int launch_c3(C3Args& p, int ctile0, hipStream_t st, const char* what) {
   p.nstrips = (int)ns;
   const int grid = ns < 256 ? (int)ns : 256;
   auto kern = conv3_kernel<K, CW, NT, KSPLIT, PSLOTS, RPS, UNSHUF, PSTORE>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    attr = true;
-  }
+  // (per launch: the attribute is per DEVICE, a process-wide "done" flag would leave a second GPU without it)
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
   p.stamps = rdst_stamps_begin("RDST_C3_STAMPS", grid, 8, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), CF::SMEM, st, p);
   rdst_stamps_end(what, p.stamps, grid, 8, st);   // 0 weights, 1 first rows, 2 dma issue, 3 mfma, 4 exchange, 5 epilogue, 6 barrier

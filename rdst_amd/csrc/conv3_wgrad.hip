@@ -276,11 +276,8 @@ int launch_w3(W3Args& p, float s, float* dW, float* dbias, hipStream_t st, const
   p.npg = ns < want ? (int)ns : want;
   const int grid = p.npg * CF::ROLES;
   auto kern = conv3_wgrad_kernel<CI, CO, UNSHUF>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    attr = true;
-  }
+  // (per launch: the attribute is per DEVICE, a process-wide "done" flag would leave a second GPU without it)
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), CF::SMEM, st, p);
   if (int rc = rdst_launch_status(what)) return rc;
   const int tot = CF::ROLES * CF::SLABF / 2;

@@ -317,11 +317,8 @@ int launch_l3(L3Args& p, hipStream_t st, const char* what) {
   int grid = (p.ntiles + CF::NBUF - 1) / CF::NBUF;
   if (grid > 256 * CF::WGCU) grid = 256 * CF::WGCU;
   auto kern = lin3_kernel<K, NT, LN, RES>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    attr = true;
-  }
+  // (per launch: the attribute is per DEVICE, a process-wide "done" flag would leave a second GPU without it)
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CF::NTHR), CF::SMEM, st, p);
   return rdst_launch_status(what);
 }

@@ -362,11 +362,8 @@ int launch_m3(M3Args& p, hipStream_t st) {
   if (grid > 256 * CF::WGCU) grid = 256 * CF::WGCU;
   if (grid < 1) grid = 1;
   auto kern = mlp3_fwd_kernel<C>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    attr = true;
-  }
+  // (per launch: the attribute is per DEVICE, a process-wide "done" flag would leave a second GPU without it)
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
   p.stamps = rdst_stamps_begin("RDST_M3_STAMPS", grid, 8, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CF::NTHR), CF::SMEM, st, p);
   rdst_stamps_end("mlp3_fwd: 0 wait+B0, 1 stats, 2 phase 1, 3 wait+B2, 4 phase 2, 5 B3+issue", p.stamps, grid, 8, st);

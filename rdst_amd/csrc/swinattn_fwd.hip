@@ -668,11 +668,8 @@ int launch_sa(SAArgs& p, hipStream_t st) {
   constexpr int WGCU = SA_NW == 6 ? 2 : 1;   // workgroups per CU
   static_assert(WGCU * CF::SMEM <= 160 * 1024, "LDS per CU");
   auto kern = swinattn_fwd_kernel<D>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-    attr = true;
-  }
+  // (per launch: the attribute is per DEVICE, a process-wide "done" flag would leave a second GPU without it)
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
   const int64_t nwin = (int64_t)p.g.B * p.g.nWh * p.g.nWw;
   int64_t G = 256 * WGCU;
   if (G > nwin) G = nwin;

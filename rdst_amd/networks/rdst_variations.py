@@ -314,7 +314,7 @@ class RDSTSR(nn.Module):
         m_tail.append(default_conv(self.n_feats, self.input_channel, 3))
         self.tail = nn.Sequential(*m_tail)
 
-        self.compute_dtype = torch.float32
+        self.compute_dtype, self.compute_code = torch.float32, ops.F32
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -335,19 +335,10 @@ class RDSTSR(nn.Module):
         return {'relative_position_bias_table'}
 
     def set_compute_dtype(self, dtype):
-        """torch.float32 = parity mode (default); torch.bfloat16 = throughput mode (bf16 activations,
-        fp32 accumulation, fp32 parameters and gradients)."""
-        if dtype == "fp32x3":      # fp32 tensors, split-bf16 GEMMs (ops.F32_SPLIT: a per-process switch)
-            ops.set_f32_split(True)
-            dtype = torch.float32
-        elif dtype in ("fp32", torch.float32):
-            ops.set_f32_split(False)
-            dtype = torch.float32
-        elif dtype == "bf16":
-            dtype = torch.bfloat16
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be torch.float32 ('fp32'), 'fp32x3' or torch.bfloat16 ('bf16')")
-        self.compute_dtype = dtype
+        """torch.float32 / 'fp32' = parity mode (default); 'fp32x3' = fp32 tensors, split-bf16 GEMMs; torch.bfloat16 /
+        'bf16' = throughput mode (bf16 activations, fp32 accumulation, fp32 parameters and gradients).  The mode is this
+        module's own (``compute_code``): it does not touch any other network of the process."""
+        self.compute_dtype, self.compute_code = ops.resolve_compute_dtype(dtype)
         return self
 
     def forward_features_rows(self, feat):
@@ -379,13 +370,15 @@ class RDSTSR(nn.Module):
 
     def forward_features(self, x):
         """NCHW feature map -> NCHW (API parity with the reference's forward_features)."""
-        rows = ops.nchw_to_rows(x, self.compute_dtype)
-        t = self.forward_features_rows(rows)
-        B, H, W, E = rows.shape
-        return ops.rows_to_nchw(_norm_only(t, self.norm).view(B, H, W, E))
+        with ops.compute_scope(self.compute_code):
+            rows = ops.nchw_to_rows(x, self.compute_dtype)
+            t = self.forward_features_rows(rows)
+            B, H, W, E = rows.shape
+            return ops.rows_to_nchw(_norm_only(t, self.norm).view(B, H, W, E))
 
     def forward(self, x, sr_scale=None):
-        with ops.pack_scope(self):    # the packed weight images of all layers: one batched pack per forward
+        # the packed weight images of all layers: one batched pack per forward; the arithmetic of THIS network's ops
+        with ops.compute_scope(self.compute_code), ops.pack_scope(self):
             return self._forward(x, sr_scale)
 
     def _forward(self, x, sr_scale=None):
@@ -471,6 +464,10 @@ class RDSTSR_N(RDSTSR):
             self.bottleneck.apply(self._init_weights)
 
     def forward(self, x, sr_scale=None):
+        with ops.compute_scope(self.compute_code):
+            return self._forward_n(x, sr_scale)
+
+    def _forward_n(self, x, sr_scale=None):
         rows = ops.nchw_to_rows(x, self.compute_dtype)
         rows = self.sub_mean.forward_rows(rows)
         feat = self.head.forward_rows(rows)

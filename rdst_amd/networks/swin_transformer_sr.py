@@ -511,7 +511,7 @@ class SwinIR(nn.Module):
             self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
         else:
             self.conv_last = Conv2d(embed_dim, num_out_ch, 3, 1, 1)
-        self.compute_dtype = torch.float32
+        self.compute_dtype, self.compute_code = torch.float32, ops.F32
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -532,15 +532,8 @@ class SwinIR(nn.Module):
         return {'relative_position_bias_table'}
 
     def set_compute_dtype(self, dtype):
-        if dtype == "fp32x3":      # fp32 tensors, split-bf16 GEMMs (ops.F32_SPLIT: a per-process switch)
-            ops.set_f32_split(True)
-            dtype = torch.float32
-        elif dtype in ("fp32", torch.float32):
-            ops.set_f32_split(False)
-            dtype = torch.float32
-        elif dtype == "bf16":
-            dtype = torch.bfloat16
-        self.compute_dtype = dtype
+        """torch.float32 / 'fp32' exact, 'fp32x3' split-bf16 GEMMs on fp32 tensors, torch.bfloat16 / 'bf16': this module's own mode."""
+        self.compute_dtype, self.compute_code = ops.resolve_compute_dtype(dtype)
         return self
 
     def _features_rows(self, feat):
@@ -556,6 +549,10 @@ class SwinIR(nn.Module):
         return _norm_only(t, self.norm).view(B, H, W, E)
 
     def forward(self, x):
+        with ops.compute_scope(self.compute_code):
+            return self._forward(x)
+
+    def _forward(self, x):
         self.mean = self.mean.type_as(x)
         xin = (x - self.mean) * self.img_range
         rows = ops.nchw_to_rows(xin, self.compute_dtype)

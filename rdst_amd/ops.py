@@ -19,24 +19,73 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_LEAKY001, ACT_LEAKY02, ACT_NONE, BF16, F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_LEAKY001, ACT_LEAKY02, ACT_NONE, BF16, F32, F32X3  # noqa: F401
 
 
 # The "fp32x3" compute mode (set_compute_dtype("fp32x3") on a network): fp32 tensors everywhere, but the GEMM-shaped kernels
 # take their operands as two bf16 terms (16 mantissa bits) and run on the bf16 matrix cores (RDST_F32X3, csrc/mfma.h:
-# Mma<float, true>) — the parity mode that holds the 4-decimal PSNR bar at a third of the exact-fp32 cost.  The switch is
-# per process (the mode of a step must not change between its forward and its backward); F32_SPLIT = False is exact fp32.
+# Mma<float, true>) — the parity mode that holds the 4-decimal PSNR bar at a fraction of the exact-fp32 cost.
+# The mode belongs to the MODULE: a network keeps ``compute_code`` (F32 / F32X3 / BF16) next to ``compute_dtype`` and its
+# forward runs inside ``compute_scope(code)``; every autograd Function reads the code ONCE, in its forward, and keeps it in
+# its ctx, so a backward never looks at the scope or at the default below (two networks in different modes can interleave
+# their forwards and backwards freely).  F32_SPLIT is only the DEFAULT for fp32 tensors outside any scope (op-level calls).
 F32_SPLIT = False
+_scope_tls = threading.local()
 
 
 def set_f32_split(on: bool) -> None:
+    """Default arithmetic of fp32 ops called OUTSIDE a network forward (op-level tests, tools); networks carry their own."""
     global F32_SPLIT
     F32_SPLIT = bool(on)
 
 
+class compute_scope:
+    """``with ops.compute_scope(code):`` — the fp32 arithmetic (F32 exact / F32X3 split) of every op called inside, on this
+    thread; ``None`` leaves the enclosing scope (or the default) in force.  Scopes nest."""
+
+    def __init__(self, code: Optional[int]):
+        if code not in (None, F32, _lib.F32X3, BF16):
+            raise ValueError(f"rdst_amd: bad compute code {code!r}")
+        self.code = code
+
+    def __enter__(self):
+        self.prev = getattr(_scope_tls, "code", None)
+        if self.code is not None:
+            _scope_tls.code = self.code
+        return self
+
+    def __exit__(self, *exc):
+        _scope_tls.code = self.prev
+        return False
+
+
+def resolve_compute_dtype(dtype):
+    """set_compute_dtype's argument -> (activation dtype, compute code): torch.float32 / 'fp32' = exact parity mode,
+    'fp32x3' = fp32 tensors with split-bf16 GEMMs, torch.bfloat16 / 'bf16' = throughput mode."""
+    if dtype == "fp32x3":
+        return torch.float32, _lib.F32X3
+    if dtype in ("fp32", torch.float32):
+        return torch.float32, F32
+    if dtype in ("bf16", torch.bfloat16):
+        return torch.bfloat16, BF16
+    raise ValueError("compute dtype must be torch.float32 ('fp32'), 'fp32x3' or torch.bfloat16 ('bf16')")
+
+
 def _dtype_code(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
-        return _lib.F32X3 if F32_SPLIT else F32
+        sc = getattr(_scope_tls, "code", None)
+        if sc is None or sc == BF16:   # (a bf16 network's fp32 side tensors: the image boundary ops, exact)
+            return _lib.F32X3 if (sc is None and F32_SPLIT) else F32
+        return sc
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"rdst_amd: unsupported activation dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _elt_code(t: torch.Tensor) -> int:
+    """Element type alone (layout-only ops: no arithmetic mode to choose)."""
+    if t.dtype == torch.float32:
+        return F32
     if t.dtype == torch.bfloat16:
         return BF16
     raise TypeError(f"rdst_amd: unsupported activation dtype {t.dtype} (float32 or bfloat16)")
@@ -177,7 +226,8 @@ class PackPlan:
 
     @staticmethod
     def signature(owner):
-        return (getattr(owner, "compute_dtype", None),) + tuple((p.data_ptr(), p.dtype) for p in owner.parameters())
+        return (getattr(owner, "compute_dtype", None), getattr(owner, "compute_code", None)) + tuple(
+            (p.data_ptr(), p.dtype) for p in owner.parameters())
 
     def finalize(self, device, owner=None):
         if not self.specs:
@@ -311,22 +361,23 @@ class _WindowAttention(torch.autograd.Function):
         msk = _param(mask)
         nw = 0 if msk is None else msk.shape[0]
         out = torch.empty(qkv.shape[:-1] + (C,), dtype=qkv.dtype, device=qkv.device)
+        code = _dtype_code(qkv)
         if attn_drop > 0.0:   # training-mode attention dropout: the shape-generic kernels with a counter-based mask
             _lib.check(lib.rdst_wattn_fwd_drop(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
-                                               W, C, heads, ws, shift, float(scale), _dtype_code(qkv), float(attn_drop),
+                                               W, C, heads, ws, shift, float(scale), code, float(attn_drop),
                                                seed.data_ptr(), _stream()), "rdst_wattn_fwd_drop")
         else:
             _lib.check(lib.rdst_wattn_fwd(qkv_r.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, out.data_ptr(), C, B, H,
-                                          W, C, heads, ws, shift, float(scale), _dtype_code(qkv), _stream()),
+                                          W, C, heads, ws, shift, float(scale), code, _stream()),
                        "rdst_wattn_fwd")
         ctx.save_for_backward(qkv_r, tab, msk, seed)
-        ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw, float(attn_drop))
+        ctx.geom = (B, H, W, C, heads, ws, shift, float(scale), ld, nw, float(attn_drop), code)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, tab, msk, seed = ctx.saved_tensors
-        B, H, W, C, heads, ws, shift, scale, ld, nw, attn_drop = ctx.geom
+        B, H, W, C, heads, ws, shift, scale, ld, nw, attn_drop, code = ctx.geom
         lib = _lib.load()
         dout_r, ldd = _rows(dout)
         dqkv = torch.empty(qkv.shape[:-1] + (3 * C,), dtype=qkv.dtype, device=qkv.device)
@@ -338,12 +389,12 @@ class _WindowAttention(torch.autograd.Function):
         if attn_drop > 0.0:
             _lib.check(lib.rdst_wattn_bwd_drop(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
                                                dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
-                                               C, heads, ws, shift, scale, _dtype_code(qkv), attn_drop, seed.data_ptr(),
+                                               C, heads, ws, shift, scale, code, attn_drop, seed.data_ptr(),
                                                _stream()), "rdst_wattn_bwd_drop")
         else:
             _lib.check(lib.rdst_wattn_bwd(qkv.data_ptr(), ld, tab.data_ptr(), _ptr(msk), nw, dout_r.data_ptr(), ldd,
                                           dqkv.data_ptr(), 3 * C, dtable.data_ptr(), wsp.data_ptr(), nbytes, B, H, W,
-                                          C, heads, ws, shift, scale, _dtype_code(qkv), _stream()), "rdst_wattn_bwd")
+                                          C, heads, ws, shift, scale, code, _stream()), "rdst_wattn_bwd")
         _ReduceBatch.settle(lib)
         return dqkv, dtable, None, None, None, None, None, None, None, None, None
 
@@ -454,13 +505,13 @@ class _LnLinear(torch.autograd.Function):
                                           float(out_scale), code, _stream()), "rdst_ln_linear_fwd")
         ctx.save_for_backward(x_r, lw, lb, w, stats)
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
-        ctx.meta = (M, K, N, ldx, int(in_act), float(out_scale), bias is not None, residual is not None)
+        ctx.meta = (M, K, N, ldx, int(in_act), float(out_scale), bias is not None, residual is not None, code)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, lw, lb, w, stats = ctx.saved_tensors
-        M, K, N, ldx, in_act, out_scale, has_bias, has_res = ctx.meta
+        M, K, N, ldx, in_act, out_scale, has_bias, has_res, code = ctx.meta
         lib = _lib.load()
         dy_r, lddy = _rows(dy)
         need = ctx.needs_input_grad
@@ -472,7 +523,7 @@ class _LnLinear(torch.autograd.Function):
         db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None
               else _fresh_grad(torch.empty(N, dtype=torch.float32, device=dev))) if (has_bias and need[4]) else None
         _linear_bwd_call(lib, x, ldx, lw, lb, stats, in_act, w, dy_r, lddy, dx, K, None, 0, dw, db, dlw, dlb, M, K, N,
-                         out_scale, _dtype_code(x), dev, keep=_ReduceBatch.keep if _ReduceBatch.depth > 0 else None)
+                         out_scale, code, dev, keep=_ReduceBatch.keep if _ReduceBatch.depth > 0 else None)
         _ReduceBatch.settle(lib)
         dres = dy if (has_res and need[5]) else None
         return dx, dlw, dlb, dw, db, dres, None, None, None
@@ -947,13 +998,13 @@ class _ConvRows(torch.autograd.Function):
         ctx.bias_ref = b   # only its address is used in backward (destination lookup of d(bias))
         ctx.save_for_backward(x_r, w)
         ctx.meta = (B, H, W, Cin, Cout, k, ldx, int(in_act), float(out_scale), r, bias is not None,
-                    residual is not None)
+                    residual is not None, code)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        B, H, W, Cin, Cout, k, ldx, in_act, out_scale, r, has_bias, has_res = ctx.meta
+        B, H, W, Cin, Cout, k, ldx, in_act, out_scale, r, has_bias, has_res, code = ctx.meta
         lib = _lib.load()
         dy_r, lddy = _rows(dy)
         need = ctx.needs_input_grad
@@ -963,7 +1014,6 @@ class _ConvRows(torch.autograd.Function):
         db = (_grad_like(ctx.bias_ref) if ctx.bias_ref is not None
               else _fresh_grad(torch.empty(Cout, dtype=torch.float32, device=dev))) if (has_bias and need[2]) else None
         nbytes = lib.rdst_conv_bwd_workspace(B, H, W, Cin, Cout, k)
-        code = _dtype_code(x)
 
         def call(dx_, dw_, db_, wsp_):
             _lib.check(lib.rdst_conv_bwd(x.data_ptr(), ldx, in_act, w.data_ptr(), dy_r.data_ptr(), lddy, _ptr(dx_), Cin,
@@ -1005,7 +1055,7 @@ class _NchwToRows(torch.autograd.Function):
         B, C, H, W = x.shape
         xs = x.detach().float().contiguous()
         rows = torch.empty((B, H, W, C), dtype=dtype, device=x.device)
-        _lib.check(lib.rdst_nchw_to_rows(xs.data_ptr(), rows.data_ptr(), C, B, C, H, W, _dtype_code(rows), _stream()),
+        _lib.check(lib.rdst_nchw_to_rows(xs.data_ptr(), rows.data_ptr(), C, B, C, H, W, _elt_code(rows), _stream()),
                    "rdst_nchw_to_rows")
         return rows
 
@@ -1023,7 +1073,7 @@ class _RowsToNchw(torch.autograd.Function):
         r, ld = _rows(rows)
         ctx.dtype = rows.dtype
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=rows.device)
-        _lib.check(lib.rdst_rows_to_nchw(r.data_ptr(), ld, out.data_ptr(), B, C, H, W, _dtype_code(rows), _stream()),
+        _lib.check(lib.rdst_rows_to_nchw(r.data_ptr(), ld, out.data_ptr(), B, C, H, W, _elt_code(rows), _stream()),
                    "rdst_rows_to_nchw")
         return out
 
@@ -1040,7 +1090,7 @@ class _Upsample2(torch.autograd.Function):
         B, H, W, C = rows.shape
         r, ld = _rows(rows)
         out = torch.empty((B, 2 * H, 2 * W, C), dtype=rows.dtype, device=rows.device)
-        _lib.check(lib.rdst_upsample2_fwd(r.data_ptr(), ld, out.data_ptr(), C, B, H, W, C, _dtype_code(rows), _stream()),
+        _lib.check(lib.rdst_upsample2_fwd(r.data_ptr(), ld, out.data_ptr(), C, B, H, W, C, _elt_code(rows), _stream()),
                    "rdst_upsample2_fwd")
         ctx.geom = (B, H, W, C)
         return out
@@ -1051,7 +1101,7 @@ class _Upsample2(torch.autograd.Function):
         B, H, W, C = ctx.geom
         d, ld = _rows(dy)
         dx = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
-        _lib.check(lib.rdst_upsample2_bwd(d.data_ptr(), ld, dx.data_ptr(), C, B, H, W, C, _dtype_code(dy), _stream()),
+        _lib.check(lib.rdst_upsample2_bwd(d.data_ptr(), ld, dx.data_ptr(), C, B, H, W, C, _elt_code(dy), _stream()),
                    "rdst_upsample2_bwd")
         return dx
 

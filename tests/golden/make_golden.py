@@ -227,9 +227,9 @@ def run_model_case(rv, st, name):
     if ONLY is not None and name not in ONLY:
         return
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from util import MODEL_CASES, seeded_fill
+    from util import MODEL_CASES, model_kwargs, seeded_fill
     kind, kw, xshape, seed, train = MODEL_CASES[name]
-    net = (st.SwinIR if kind == "swinir" else rv.RDSTSR_N)(**kw)
+    net = {"swinir": st.SwinIR, "rdstsr_n": rv.RDSTSR_N, "rdstsr": rv.RDSTSR}[kind](**model_kwargs(kw))
     net.load_state_dict(seeded_fill(net.state_dict(), seed), strict=True)
     layout = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
     with open(os.path.join(HERE, f"state_dict_{name}.json"), "w") as f:
@@ -299,6 +299,10 @@ def main():
                  grad_keys=["body.0.conv.0.weight", "body.0.body.0.tail.0.weight"])
     # --- "next" rows: SwinIR baseline and the RDSTSR_N bottleneck variant ----------------------------
     for name in ("swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "swinir_nearest_x4", "rdstsr_n_mlp", "rdstsr_n_conv"):
+        run_model_case(rv, st, name)
+    # --- constructor branches of RDSTSR that make_RDSTSR can select ('head' dim modifier pre- / post-norm, nn.Identity
+    # norms, absolute position embedding, qk_scale): fixtures straight from the reference, every gradient elementwise
+    for name in ("rdstsr_head_pre", "rdstsr_head_post", "rdstsr_identity_norm", "rdstsr_ape", "rdstsr_qk_scale"):
         run_model_case(rv, st, name)
 
 

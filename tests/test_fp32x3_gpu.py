@@ -17,7 +17,7 @@ DEV = "cuda:0"
 @pytest.fixture(autouse=True)
 def _exact_after():
     yield
-    ops.set_f32_split(False)       # the switch is per process: leave the exact mode behind for the other tests
+    ops.set_f32_split(False)       # the op-level tests below set the DEFAULT of ops called outside a network: leave exact behind
 
 
 def _e1_step(mode, B=4, seed=11):
@@ -42,7 +42,7 @@ def test_e1_fp32x3_bench_shape_psnr_equal_to_4_decimals():
     every gradient to 4e-3 relative L2 (measured worst 1.6e-3: the first block's relative-position table, a 225 x 6 tensor whose
     gradient is a difference of large sums; the exact mode has 1e-3 there) and the total gradient to 2e-4 (measured 9e-5)."""
     cfg, sd, net, x, tgt, yc, loss = _e1_step("fp32x3")
-    assert ops.F32_SPLIT
+    assert net.compute_code == ops.F32X3 and not ops.F32_SPLIT      # the mode is the module's, the process default untouched
     params = dict(net.named_parameters())
     osd = {k: (v.clone().requires_grad_(True) if (k in params and params[k].requires_grad) else v) for k, v in sd.items()}
     oy = O.rdstsr_forward(x, osd, cfg)
@@ -69,7 +69,6 @@ def test_fp32x3_differs_from_exact_fp32_and_stays_close():
     representation: out max|d| <= 2e-4 of a [0, 1]-ranged image against exact fp32 on the same weights and inputs."""
     *_, y3, l3 = _e1_step("fp32x3", B=2)
     *_, y1, l1 = _e1_step("fp32", B=2)
-    assert not ops.F32_SPLIT
     d = (y3 - y1).abs().max().item()
     print(f"\nfp32x3 vs exact fp32: out max|d| {d:.2e}, loss {l3:.7f} vs {l1:.7f}")
     assert 0.0 < d <= 2e-4
@@ -235,3 +234,48 @@ def test_network_fp32x3_vs_reference_fixture(name):
     for k, l2 in zip([str(k) for k in g["grad_keys"]], g["grad_l2"]):
         assert abs(params[k].grad.double().norm().item() - l2) <= 1e-3 * max(l2, 1e-9), k
     assert worst <= 5e-3
+
+
+def test_two_networks_in_different_modes_interleave_bit_for_bit():
+    """The compute mode is per MODULE (compute_code + ops.compute_scope, saved in every Function's ctx): an fp32x3 network and an
+    exact-fp32 network run alternately in one process — the forward of one BETWEEN the forward and the backward of the other,
+    set_compute_dtype called on one while the other has a graph of pending backward nodes — and each must reproduce its own
+    single-mode outputs and gradients bit for bit.  (With the former process-global switch netA silently ran in netB's mode.)"""
+    cfg = O.make_cfg(**{**O.CFG_E1, "img_size": 16, "dense_layer_depths": [2], "num_heads": [6], "window_size": [8],
+                        "rdb_depths": [2]})
+    sd = O.make_weights(cfg, 5)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(2, 1, 16, 16, generator=g).to(DEV)
+    tgt = torch.rand(2, 1, 64, 64, generator=g).to(DEV)
+
+    def make(mode):
+        net = build_net(cfg)
+        net.load_state_dict(sd, strict=True)
+        return net.to(DEV).train().set_compute_dtype(mode)
+
+    def solo(mode):
+        net = make(mode)
+        y = net(x)
+        F.l1_loss(y, tgt).backward()
+        torch.cuda.synchronize()
+        return y.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    y3_ref, g3_ref = solo("fp32x3")
+    y1_ref, g1_ref = solo("fp32")
+    assert (y3_ref - y1_ref).abs().max().item() > 0          # the two modes do differ
+    net3, net1 = make("fp32x3"), make("fp32")
+    y3 = net3(x)                          # forward of the split network ...
+    y1 = net1(x)                          # ... then the exact one's forward in between ...
+    net1.set_compute_dtype("fp32")        # (a per-module call: must not reach net3's pending backward)
+    F.l1_loss(y3, tgt).backward()         # ... and only now the split network's backward
+    y3b = net3(x)                         # a second split forward before the exact backward
+    F.l1_loss(y1, tgt).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(y3.detach(), y3_ref) and torch.equal(y3b.detach(), y3_ref) and torch.equal(y1.detach(), y1_ref)
+    for k, p in net3.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g3_ref[k]), k
+    for k, p in net1.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g1_ref[k]), k
+    assert not ops.F32_SPLIT

@@ -115,16 +115,20 @@ def test_package_does_not_import_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(dp, fn)
 
 
-@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "swinir_nearest_x4", "rdstsr_n_mlp", "rdstsr_n_conv"])
+@pytest.mark.parametrize("name", ["swinir_ps_x4", "swinir_psd_x2_rgb", "swinir_denoise", "swinir_nearest_x4", "rdstsr_n_mlp", "rdstsr_n_conv",
+                                  "rdstsr_head_pre", "rdstsr_head_post", "rdstsr_identity_norm", "rdstsr_ape", "rdstsr_qk_scale"])
 def test_next_row_models_state_dict_layout(name):
-    """SwinIR baseline and RDSTSR_N ("next" rows): same state-dict keys / order / shapes / dtypes as the reference."""
-    from util import MODEL_CASES
+    """SwinIR baseline, RDSTSR_N ("next" rows) and the RDSTSR constructor branches ('head' dim modifier, nn.Identity norms, ape,
+    qk_scale): same state-dict keys / order / shapes / dtypes as the reference."""
+    from util import MODEL_CASES, model_kwargs
     kind, kw, _x, _seed, _train = MODEL_CASES[name]
     if kind == "swinir":
         from networks.swin_transformer_sr import SwinIR as cls
+    elif kind == "rdstsr":
+        from networks.rdst_variations import RDSTSR as cls
     else:
         from networks.rdst_variations import RDSTSR_N as cls
-    net = cls(**kw)
+    net = cls(**model_kwargs(kw))
     ref = json.load(open(os.path.join(GOLDEN, f"state_dict_{name}.json")))["entries"]
     mine = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
     assert list(mine) == list(ref) and mine == ref
@@ -299,22 +303,36 @@ def test_dropout_probabilities_are_validated_like_nn_dropout():
 
 def test_compute_dtype_switch_and_dtype_codes():
     """set_compute_dtype: torch.float32 / 'fp32' = exact parity mode, 'fp32x3' = fp32 tensors with the split-bf16 GEMMs (the C ABI's
-    RDST_F32X3 for every fp32 tensor of the process), torch.bfloat16 / 'bf16' = throughput mode; anything else is refused."""
+    RDST_F32X3), torch.bfloat16 / 'bf16' = throughput mode; anything else is refused.  The mode is the MODULE's
+    (``compute_code``, applied by ``ops.compute_scope`` around its forward): setting it on one network changes neither another
+    network nor the process default ``ops.F32_SPLIT`` (which only governs fp32 ops called outside any network)."""
     from rdst_amd import _lib, ops
-    net = build_net(O.CFG_TINY)
+    net, other = build_net(O.CFG_TINY), build_net(O.CFG_TINY)
     x32, xbf = torch.zeros(2, 4), torch.zeros(2, 4, dtype=torch.bfloat16)
     try:
-        assert net.compute_dtype == torch.float32 and not ops.F32_SPLIT
+        assert net.compute_dtype == torch.float32 and net.compute_code == _lib.F32 and not ops.F32_SPLIT
         assert ops._dtype_code(x32) == _lib.F32 and ops._dtype_code(xbf) == _lib.BF16
         assert net.set_compute_dtype("fp32x3") is net
-        assert net.compute_dtype == torch.float32 and ops.F32_SPLIT
-        assert ops._dtype_code(x32) == _lib.F32X3 == 2 and ops._dtype_code(xbf) == _lib.BF16
+        assert net.compute_dtype == torch.float32 and net.compute_code == _lib.F32X3 == 2
+        assert not ops.F32_SPLIT and other.compute_code == _lib.F32           # nobody else changed
+        assert ops._dtype_code(x32) == _lib.F32                                # outside the network: the default
+        with ops.compute_scope(net.compute_code):                              # what net.forward opens
+            assert ops._dtype_code(x32) == _lib.F32X3 and ops._dtype_code(xbf) == _lib.BF16
+            with ops.compute_scope(other.compute_code):                        # a nested forward of the other network
+                assert ops._dtype_code(x32) == _lib.F32
+            assert ops._dtype_code(x32) == _lib.F32X3
+        assert ops._dtype_code(x32) == _lib.F32
         net.set_compute_dtype("bf16")
-        assert net.compute_dtype == torch.bfloat16 and ops.F32_SPLIT          # (the switch only concerns fp32 tensors)
+        assert net.compute_dtype == torch.bfloat16 and net.compute_code == _lib.BF16
+        with ops.compute_scope(net.compute_code):
+            assert ops._dtype_code(x32) == _lib.F32 and ops._dtype_code(xbf) == _lib.BF16   # fp32 side tensors of a bf16 net: exact
         net.set_compute_dtype(torch.float32)
-        assert net.compute_dtype == torch.float32 and not ops.F32_SPLIT
-        net.set_compute_dtype("fp32x3").set_compute_dtype("fp32")
-        assert not ops.F32_SPLIT
+        assert net.compute_dtype == torch.float32 and net.compute_code == _lib.F32
+        ops.set_f32_split(True)                                                # the default, for op-level calls
+        assert ops._dtype_code(x32) == _lib.F32X3
+        with ops.compute_scope(_lib.F32):
+            assert ops._dtype_code(x32) == _lib.F32                            # a module's own mode outranks it
+        assert ops.PackPlan.signature(net) != ops.PackPlan.signature(net.set_compute_dtype("fp32x3"))
         with pytest.raises(ValueError):
             net.set_compute_dtype(torch.float16)
         with pytest.raises(TypeError):

@@ -100,4 +100,35 @@ MODEL_CASES = {
                                        growth_rate=24, pre_norm=True, global_bottleneck=True, global_bottleneck_ratio=1.,
                                        global_bottleneck_mode="conv"),
                       (1, 1, 16, 16), 25, True),
+    # constructor branches of RDSTSR the factory can select (rdst_variations.py:286-303 'head' mode, :1398-1399 nn.Identity for
+    # rdst_layer_norm = False, :1245-1248 / :1330-1331 absolute position embedding; swin_transformer_sr.py:82 qk_scale)
+    "rdstsr_head_pre": ("rdstsr", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2], num_heads=[6],
+                                       window_size=[8], rdb_depths=[2], mlp_ratio=2., growth_rate=24, dim_modify_mode="head",
+                                       pre_norm=True, feature_last_operation=True, dense_scale=0.8),
+                        (2, 1, 16, 16), 31, True),
+    "rdstsr_head_post": ("rdstsr", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2], num_heads=[6],
+                                        window_size=[8], rdb_depths=[2], mlp_ratio=2., growth_rate=24, dim_modify_mode="head",
+                                        pre_norm=False, rdb_residual_scale=0.9),
+                         (1, 1, 16, 16), 32, True),
+    "rdstsr_identity_norm": ("rdstsr", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2], num_heads=[6],
+                                            window_size=[8], rdb_depths=[2], mlp_ratio=2., growth_rate=24, pre_norm=True,
+                                            norm_layer="identity", feature_last_operation=True),
+                             (1, 1, 16, 16), 33, True),
+    "rdstsr_ape": ("rdstsr", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2], num_heads=[6],
+                                  window_size=[8], rdb_depths=[2], mlp_ratio=2., growth_rate=24, pre_norm=True, ape=True,
+                                  feature_last_operation=True),
+                   (2, 1, 16, 16), 34, True),
+    "rdstsr_qk_scale": ("rdstsr", dict(img_size=16, in_chans=1, sr_scale=2, embed_dim=48, dense_layer_depths=[2], num_heads=[6],
+                                       window_size=[8], rdb_depths=[2], mlp_ratio=2., growth_rate=24, pre_norm=True, qk_scale=0.3,
+                                       feature_last_operation=True),
+                        (1, 1, 16, 16), 35, True),
 }
+
+
+def model_kwargs(kw):
+    """MODEL_CASES keeps plain data; 'identity' / 'layernorm' name the norm_layer class."""
+    import torch.nn as nn
+    kw = dict(kw)
+    if "norm_layer" in kw:
+        kw["norm_layer"] = {"identity": nn.Identity, "layernorm": nn.LayerNorm}[kw["norm_layer"]]
+    return kw
