@@ -112,7 +112,7 @@ class DenseSTLayer(nn.Module):
         sink = self._grad_sink(x)
         if not _slot_ok(self.tail):
             new = self.new_features(x, x_size, sink=sink)
-            buf.slot(x.shape[-1], new.shape[-1]).copy_(new.detach())   # values only: `new` itself stays in the graph
+            buf.fill(x.shape[-1], new)   # values only: `new` itself stays in the graph
             return ops.dense_join(x, new, buf, sink)
         new = self.new_features(x, x_size, out_slot=(buf, x.shape[-1]), sink=sink)
         return ops.dense_join(x, new, buf, sink)

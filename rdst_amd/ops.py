@@ -541,6 +541,12 @@ class DenseBuffer:
     def slot(self, c0, n):
         return self.t[..., c0:c0 + n]
 
+    def fill(self, c0, src):
+        """Copy values into channels [c0, c0 + C) WITHOUT touching the buffer's autograd version counter (``.data``): views of
+        the buffer that custom Functions returned earlier (the patch norm's / a fusion conv's out_slot) stay usable — a plain
+        ``slot().copy_()`` marks their base as modified in place and autograd then refuses them."""
+        self.t.data[..., c0:c0 + src.shape[-1]].copy_(src.detach())
+
 
 class _IntoDense(torch.autograd.Function):
     """x -> the first channels of a dense buffer (the only copy an RDSTB makes)."""
