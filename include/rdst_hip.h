@@ -254,6 +254,8 @@ int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w, const flo
 #define RDST_PACK_CONV3_FWD 1
 #define RDST_PACK_LINEAR_SEC3 2   /* a Linear whose N = 3 C outputs are the sections q | k | v, each padded to whole 32-row tiles
                                      (the qkv half of rdst_swin_attn_fwd's workspace; N % 3 == 0) */
+#define RDST_PACK_LINEAR_X3 3     /* the RDST_F32X3 image of a Linear: hi / lo bf16 fragment pairs + b' (what rdst_ln_linear_fwd reads with
+                                     dtype = RDST_F32X3 on the shapes rdst_ln_linear_fwd_packable reports; same `out` size) */
 typedef struct rdst_pack_job {
   int kind;
   const float* W; const float* gamma; const float* beta; const float* bias;

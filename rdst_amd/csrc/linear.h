@@ -61,3 +61,11 @@ size_t mlp3_pack_bytes(int C, int hid);
 int mlp3_fwd_bf16(const bf16* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* W1, const float* b1, const float* W2,
                   const float* b2, bf16* Y, int64_t ldy, float* stats, int64_t M, int C, int hid, void* wpack, bool prepacked,
                   hipStream_t st);
+
+// the same streaming forward on fp32 rows in the RDST_F32X3 arithmetic (lin3x_mfma.hip); wpack: lin3x_pack_bytes(K, N) bytes (pack.h)
+int lin3x_kind(int K, int N, bool ln, bool res, int in_act);   // 0 = not covered
+int lin3x_fwd_f32(const float* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_act, const float* Wt, const float* bias,
+                  const float* R, int64_t ldr, float* Y, int64_t ldy, float* stats, int64_t M, int K, int N, float s, void* wpack,
+                  bool prepacked, hipStream_t st);
+int lin3x_pack_launch(const float* W, const float* gamma, const float* beta, const float* bias, void* out, int N, int K, float s,
+                      hipStream_t st);

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "gemm_valu.h"
 #include "linear.h"
+#include "pack.h"
 
 // out[i] = sum_s slab[s*n + i]: 16 outputs x 16 slab-groups per block (short dependent chains: these
 // reductions are latency-bound), fixed summation order => reproducible
@@ -600,13 +601,17 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
 
 extern "C" int rdst_ln_linear_fwd_packable(int K, int N, int has_ln, int has_residual, int in_act, int dtype) {
   SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
+  if (dtype == RDST_F32 && rdst_split()) return lin3x_kind(K, N, has_ln != 0, has_residual != 0, in_act) != 0;   // lin3x_mfma.hip
   if (dtype != RDST_BF16 || in_act || !(K == 60 || K == 90 || K == 120)) return 0;
   return (has_ln && !has_residual && (N == 3 * K || N == 30)) || (!has_ln && has_residual && N == K);
 }
 
+// (one size for both image kinds — the bf16 fragments + S / b' of lin3_mfma.hip and the hi / lo fragments + b' of lin3x_mfma.hip —
+// so that the callers' arena layouts do not depend on the compute mode)
 extern "C" size_t rdst_ln_linear_fwd_workspace(int K, int N) {
   if (K <= 0 || N <= 0) return 16;
-  return lin3_pack_bytes(K, N);
+  const size_t a = lin3_pack_bytes(K, N), b = lin3x_pack_bytes(K, N);
+  return a > b ? a : b;
 }
 
 extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
@@ -628,6 +633,11 @@ extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w
     const int rc = lin3_fwd_bf16((const bf16*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, stats, M,
                                  K, N, out_scale, workspace, workspace_bytes == RDST_PREPACKED, st);
     if (rc != RDST_ENOTSUP) return rc;   // (a prepacked image the call cannot use is simply ignored)
+  }
+  if (dtype == RDST_F32 && rdst_split() && workspace && workspace_bytes >= rdst_ln_linear_fwd_workspace(K, N)) {
+    const int rc = lin3x_fwd_f32((const float*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const float*)R, ld_r, (float*)Y, ld_y, stats, M,
+                                 K, N, out_scale, workspace, workspace_bytes == RDST_PREPACKED, st);
+    if (rc != RDST_ENOTSUP) return rc;
   }
   if (dtype == RDST_F32)
     return fwd_t<float>((const float*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const float*)R, ld_r, (float*)Y, ld_y, stats, M, K, N, out_scale, st);

@@ -167,3 +167,58 @@ static inline int conv3_pack_blocks(int K, int N) {
   const int ks = (K + 15) / 16, ct = (N + 31) / 32;
   return (ct * 9 * ks * 64 + 255) / 256;
 }
+
+
+// ---- RDST_F32X3 image of a Linear layer (lin3x_mfma.hip): every weight as TWO bf16 terms, hi = bf16(w), lo = bf16(w - hi) ----
+// fragment (nt, ks) = [hi: 64 lanes x 8 bf16][lo: 64 lanes x 8 bf16] (2 KB); lane (r, h): output n = 32 nt + r, inputs k = 16 ks + 8 h + e of
+// w = W[n][k] gamma[k] s.  Behind the fragments: b'[32 nt + r] = (bias[n] + sum_k W[n][k] beta[k]) s (fp32; 0 for the pad rows).
+// The kernels that read it normalise the rows BEFORE the product (x-hat = (x - mean) rstd, split into hi + lo), so no S[n] term exists.
+__device__ __forceinline__ void lin3x_pack_block(int bid, const float* __restrict__ W, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ bias, uint32_t* __restrict__ wp,
+                                                 float* __restrict__ bp, int N, int K, int ksteps, int ntiles, float s) {
+  const int nfr = ntiles * ksteps * 64, nb1 = (nfr + 255) / 256;
+  if (bid < nb1) {
+    const int i = bid * 256 + threadIdx.x;
+    if (i >= nfr) return;
+    const int lane = i & 63, f = i >> 6;
+    const int ks = f % ksteps, nt = f / ksteps;
+    const int n = nt * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+    u32x4_a4 hi, lo;
+    uint32_t* ph = reinterpret_cast<uint32_t*>(&hi);
+    uint32_t* pl = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int e1 = 0; e1 < 2; ++e1) {
+        const int k = k0 + 2 * e2 + e1;
+        v[e1] = (n < N && k < K) ? W[(int64_t)n * K + k] * (gamma ? gamma[k] : 1.f) * s : 0.f;
+      }
+      ph[e2] = pack_bf16x2(v[0], v[1]);
+      pl[e2] = pack_bf16x2(v[0] - bf16lo(ph[e2]), v[1] - bf16hi(ph[e2]));
+    }
+    uint32_t* dst = wp + ((int64_t)f * 128 + lane) * 4;
+    *reinterpret_cast<u32x4_a4*>(dst) = hi;
+    *reinterpret_cast<u32x4_a4*>(dst + 256) = lo;
+    return;
+  }
+  const int n = (bid - nb1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // b': one wave per output row
+  const int NP = ntiles * 32;
+  if (n >= NP) return;
+  float bb = 0.f;
+  if (n < N) {
+    if (beta)
+      for (int k = lane; k < K; k += 64) bb = fmaf(W[(int64_t)n * K + k], beta[k], bb);
+    bb = wave_sum(bb);
+    bb = (bb + (bias ? bias[n] : 0.f)) * s;
+  }
+  if (lane == 0) bp[n] = bb;
+}
+static inline int lin3x_pack_blocks(int K, int N) {
+  const int nt = (N + 31) / 32, ks = (K + 15) / 16;
+  return (nt * ks * 64 + 255) / 256 + (nt * 32 + 3) / 4;
+}
+static __host__ __device__ inline size_t lin3x_pack_bytes(int K, int N) {
+  const int nt = (N + 31) / 32, ks = (K + 15) / 16;
+  return (size_t)nt * ks * 2048 + (size_t)nt * 32 * 4 + 256;
+}

@@ -272,7 +272,12 @@ _PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # owner modu
 
 def pack_plan_of(owner) -> Optional[PackPlan]:
     return _PLANS.get(owner)
-PACK_LINEAR, PACK_CONV3_FWD, PACK_LINEAR_SEC3 = 0, 1, 2
+PACK_LINEAR, PACK_CONV3_FWD, PACK_LINEAR_SEC3, PACK_LINEAR_X3 = 0, 1, 2, 3
+
+
+def _linear_pack_kind(code: int) -> int:
+    """The packed image a Linear forward of this compute code reads: bf16 fragments, or hi / lo bf16 pairs in the fp32x3 mode."""
+    return PACK_LINEAR_X3 if code == F32X3 else PACK_LINEAR
 
 
 class pack_scope:
@@ -334,6 +339,7 @@ _side_streams: dict = {}
 TWO_STREAM_BACKWARD = os.environ.get("RDST_TWO_STREAM", "0") != "0"   # env switch: profiling with clean kernel durations
 MLP_FUSED = os.environ.get("RDST_MLP_FUSED", "1") != "0"   # K7 (fused Mlp kernels) on/off
 ATTN_LSE = os.environ.get("RDST_ATTN_LSE", "1") != "0"       # window 16: keep the forward's row statistics for the backward (rdst_wattn_*_lse)
+X3_STREAM = os.environ.get("RDST_X3_STREAM", "1") != "0"     # fp32x3: the streaming Linear kernels on prepacked hi / lo images (lin3x_mfma.hip, lnlin3x_mfma.hip) on/off
 ATTN_FUSED = os.environ.get("RDST_ATTN_FUSED", "1") != "0"   # K8 (LayerNorm + qkv -> attention -> proj + shortcut in one launch) on/off
 
 
@@ -495,8 +501,9 @@ class _LnLinear(torch.autograd.Function):
             r_r, ldr = _rows(residual)
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device) if lw is not None else None
         code = _dtype_code(x)
-        if w is not None and lib.rdst_ln_linear_fwd_packable(K, N, int(lw is not None), int(r_r is not None), int(in_act), code):
-            _wsp, wptr, nws = _packed_workspace(PACK_LINEAR, w, lw, lb, b, N, K, out_scale,
+        if w is not None and (X3_STREAM or code != F32X3) and lib.rdst_ln_linear_fwd_packable(
+                K, N, int(lw is not None), int(r_r is not None), int(in_act), code):
+            _wsp, wptr, nws = _packed_workspace(_linear_pack_kind(code), w, lw, lb, b, N, K, out_scale,
                                                 lib.rdst_ln_linear_fwd_workspace(K, N), x.device)
         else:
             _wsp, wptr, nws = None, None, 0
@@ -745,8 +752,8 @@ class _SwinBlock(torch.autograd.Function):
         st = _stream()
 
         def lin(xp, ld, lw, lb, act, w, b, rp, ldr, out, N, stats, K):
-            if lib.rdst_ln_linear_fwd_packable(K, N, int(lw is not None), int(rp is not None), act, code):
-                _wsp, wptr, nws = _packed_workspace(PACK_LINEAR, w, lw, lb, b, N, K, 1.0, lib.rdst_ln_linear_fwd_workspace(K, N), dev)
+            if (X3_STREAM or code != F32X3) and lib.rdst_ln_linear_fwd_packable(K, N, int(lw is not None), int(rp is not None), act, code):
+                _wsp, wptr, nws = _packed_workspace(_linear_pack_kind(code), w, lw, lb, b, N, K, 1.0, lib.rdst_ln_linear_fwd_workspace(K, N), dev)
             else:
                 _wsp, wptr, nws = None, None, 0
             _lib.check(lib.rdst_ln_linear_fwd(xp, ld, _ptr(lw), _ptr(lb), act, w.data_ptr(), _ptr(b), rp, ldr,

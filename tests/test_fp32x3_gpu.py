@@ -121,7 +121,11 @@ def test_wattn_fp32x3_vs_oracle(B, H, W, C, heads, ws, shift):
 
 
 @pytest.mark.parametrize("K,N,ln,act,res", [(60, 180, 1, 0, 0), (90, 270, 1, 0, 0), (120, 360, 1, 0, 0), (120, 120, 0, 0, 1),
-                                            (240, 120, 0, 1, 1), (120, 30, 1, 0, 0), (94, 50, 0, 2, 1)])
+                                            (240, 120, 0, 1, 1), (120, 30, 1, 0, 0), (94, 50, 0, 2, 1),
+                                            # the rest of the streaming kernels' shape set (lin3x_mfma.hip / lnlin3x_mfma.hip): proj, tails, fc1, fc2
+                                            (60, 60, 0, 0, 1), (90, 90, 0, 0, 1), (60, 30, 1, 0, 0), (90, 30, 1, 0, 0),
+                                            (60, 120, 1, 0, 0), (90, 180, 1, 0, 0), (120, 240, 1, 0, 0),
+                                            (120, 60, 0, 1, 1), (180, 90, 0, 1, 1)])
 def test_ln_linear_fp32x3_vs_torch(K, N, ln, act, res):
     """LayerNorm / activation -> Linear -> residual, forward + every gradient, split-bf16 operands against fp32 torch on the CPU
     (nn.LayerNorm, nn.GELU / LeakyReLU(0.2), nn.Linear as rdst_variations.py:335-341 composes them): relative L2 <= 3e-5."""

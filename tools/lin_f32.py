@@ -19,7 +19,9 @@ def timed(fn, n=6):
 
 
 for (K, N, ln, act, res, name) in [(60, 180, 1, 0, 0, "ln+qkv60"), (90, 270, 1, 0, 0, "ln+qkv90"), (120, 360, 1, 0, 0, "ln+qkv120"),
-                                   (120, 120, 0, 0, 1, "proj120"), (120, 240, 1, 0, 0, "ln+fc1_120"),
+                                   (60, 60, 0, 0, 1, "proj60"), (90, 90, 0, 0, 1, "proj90"), (120, 120, 0, 0, 1, "proj120"),
+                                   (120, 30, 1, 0, 0, "tail120"), (60, 120, 1, 0, 0, "ln+fc1_60"), (90, 180, 1, 0, 0, "ln+fc1_90"),
+                                   (120, 240, 1, 0, 0, "ln+fc1_120"), (120, 60, 0, 1, 1, "gelu+fc2_60"),
                                    (180, 90, 0, 1, 1, "gelu+fc2_90"), (240, 120, 0, 1, 1, "gelu+fc2_120")]:
     xs = [torch.randn(M, K, device=dev, dtype=dt, requires_grad=True) for _ in range(3)]
     w = (torch.randn(N, K, device=dev) * K ** -0.5).requires_grad_(True); b = torch.zeros(N, device=dev, requires_grad=True)
