@@ -119,6 +119,9 @@ int rdst_wattn_drop_mask(float* out, int B, int H, int W, int heads, int ws, flo
  *               stage the fp32 weights themselves.
  */
 size_t rdst_ln_linear_fwd_workspace(int K, int N);
+/* ... per compute mode (ABI 11): with dtype = RDST_F32X3 the image is hi / lo bf16 fragment pairs + b' (RDST_PACK_LINEAR_X3), twice
+ * the bf16 one; every other dtype gives rdst_ln_linear_fwd_workspace(K, N). */
+size_t rdst_ln_linear_fwd_workspace2(int K, int N, int dtype);
 int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
                        const float* Wt, const float* bias, const void* R, int64_t ld_r, void* Y,
                        int64_t ld_y, float* stats, void* workspace, size_t workspace_bytes, int64_t M, int K,
@@ -255,7 +258,8 @@ int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w, const flo
 #define RDST_PACK_LINEAR_SEC3 2   /* a Linear whose N = 3 C outputs are the sections q | k | v, each padded to whole 32-row tiles
                                      (the qkv half of rdst_swin_attn_fwd's workspace; N % 3 == 0) */
 #define RDST_PACK_LINEAR_X3 3     /* the RDST_F32X3 image of a Linear: hi / lo bf16 fragment pairs + b' (what rdst_ln_linear_fwd reads with
-                                     dtype = RDST_F32X3 on the shapes rdst_ln_linear_fwd_packable reports; same `out` size) */
+                                     dtype = RDST_F32X3 on the shapes rdst_ln_linear_fwd_packable reports; `out` needs
+                                     rdst_ln_linear_fwd_workspace2(K, N, RDST_F32X3) bytes) */
 typedef struct rdst_pack_job {
   int kind;
   const float* W; const float* gamma; const float* beta; const float* bias;

@@ -24,6 +24,7 @@ SIGNATURES = {
     "rdst_wattn_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
     "rdst_wattn_bwd": (_i, [_p, _l, _p, _p, _i, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rdst_ln_linear_fwd_workspace": (_z, [_i, _i]),
+    "rdst_ln_linear_fwd_workspace2": (_z, [_i, _i, _i]),
     "rdst_ln_linear_fwd": (_i, [_p, _l, _p, _p, _i, _p, _p, _p, _l, _p, _l, _p, _p, _z, _l, _i, _i, _f, _i, _p]),
     "rdst_ln_linear_bwd_workspace": (_z, [_l, _i, _i]),
     "rdst_ln_linear_bwd": (_i, [_p, _l, _p, _p, _p, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _p, _z,
@@ -81,7 +82,7 @@ SIGNATURES = {
     "rdst_u_dice_bwd": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _p, _p, _l, _i, _i, _p]),
 }
 
-ABI_VERSION = 10             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
+ABI_VERSION = 11             # must equal rdst_abi_version() of the loaded library (argument lists change between versions)
 PREPACKED = (1 << 64) - 1   # RDST_PREPACKED ((size_t)-1)
 
 

@@ -69,3 +69,10 @@ int lin3x_fwd_f32(const float* X, int64_t ldx, const float* ln_w, const float* l
                   bool prepacked, hipStream_t st);
 int lin3x_pack_launch(const float* W, const float* gamma, const float* beta, const float* bias, void* out, int N, int K, float s,
                       hipStream_t st);
+// one-pass Linear backward on fp32 rows in the RDST_F32X3 arithmetic (lnlin3x_mfma.hip): dX (+ LayerNorm backward / GELU' / addends), dW,
+// dbias, d(gamma), d(beta); slab: linear_wgrad_mfma_slab_floats(M, K, N) floats, G: N (K + 1) floats (LayerNorm only)
+int lnlin3x_bwd_kind(int K, int N, bool ln, int in_act);   // 0 = not covered
+int lnlin3x_bwd_f32(const float* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act, const float* Wt,
+                    const float* dY, int64_t lddy, float* dX, int64_t lddx, const float* acc, int64_t ldacc, const float* acc2,
+                    int64_t ldacc2, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G, int64_t M, int K, int N,
+                    float s, hipStream_t st);

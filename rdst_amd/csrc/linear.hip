@@ -442,6 +442,13 @@ int bwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, const f
   float* dA = wsp;
   float* slabW = dA + (ln_w ? M * K : 0);
   float* small = slabW + slab_floats(M, K, N);
+  if constexpr (sizeof(T) == 4) {   // RDST_F32X3: the one-pass kernel of the E1 shapes (every gradient requested), else the paths below
+    if (rdst_split() && Wt && dX && dW && dbias && (!ln_w || (dln_w && dln_b && (int64_t)N * (K + 1) <= M * K)) && !rdst_dbg_getenv("RDST_LBX_OFF")) {
+      const int rc = lnlin3x_bwd_f32(X, ldx, ln_w, ln_b, stats, in_act, Wt, dY, lddy, dX, lddx, acc, ldacc, acc2, ldacc2, dW, dbias, dln_w,
+                                     dln_b, slabW, dA, M, K, N, s, st);
+      if (rc != RDST_ENOTSUP) return rc;
+    }
+  }
   if (acc2) {   // a second addend of dX: only the one-pass LayerNorm-Linear backward of the E1 shapes takes it (nothing is launched otherwise)
     if constexpr (sizeof(T) == 2) {
       if (Wt && ln_w && ln_b && dW && dbias && dln_w && dln_b && dX && K <= 128 && (int64_t)N * (K + 1) <= M * K)
@@ -606,12 +613,15 @@ extern "C" int rdst_ln_linear_fwd_packable(int K, int N, int has_ln, int has_res
   return (has_ln && !has_residual && (N == 3 * K || N == 30)) || (!has_ln && has_residual && N == K);
 }
 
-// (one size for both image kinds — the bf16 fragments + S / b' of lin3_mfma.hip and the hi / lo fragments + b' of lin3x_mfma.hip —
-// so that the callers' arena layouts do not depend on the compute mode)
 extern "C" size_t rdst_ln_linear_fwd_workspace(int K, int N) {
   if (K <= 0 || N <= 0) return 16;
-  const size_t a = lin3_pack_bytes(K, N), b = lin3x_pack_bytes(K, N);
-  return a > b ? a : b;
+  return lin3_pack_bytes(K, N);
+}
+
+// the same per compute mode: RDST_F32X3 reads hi / lo fragment pairs + b' (lin3x_mfma.hip), twice the bf16 image
+extern "C" size_t rdst_ln_linear_fwd_workspace2(int K, int N, int dtype) {
+  if (K <= 0 || N <= 0) return 16;
+  return dtype == RDST_F32X3 ? lin3x_pack_bytes(K, N) : lin3_pack_bytes(K, N);
 }
 
 extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b, int in_act,
@@ -634,7 +644,7 @@ extern "C" int rdst_ln_linear_fwd(const void* X, int64_t ld_x, const float* ln_w
                                  K, N, out_scale, workspace, workspace_bytes == RDST_PREPACKED, st);
     if (rc != RDST_ENOTSUP) return rc;   // (a prepacked image the call cannot use is simply ignored)
   }
-  if (dtype == RDST_F32 && rdst_split() && workspace && workspace_bytes >= rdst_ln_linear_fwd_workspace(K, N)) {
+  if (dtype == RDST_F32 && rdst_split() && workspace && workspace_bytes >= lin3x_pack_bytes(K, N)) {
     const int rc = lin3x_fwd_f32((const float*)X, ld_x, ln_w, ln_b, in_act, Wt, bias, (const float*)R, ld_r, (float*)Y, ld_y, stats, M,
                                  K, N, out_scale, workspace, workspace_bytes == RDST_PREPACKED, st);
     if (rc != RDST_ENOTSUP) return rc;
@@ -667,14 +677,15 @@ extern "C" int rdst_ln_linear_bwd2(const void* X, int64_t ld_x, const float* ln_
   if (M == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   float* wsp = (float*)workspace;
-  if (dX_add2 && (!Wt || dtype != RDST_BF16)) return RDST_ENOTSUP;
+  if (dX_add2 && (!Wt || (dtype != RDST_BF16 && !(dtype == RDST_F32 && rdst_split() && lnlin3x_bwd_kind(K, N, ln_w != nullptr, in_act))))) return RDST_ENOTSUP;
   if (!Wt) {
     if (dtype == RDST_F32)
       return ln_only_bwd<float>((const float*)X, ld_x, ln_w, stats, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dln_w, dln_b, wsp, M, K, out_scale, st);
     return ln_only_bwd<bf16>((const bf16*)X, ld_x, ln_w, stats, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dln_w, dln_b, wsp, M, K, out_scale, st);
   }
   if (dtype == RDST_F32)
-    return bwd_t<float>((const float*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st);
+    return bwd_t<float>((const float*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const float*)dY, ld_dy, (float*)dX, ld_dx, (const float*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st,
+                      (const float*)dX_add2, ld_dx_add2);
   return bwd_t<bf16>((const bf16*)X, ld_x, ln_w, ln_b, stats, in_act, Wt, (const bf16*)dY, ld_dy, (bf16*)dX, ld_dx, (const bf16*)dX_add, ld_dx_add, dW, dbias, dln_w, dln_b, wsp, M, K, N, out_scale, st,
                      (const bf16*)dX_add2, ld_dx_add2);
 }

@@ -1,0 +1,537 @@
+// Backward of a (LayerNorm- / GELU-fronted) Linear in ONE pass over (x, dY) in the RDST_F32X3 arithmetic: fp32 rows in HBM, every
+// matrix operand as two bf16 terms (hi = bf16(v), lo = bf16(v - hi)), three v_mfma_f32_32x32x16_bf16 per product
+// (hi.hi + hi.lo + lo.hi; the dropped lo.lo is <= 2^-18 relative).  It is lnlin3_mfma.hip (bf16 rows) rebuilt for 4-byte rows; the
+// round-5 split mode ran three launches per Linear (lin_wgrad_mfma + lin_dgrad_ln2, the latter twice for the wide shapes), each
+// re-reading x and dY and re-splitting the weights per workgroup:
+//   * waves are SPECIALISED: weight-gradient waves own TN x TC accumulator tiles of G = dY^T.X' for the whole kernel (X' = x-hat
+//     behind a LayerNorm, x for a plain Linear, GELU(x) for fc2 whose input is fc1's pre-activation; column K of X' is a ones
+//     column: d(bias)); data-gradient wave d owns DT channel tiles of dA^T = (W gamma)^T.dY^T and keeps its (W gamma)^T fragments —
+//     hi AND lo — in registers for the whole kernel;
+//   * the RAW fp32 rows of a 32-token tile (dY, x, the forward's statistics) come by LDS-DMA one tile ahead (two raw buffers, counted
+//     vmcnt waits: no wave carries prefetch registers — beside 120-190 registers of fragments or accumulators they spilled); ONE
+//     conversion pass per tile, shared by all waves, normalises (LayerNorm) / applies the 1.5e-7 GELU (fc2), splits, and writes two
+//     bf16 PLANES per operand ([token][channel], the layouts of the bf16 kernel): the weight-gradient operands are
+//     ds_read_b64_tr_b16 of either plane, the data-gradient B operand is ds_read_b128 of the dY planes; two barriers per tile;
+//   * LayerNorm backward: the two row sums need all channel tiles — partial sums through LDS, rows finished after the NEXT barrier;
+//     dX_add (+ the dense join's strided slice dX_add2) and, for fc2, the pre-activation for GELU' are read straight from HBM in
+//     the lane's own 8-channel runs one tile ahead; dX leaves as 16-byte row stores after one v_permlane32_swap per register pair;
+//   * per-workgroup fp32 slabs G [N][K+1], summed in fixed order (reduce_batch.h; behind a LayerNorm the finish kernel forms
+//     dW = gamma G + beta db^T, d(gamma), d(beta) from the summed G).
+// Where (W gamma)^T hi + lo and the G tiles do not fit the register file together (norm1 + qkv at C = 120: 736 + 768 registers
+// per lane) the host splits N in two launches over halves of the output features — LayerNorm backward is linear in dA — the
+// second accumulating onto the first's dX in place.
+#include "linear.h"
+#include "mfma.h"
+#include "reduce_batch.h"
+#include "wattn_hd.h"
+
+#ifndef LBX_ABL
+#define LBX_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no weight-gradient MFMAs, 2 no data-gradient MFMAs, 4 no dX stores, 8 no slab dump
+#endif
+
+namespace {
+using namespace wahd;
+constexpr int BX_PLAIN = 0, BX_LN = 1, BX_GELU = 2;
+
+struct LBXArgs {
+  const float* X; int64_t ldx; const float* stats; const float* lnw; const float* W;
+  const float* dY; int64_t lddy; float* dX; int64_t lddx; const float* Acc; int64_t ldacc;
+  const float* Acc2; int64_t ldacc2;   // second addend of dX
+  float* slab; int64_t slab_stride;    // floats per workgroup
+  int64_t M; int64_t ntiles; int tiles_per_wg;
+  int x_bytes, y_bytes;                // extents of X / dY (32-bit DMA offsets)
+};
+
+__host__ __device__ constexpr int lbx_ld(int cols) {   // plane row stride (bytes): odd 16-B slot count, not 16..47 (mod 256)
+  const int b = cols * 2 + 16;
+  return (b & 255) < 48 ? b + 64 : b;
+}
+
+// DT channel tiles per data-gradient wave, TN x TC accumulator tiles per weight-gradient wave
+template <int K_, int N_, int MODE_, int DT_, int TN_, int TC_>
+struct LBX {
+  static constexpr int K = K_, N = N_, MODE = MODE_, DT = DT_, TN = TN_, TC = TC_;
+  static constexpr int NCT = (K + 1 + 31) / 32, NW = (N + 31) / 32, KN = (N + 15) / 16;
+  static_assert(NW % TN == 0 && NCT % TC == 0 && NCT % DT == 0, "blocking");
+  static constexpr int NGN = NW / TN, NGC = NCT / TC, NWG = NGN * NGC;   // weight-gradient waves
+  static constexpr int NDG = NCT / DT;                                    // data-gradient waves
+  static constexpr int NWV = NWG + NDG, NT = 64 * NWV;
+  static constexpr int CKX = (K + 3) / 4, CKY = (N + 3) / 4;             // 4-float chunks per row
+  static constexpr int NXC = 32 * CKX, NYC = 32 * CKY;
+  // raw rows in LDS: 16-byte slots, a region = whole 1 KB DMA pieces
+  static constexpr int RSX = (4 * K + 15) / 16 * 16, RSY = (4 * N + 15) / 16 * 16;
+  static constexpr int TPX = (32 * RSX + 1023) / 1024, TPY = (32 * RSY + 1023) / 1024, TPS = MODE == BX_LN ? 1 : 0;
+  static constexpr int TPT = TPY + TPX + TPS, CNT = (TPT + NWV - 1) / NWV;   // pieces per tile / per wave
+  static constexpr int RAW_X = TPY * 1024, RAW_S = RAW_X + TPX * 1024, RAWB = RAW_S + TPS * 1024;
+  static constexpr int CP = 32 * NCT;
+  static constexpr int LDX = lbx_ld(CP), LDY = lbx_ld(32 * NW);
+  static constexpr int OFF_XL = 32 * LDX, OFF_YH = 64 * LDX, OFF_YL = OFF_YH + 32 * LDY, PLB = OFF_YL + 32 * LDY;   // the planes (one set)
+  static constexpr int OFF_RED = (PLB + 15) / 16 * 16;
+  static constexpr int OFF_RAW = (OFF_RED + 2 * NCT * 256 + 1023) / 1024 * 1024;
+  static constexpr int SMEM = OFF_RAW + 2 * RAWB;
+  static constexpr int WPS = (NWV + 3) / 4;
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert(TPT >= NWV && CNT < 64, "every wave owns at least one piece of a tile");
+  static_assert(MODE != BX_LN || DT == 1, "LayerNorm backward: one channel tile per data-gradient wave");
+};
+
+// hi / lo bf16 pairs of 4 floats: (hi.x | hi.y) and (lo.x | lo.y)
+__device__ __forceinline__ void split4(const float* f, u32x2_t& hi, u32x2_t& lo) {
+  hi.x = pack_bf16x2(f[0], f[1]);
+  hi.y = pack_bf16x2(f[2], f[3]);
+  lo.x = pack_bf16x2(f[0] - bf16lo(hi.x), f[1] - bf16hi(hi.x));
+  lo.y = pack_bf16x2(f[2] - bf16lo(hi.y), f[3] - bf16hi(hi.y));
+}
+__device__ __forceinline__ void put8(char* dst, const u32x2_t& v) {   // 8 bytes, 4-byte aligned at least
+  if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) *reinterpret_cast<u32x2_t*>(dst) = v;
+  else {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    d[0] = v.x; d[1] = v.y;
+  }
+}
+
+template <class CF>
+__global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const LBXArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int K = CF::K, N = CF::N, MODE = CF::MODE, DT = CF::DT, TN = CF::TN, TC = CF::TC;
+  constexpr int NCT = CF::NCT, KN = CF::KN, NGC = CF::NGC, NWG = CF::NWG, NT = CF::NT, LDX = CF::LDX, LDY = CF::LDY;
+  constexpr bool LN = MODE == BX_LN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, hh = lane >> 5;
+
+  // ---- prologue: zero the planes (pad columns) and the exchange slots, ones column of X' (hi plane; the lo plane keeps its zero) ----
+  lds_zero16(smem, CF::OFF_RAW, tid, NT);
+  __syncthreads();
+  if (tid < 32) *reinterpret_cast<uint16_t*>(smem + tid * LDX + K * 2) = 0x3f80;
+
+  const int q = (lane & 15) >> 2, pp = lane & 3, gq1 = (lane >> 4) & 1;
+  const int trc = (16 * gq1 + 4 * pp) * 2;
+  const int tro_y = CF::OFF_YH + (8 * hh + q) * LDY + trc;   // transposed-read lane offsets (hi planes)
+  const int tro_x = (8 * hh + q) * LDX + trc;
+
+  const bool is_wg = wave < NWG;
+  const int gn = wave / NGC, gc = wave - gn * NGC;   // weight-gradient block of this wave
+  const int dwv = wave - NWG;                         // data-gradient wave index: channel tiles DT dwv .. DT dwv + DT - 1
+
+  const int64_t t0 = (int64_t)blockIdx.x * p.tiles_per_wg;
+  const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
+
+  // ---- raw rows by LDS-DMA: every wave issues exactly CNT 1 KB pieces per tile (a wave whose share is one short repeats its last
+  // piece; rows past M and the tail of a region arrive as zeros), so "the tile issued one iteration ago has landed" is vmcnt(CNT)
+  // behind the next tile's issue.  (The addend loads and dX stores are the compiler's: its waits can only wait for more.)
+  typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
+  auto make_rsrc = [&](const void* ptr, uint32_t bytes) {
+    u32x4s_t v;
+    v.x = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ptr);
+    v.y = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)ptr >> 32) & 0xffffu);
+    v.z = __builtin_amdgcn_readfirstlane(bytes);
+    v.w = 0x00020000u;
+    return v;
+  };
+  const u32x4s_t rsy = make_rsrc(p.dY, (uint32_t)p.y_bytes), rsx = make_rsrc(p.X, (uint32_t)p.x_bytes),
+                 rss = make_rsrc(MODE == BX_LN ? (const void*)p.stats : (const void*)p.X, MODE == BX_LN ? (uint32_t)(p.M * 8) : 0u);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma = [&](const u32x4s_t& rs, uint32_t ldst, int off) {   // inline asm: see conv3_mfma.hip
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
+  };
+  auto issue_tile = [&](int64_t tile, int b) {
+    const bool tin = tile < t1;
+#pragma unroll
+    for (int i = 0; i < CF::CNT; ++i) {
+      int pc = wave + CF::NWV * i;
+      pc = pc < CF::TPT ? pc : pc - CF::NWV;                  // wave-uniform
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(CF::OFF_RAW + b * CF::RAWB + pc * 1024));
+      if (pc < CF::TPY) {
+        const int sidx = pc * 64 + lane, row = sidx / (CF::RSY / 16), sl = sidx - row * (CF::RSY / 16);
+        const int64_t grow = tile * 32 + row;
+        const bool ok = tin && row < 32 && grow < p.M;
+        dma(rsy, dst, ok ? (int)(grow * (p.lddy * 4)) + sl * 16 : p.y_bytes);
+      } else if (pc < CF::TPY + CF::TPX) {
+        const int sidx = (pc - CF::TPY) * 64 + lane, row = sidx / (CF::RSX / 16), sl = sidx - row * (CF::RSX / 16);
+        const int64_t grow = tile * 32 + row;
+        const bool ok = tin && row < 32 && grow < p.M;
+        dma(rsx, dst, ok ? (int)(grow * (p.ldx * 4)) + sl * 16 : p.x_bytes);
+      } else {   // the tile's 32 (mean, rstd) pairs: 16 lanes of one piece
+        const int64_t grow = tile * 32 + 2 * lane;
+        const bool ok = tin && lane < 16 && grow < p.M;
+        dma(rss, dst, ok ? (int)(grow * 8) : (int)(p.M * 8));
+      }
+    }
+  };
+  // ---- the conversion pass of one tile, all waves: raw chunk of 4 floats -> (x-hat | GELU | as it is) -> hi / lo into the planes ----
+  auto convert = [&](int b) {
+    const char* raw = smem + CF::OFF_RAW + b * CF::RAWB;
+    for (int idx = tid; idx < CF::NYC + CF::NXC; idx += NT) {
+      const bool isy = idx < CF::NYC;
+      const int li = isy ? idx : idx - CF::NYC;
+      const int per = isy ? CF::CKY : CF::CKX, width = isy ? N : K;
+      const int row = li / per, chk = li - row * per;
+      int c0 = chk * 4;
+      c0 = c0 + 4 <= width ? c0 : width - 4;   // (a ragged last chunk overlaps its neighbour and rewrites the same values)
+      const char* src = raw + (isy ? row * CF::RSY : CF::RAW_X + row * CF::RSX) + c0 * 4;
+      float f[4];
+      if ((c0 & 3) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+      } else {
+        const float2 v0 = *reinterpret_cast<const float2*>(src), v1 = *reinterpret_cast<const float2*>(src + 8);
+        f[0] = v0.x; f[1] = v0.y; f[2] = v1.x; f[3] = v1.y;
+      }
+      if (!isy) {
+        if (MODE == BX_LN) {
+          const float2 st2 = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = (f[e] - st2.x) * st2.y;
+        } else if (MODE == BX_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = gelu_fast(f[e]);
+        }
+      }
+      u32x2_t hi, lo;
+      split4(f, hi, lo);
+      char* dst = smem + (isy ? CF::OFF_YH + row * LDY : row * LDX) + c0 * 2;
+      put8(dst, hi);
+      put8(dst + (isy ? 32 * LDY : CF::OFF_XL), lo);
+    }
+  };
+  if (t0 < t1) issue_tile(t0, 0);
+
+  // The two roles run SEPARATE copies of the tile loop (same barrier count): in one loop body the register allocator would have
+  // to keep the G tiles and the W fragments alive side by side in every wave.
+  if (is_wg) {
+    f32x16 G[TN][TC];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) G[i][j][v] = 0.f;
+    int b = 0;
+    for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
+      const char* buf = smem;
+      issue_tile(tile + 1, b ^ 1);   // (raw buffer b ^ 1: converted one iteration ago)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::CNT) : "memory");
+      __syncthreads();   // raw tile landed (every wave's pieces); everybody is done with the planes
+      convert(b);
+      __syncthreads();   // planes staged
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Pack16 yh[TN], yl[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const lds_cp yp = (lds_cp)(buf + tro_y + 16 * s * LDY) + (gn * TN + i) * 64;
+          yh[i] = lds_tr_pack(yp, yp + 4 * LDY);
+          yl[i] = lds_tr_pack(yp + 32 * LDY, yp + 36 * LDY);
+        }
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {   // (the X' operands one channel tile at a time: 8 registers instead of 8 TC)
+          const lds_cp xp = (lds_cp)(buf + tro_x + 16 * s * LDX) + (gc * TC + j) * 64;
+          const Pack16 xh = lds_tr_pack(xp, xp + 4 * LDX);
+          const Pack16 xl = lds_tr_pack(xp + CF::OFF_XL, xp + CF::OFF_XL + 4 * LDX);
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+#if !(LBX_ABL & 1)
+            // rows = output features n, columns = channels (column K = d(bias))
+            G[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, yl[i]), __builtin_bit_cast(bf16x8_t, xh), G[i][j], 0, 0, 0);
+            G[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, yh[i]), __builtin_bit_cast(bf16x8_t, xl), G[i][j], 0, 0, 0);
+            G[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, yh[i]), __builtin_bit_cast(bf16x8_t, xh), G[i][j], 0, 0, 0);
+#else
+            G[i][j][0] += __uint_as_float(yh[i].w[0] ^ xh.w[0] ^ yl[i].w[1] ^ xl.w[1]);
+#endif
+          }
+        }
+      }
+    }
+    if (LN) __syncthreads();   // (the data-gradient waves' closing barrier)
+    // fp32 slab G [N][K+1] of this workgroup: consecutive lanes = consecutive channels of one row
+    float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        const int c = 32 * (gc * TC + j) + r;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int n = 32 * (gn * TN + i) + acc_row(v, hh);
+          if (n < N && c <= K && !(LBX_ABL & 8)) my[(int64_t)n * (K + 1) + c] = G[i][j][v];
+        }
+      }
+    return;
+  }
+
+  // ---- data-gradient wave: (W gamma)^T fragments hi / lo, lane (r, hh) of k-step ks holds W[16 ks + 8 hh + e][channel] gamma ----
+  Pack16 wfh[DT][KN], wfl[DT][KN];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const int c = 32 * (DT * dwv + dt) + r;
+    const int cc = c < K ? c : K - 1;
+    const float gm = (c < K) ? (LN ? p.lnw[cc] : 1.0f) : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KN; ++ks) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = 16 * ks + 8 * hh + e;
+        const float w = p.W[(size_t)(n < N ? n : N - 1) * K + cc];
+        f[e] = n < N ? w * gm : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wfh[dt][ks].w[e] = pack_bf16x2(f[2 * e], f[2 * e + 1]);
+        wfl[dt][ks].w[e] = pack_bf16x2(f[2 * e] - bf16lo(wfh[dt][ks].w[e]), f[2 * e + 1] - bf16hi(wfh[dt][ks].w[e]));
+      }
+    }
+  }
+  constexpr float invK = 1.0f / (float)K;
+  float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
+  const bool has_acc = p.Acc != nullptr, has_acc2 = p.Acc2 != nullptr;
+  // the lane's runs of a row-wise operand (dX_add, dX_add2, fc2's pre-activation) in the layout the stores have: [cb, cb + 8),
+  // cb = 32 ct + 8 (2 gp + hh), 4 x 16 bytes per channel tile, read straight from HBM beside the products
+  auto load_runs = [&](const float* base, int64_t ldb, int64_t row, int ct, u32x4_a4 (&o)[4]) {
+    const int64_t rr = row < p.M ? row : p.M - 1;
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int cb = 32 * ct + 8 * (2 * gp + hh);
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        int c0 = cb + 4 * qq;
+        c0 = c0 + 4 <= K ? c0 : K - 4;   // (clamped: the values of columns past K are never stored)
+        o[2 * gp + qq] = *reinterpret_cast<const u32x4_a4*>(base + rr * ldb + c0);
+      }
+    }
+  };
+  auto load_addends = [&](int64_t row, int ct, u32x4_a4 (&o)[4]) {
+    if (MODE == BX_GELU) load_runs(p.X, p.ldx, row, ct, o);
+    else if (has_acc) load_runs(p.Acc, p.ldacc, row, ct, o);
+    else if (has_acc2) load_runs(p.Acc2, p.ldacc2, row, ct, o);
+    if (MODE != BX_GELU && has_acc && has_acc2) {
+      u32x4_a4 a2[4];
+      load_runs(p.Acc2, p.ldacc2, row, ct, a2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i].x = __float_as_uint(__uint_as_float(o[i].x) + __uint_as_float(a2[i].x));
+        o[i].y = __float_as_uint(__uint_as_float(o[i].y) + __uint_as_float(a2[i].y));
+        o[i].z = __float_as_uint(__uint_as_float(o[i].z) + __uint_as_float(a2[i].z));
+        o[i].w = __float_as_uint(__uint_as_float(o[i].w) + __uint_as_float(a2[i].w));
+      }
+    }
+  };
+  // one channel tile of one token tile: dA (registers: channel, lane: token) -> dX rows.  LayerNorm: the row sums of ALL channel
+  // tiles come from `red` (slot pb), x-hat and rstd of the lane's elements waited in registers
+  auto finish = [&](const f32x16& dxv, const u32x4_a4 (&adv)[4], const float* xs, float rstd, int ct, int64_t row, int pb) {
+    float o[16];
+    if (LN) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NCT; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(red + ((pb * NCT + w) * 32 + r) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+      s1 *= invK; s2 *= invK;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) o[v] = rstd * (dxv[v] - s1 - xs[LN ? v : 0] * s2);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) o[v] = dxv[v];
+    }
+    if (row >= p.M) return;
+    float* drow = p.dX + row * p.lddx;
+#pragma unroll
+    for (int gp2 = 0; gp2 < 2; ++gp2) {
+      float c8[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * gp2 + e]), __float_as_uint(o[8 * gp2 + 4 + e]), false, false);
+        c8[e] = __uint_as_float(sw[0]);
+        c8[4 + e] = __uint_as_float(sw[1]);
+      }
+      const int cb = 32 * ct + 8 * (2 * gp2 + hh);
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int c0 = cb + 4 * qq;
+        if (c0 >= K) continue;
+        const u32x4_a4 a4 = adv[2 * gp2 + qq];
+        const float a[4] = {__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w)};
+        if (LBX_ABL & 4) continue;
+        if (c0 + 4 <= K) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (MODE == BX_GELU) y[e] = c8[4 * qq + e] * gelu_grad_fast(a[e]);
+            else y[e] = (has_acc || has_acc2) ? c8[4 * qq + e] + a[e] : c8[4 * qq + e];
+          }
+          u32x4_a4 u;
+          u.x = __float_as_uint(y[0]); u.y = __float_as_uint(y[1]); u.z = __float_as_uint(y[2]); u.w = __float_as_uint(y[3]);
+          *reinterpret_cast<u32x4_a4*>(drow + c0) = u;
+        } else {   // K % 4 != 0: the addend run was clamped to [K - 4, K): realign per element
+          const int sh = c0 + 4 - K;   // the loaded run starts sh columns early
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < K) {
+              float ae = 0.f;
+#pragma unroll
+              for (int e2 = 0; e2 < 4; ++e2) ae = (e2 == e + sh) ? a[e2] : ae;
+              const float v0 = c8[4 * qq + e];
+              drow[c0 + e] = MODE == BX_GELU ? v0 * gelu_grad_fast(ae) : ((has_acc || has_acc2) ? v0 + ae : v0);
+            }
+        }
+      }
+    }
+  };
+  auto product = [&](const char* buf, int dt, f32x16& dxv) {
+    const lds_cp yrow = (lds_cp)(buf + CF::OFF_YH + r * LDY + hh * 16);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dxv[v] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KN; ++ks) {
+      const Pack16 yh = lds_pack(yrow + 32 * ks), yl = lds_pack(yrow + 32 * LDY + 32 * ks);
+#if !(LBX_ABL & 2)
+      // rows = channels, columns = tokens
+      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfl[dt][ks]), __builtin_bit_cast(bf16x8_t, yh), dxv, 0, 0, 0);
+      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfh[dt][ks]), __builtin_bit_cast(bf16x8_t, yl), dxv, 0, 0, 0);
+      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfh[dt][ks]), __builtin_bit_cast(bf16x8_t, yh), dxv, 0, 0, 0);
+#else
+      dxv[0] += __uint_as_float(yh.w[0] ^ yl.w[1] ^ wfh[dt][ks].w[0] ^ wfl[dt][ks].w[1]);
+#endif
+    }
+  };
+  // LayerNorm: state of the unfinished tile (finished after the next tile's first barrier): dA, x-hat, rstd, the addend runs, the row
+  f32x16 dxp;
+  u32x4_a4 adp[4];
+  float xsp[LN ? 16 : 1], rstdp = 0.f;
+  int64_t prow = -1;
+  int b = 0;
+  for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
+    const char* buf = smem;
+    issue_tile(tile + 1, b ^ 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::CNT) : "memory");
+    __syncthreads();
+    if constexpr (LN) {
+      if (prow >= 0) finish(dxp, adp, xsp, rstdp, dwv, prow, b ^ 1);
+    }
+    convert(b);
+    __syncthreads();
+    const int64_t nrow = tile * 32 + r;
+    if constexpr (LN) {
+      load_addends(nrow, dwv, adp);   // consumed one barrier later
+      product(buf, 0, dxp);
+      prow = nrow;
+      // x-hat of the lane's own (token, channel) elements = hi + lo of the planes; partial row sums of this channel tile
+      const lds_cp xrow = (lds_cp)(buf + r * LDX) + (32 * dwv + 4 * hh) * 2;
+      rstdp = reinterpret_cast<const float2*>(smem + CF::OFF_RAW + b * CF::RAWB + CF::RAW_S)[r].y;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const u32x2_t vh = *reinterpret_cast<const LDS_AS u32x2_t*>(xrow + 16 * g4);
+        const u32x2_t vl = *reinterpret_cast<const LDS_AS u32x2_t*>(xrow + CF::OFF_XL + 16 * g4);
+        xsp[LN ? 4 * g4 : 0] = bf16lo(vh.x) + bf16lo(vl.x); xsp[LN ? 4 * g4 + 1 : 0] = bf16hi(vh.x) + bf16hi(vl.x);
+        xsp[LN ? 4 * g4 + 2 : 0] = bf16lo(vh.y) + bf16lo(vl.y); xsp[LN ? 4 * g4 + 3 : 0] = bf16hi(vh.y) + bf16hi(vl.y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1 += dxp[4 * g4 + e];
+          s2 = fmaf(dxp[4 * g4 + e], xsp[LN ? 4 * g4 + e : 0], s2);
+        }
+      }
+      s1 = half_swap_sum(s1);
+      s2 = half_swap_sum(s2);
+      if (hh == 0) *reinterpret_cast<float2*>(red + ((b * NCT + dwv) * 32 + r) * 2) = make_float2(s1, s2);
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {   // one channel tile at a time: one accumulator and one set of addend runs alive
+        const int ct = DT * dwv + dt;
+        f32x16 dxv;
+        u32x4_a4 adv[4];
+        float xdummy[1] = {0.f};
+        load_addends(nrow, ct, adv);
+        product(buf, dt, dxv);
+        finish(dxv, adv, xdummy, 0.f, ct, nrow, b);
+      }
+    }
+  }
+  if constexpr (LN) {
+    __syncthreads();   // (the last tile's partial sums)
+    if (prow >= 0) finish(dxp, adp, xsp, rstdp, dwv, prow, b ^ 1);
+  }
+}
+
+template <int K, int N, int MODE, int DT, int TN, int TC>
+int lbx_launch(LBXArgs& p, int64_t max_wgs, int* grid_out, hipStream_t st) {
+  using CF = LBX<K, N, MODE, DT, TN, TC>;
+  auto kern = lnlin3x_bwd_kernel<CF>;
+  int per_cu = CF::NWV <= 6 && 2 * CF::SMEM <= 160 * 1024 ? 2 : 1;
+  int64_t cap = 256 * (int64_t)per_cu;
+  if (cap > max_wgs) cap = max_wgs;
+  int64_t grid = p.ntiles < cap ? p.ntiles : cap;
+  p.tiles_per_wg = (int)((p.ntiles + grid - 1) / grid);
+  grid = (p.ntiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+  p.slab_stride = (int64_t)N * (K + 1);
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CF::NT), CF::SMEM, st, p);
+  *grid_out = (int)grid;
+  return rdst_launch_status("lnlin3x_bwd");
+}
+
+// one launch over output features [n0, n0 + NN) of a Linear with N outputs in all (NN = N: the whole layer)
+int lbx_dispatch(LBXArgs& p, int K, int NN, int mode, int64_t max_wgs, int* grid_out, hipStream_t st) {
+#define RDST_LBX(KK, NV, MM, DT, TN, TC) if (K == KK && NN == NV && mode == MM) return lbx_launch<KK, NV, MM, DT, TN, TC>(p, max_wgs, grid_out, st);
+  // norm1 + qkv (C = 120: halves of 180 output features), proj, dense tails, norm2 + fc1, fc2 (GELU on the way in, K = 2 C)
+  RDST_LBX(60, 180, BX_LN, 1, 3, 1) RDST_LBX(90, 270, BX_LN, 1, 3, 3) RDST_LBX(120, 180, BX_LN, 1, 3, 2)
+  RDST_LBX(60, 60, BX_PLAIN, 1, 1, 2) RDST_LBX(90, 90, BX_PLAIN, 1, 1, 3) RDST_LBX(120, 120, BX_PLAIN, 1, 2, 2)
+  RDST_LBX(60, 30, BX_LN, 1, 1, 2) RDST_LBX(90, 30, BX_LN, 1, 1, 3) RDST_LBX(120, 30, BX_LN, 1, 1, 4)
+  RDST_LBX(60, 120, BX_LN, 1, 2, 1) RDST_LBX(90, 180, BX_LN, 1, 2, 3) RDST_LBX(120, 240, BX_LN, 1, 2, 4)
+  RDST_LBX(120, 60, BX_GELU, 1, 1, 2) RDST_LBX(180, 90, BX_GELU, 2, 1, 6) RDST_LBX(240, 120, BX_GELU, 2, 1, 8)
+#undef RDST_LBX
+  return RDST_ENOTSUP;
+}
+
+}  // namespace
+
+// 0 = not covered; 1 = one launch; 2 = two launches over halves of the output features
+int lnlin3x_bwd_kind(int K, int N, bool ln, int in_act) {
+  const int mode = ln ? BX_LN : in_act == RDST_ACT_GELU ? BX_GELU : in_act ? -1 : BX_PLAIN;
+  if (mode < 0) return 0;
+  if (mode == BX_LN && K == 120 && N == 360) return 2;
+  if (mode == BX_LN && (K == 60 || K == 90 || K == 120) && (N == 3 * K || N == 30 || N == 2 * K)) return 1;
+  if (mode == BX_PLAIN && (K == 60 || K == 90 || K == 120) && N == K) return 1;
+  if (mode == BX_GELU && (N == 60 || N == 90 || N == 120) && K == 2 * N) return 1;
+  return 0;
+}
+
+// The E1 shapes of the one-pass Linear backward on fp32 rows in the split arithmetic; RDST_ENOTSUP for everything else (the caller
+// falls back to the three-launch path of linear_mfma.hip).  Queues / runs the slab sums and the LayerNorm finish itself.
+int lnlin3x_bwd_f32(const float* X, int64_t ldx, const float* ln_w, const float* ln_b, const float* stats, int in_act, const float* Wt,
+                    const float* dY, int64_t lddy, float* dX, int64_t lddx, const float* acc, int64_t ldacc, const float* acc2,
+                    int64_t ldacc2, float* dW, float* dbias, float* dln_w, float* dln_b, float* slab, float* G, int64_t M, int K, int N,
+                    float s, hipStream_t st) {
+  const bool ln = ln_w != nullptr;
+  const int kind = lnlin3x_bwd_kind(K, N, ln, in_act);
+  if (!kind || s != 1.0f || M <= 0 || !dX || !dW || !dbias || (ln && (!ln_b || !dln_w || !dln_b || !stats || !G))) return RDST_ENOTSUP;
+  if (((uintptr_t)X & 3) || ((uintptr_t)dY & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3) || ((uintptr_t)acc2 & 3)) return RDST_ENOTSUP;
+  const int mode = ln ? BX_LN : in_act == RDST_ACT_GELU ? BX_GELU : BX_PLAIN;
+  if (mode == BX_GELU && (acc || acc2)) return RDST_ENOTSUP;
+  if (((M - 1) * ldx + K) * 4 >= (1ll << 31) || ((M - 1) * lddy + N) * 4 >= (1ll << 31) || M * 8 >= (1ll << 31)) return RDST_ENOTSUP;   // 32-bit DMA offsets
+  const int max_wgs = linear_wgrad_max_wgs(N);
+  const int NN = kind == 2 ? N / 2 : N;
+  for (int half = 0; half < kind; ++half) {
+    const int n0 = half * NN;
+    LBXArgs p{};
+    p.X = X; p.ldx = ldx; p.stats = stats; p.lnw = ln_w; p.W = Wt + (int64_t)n0 * K; p.dY = dY + n0; p.lddy = lddy; p.dX = dX; p.lddx = lddx;
+    p.Acc = half == 0 ? acc : dX; p.ldacc = half == 0 ? ldacc : lddx; p.Acc2 = half == 0 ? acc2 : nullptr; p.ldacc2 = ldacc2;
+    float* sl = slab + (int64_t)half * max_wgs * NN * (K + 1);   // (the region holds max_wgs slabs of N x (K + 1): half the rows each)
+    p.slab = sl; p.M = M; p.ntiles = (M + 31) / 32;
+    p.x_bytes = (int)(((M - 1) * ldx + K) * 4); p.y_bytes = (int)(((M - 1) * lddy + NN) * 4);
+    int grid = 0;
+    if (int rc = lbx_dispatch(p, K, NN, mode, max_wgs, &grid, st)) return rc;
+    rbatch::SumJob sj{};
+    sj.slab = sl; sj.nwg = grid; sj.stride = (int64_t)NN * (K + 1); sj.g4 = 0; sj.tot = NN * (K + 1);
+    if (!ln) {
+      sj.map = rbatch::MAP_LINEAR; sj.out = dW; sj.out2 = dbias; sj.a = K; sj.b = K + 1; sj.s = 1.0f;
+    } else {
+      sj.map = rbatch::MAP_COPY; sj.out = G + (int64_t)n0 * (K + 1);
+    }
+    if (int rc = rbatch::sum(sj, st)) return rc;
+  }
+  if (ln) return wgrad_ln_finish_launch(G, Wt, ln_w, ln_b, N, K, 1.0f, dW, dbias, dln_w, dln_b, st);
+  return 0;
+}

@@ -6,7 +6,7 @@
 thread_local char g_rdst_err[256] = {0};
 thread_local int g_rdst_split = 0;
 
-extern "C" int rdst_abi_version(void) { return 10; }
+extern "C" int rdst_abi_version(void) { return 11; }
 extern "C" const char* rdst_last_error(void) { return g_rdst_err; }
 
 namespace {

@@ -504,7 +504,7 @@ class _LnLinear(torch.autograd.Function):
         if w is not None and (X3_STREAM or code != F32X3) and lib.rdst_ln_linear_fwd_packable(
                 K, N, int(lw is not None), int(r_r is not None), int(in_act), code):
             _wsp, wptr, nws = _packed_workspace(_linear_pack_kind(code), w, lw, lb, b, N, K, out_scale,
-                                                lib.rdst_ln_linear_fwd_workspace(K, N), x.device)
+                                                lib.rdst_ln_linear_fwd_workspace2(K, N, code), x.device)
         else:
             _wsp, wptr, nws = None, None, 0
         _lib.check(lib.rdst_ln_linear_fwd(x_r.data_ptr(), ldx, _ptr(lw), _ptr(lb), int(in_act), _ptr(w), _ptr(b),
@@ -753,7 +753,8 @@ class _SwinBlock(torch.autograd.Function):
 
         def lin(xp, ld, lw, lb, act, w, b, rp, ldr, out, N, stats, K):
             if (X3_STREAM or code != F32X3) and lib.rdst_ln_linear_fwd_packable(K, N, int(lw is not None), int(rp is not None), act, code):
-                _wsp, wptr, nws = _packed_workspace(_linear_pack_kind(code), w, lw, lb, b, N, K, 1.0, lib.rdst_ln_linear_fwd_workspace(K, N), dev)
+                _wsp, wptr, nws = _packed_workspace(_linear_pack_kind(code), w, lw, lb, b, N, K, 1.0,
+                                                    lib.rdst_ln_linear_fwd_workspace2(K, N, code), dev)
             else:
                 _wsp, wptr, nws = None, None, 0
             _lib.check(lib.rdst_ln_linear_fwd(xp, ld, _ptr(lw), _ptr(lb), act, w.data_ptr(), _ptr(b), rp, ldr,

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().rdst_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.load().rdst_abi_version() == _lib.ABI_VERSION == 11
 
 
 @pytest.mark.parametrize("name", sorted(NET_CASES))

@@ -168,7 +168,7 @@ def _model_vs_fixture(name, mode="fp32", out_tol=1e-4, loss_tol=1e-6, grad_tol=1
     loss.backward()
     torch.cuda.synchronize()
     assert np.abs(y.detach().cpu().numpy() - g["y"]).max() <= out_tol
-    assert abs(loss.item() - float(g["loss"])) <= loss_tol
+    assert abs(loss.item() - float(g["loss"])) <= loss_tol * max(1.0, abs(float(g["loss"])))   # (relative above 1: these losses are ~1.0-1.3)
     params = dict(net.named_parameters())
     keys = [str(k) for k in g["grad_keys"]]
     for k, l2 in zip(keys, g["grad_l2"]):

@@ -21,7 +21,7 @@ for K, N, ln, act, res, name in SH:
     w = torch.randn(N, K, device=dev) * K ** -0.5; b = torch.randn(N, device=dev) * 0.1
     lw = torch.ones(K, device=dev) if ln else None; lb = torch.zeros(K, device=dev) if ln else None
     stats = torch.empty(M, 2, device=dev)
-    nws = lib.rdst_ln_linear_fwd_workspace(K, N)
+    nws = lib.rdst_ln_linear_fwd_workspace2(K, N, _lib.F32X3)
     wsp = torch.empty(nws, dtype=torch.uint8, device=dev)
 
     def call(i, wbytes):
