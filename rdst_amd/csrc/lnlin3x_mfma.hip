@@ -12,9 +12,11 @@
 //     conversion pass per tile, shared by all waves, normalises (LayerNorm) / applies the 1.5e-7 GELU (fc2), splits, and writes two
 //     bf16 PLANES per operand ([token][channel], the layouts of the bf16 kernel): the weight-gradient operands are
 //     ds_read_b64_tr_b16 of either plane, the data-gradient B operand is ds_read_b128 of the dY planes; two barriers per tile;
-//   * LayerNorm backward: the two row sums need all channel tiles — partial sums through LDS, rows finished after the NEXT barrier;
-//     dX_add (+ the dense join's strided slice dX_add2) and, for fc2, the pre-activation for GELU' are read straight from HBM in
-//     the lane's own 8-channel runs one tile ahead; dX leaves as 16-byte row stores after one v_permlane32_swap per register pair;
+//   * LayerNorm backward in the accumulators (the two row sums need all channel tiles: partial sums through LDS, rows finished
+//     behind the NEXT tile's first barrier — a third barrier per tile measured 1.3x slower), addends and stores in the lane's own
+//     8-channel runs; WITHOUT a LayerNorm dA leaves through a per-wave LDS bounce image and is finished ROW-WISE (8 lanes on a row's 128
+//     contiguous bytes): dX_add / GELU'(pre-activation) from HBM in the same row-wise chunks, issued ahead of the products,
+//     16-byte dX stores (27 of 72 us at C = 120 proj went into dX stored from the accumulators: 64 pieces of 16 bytes in 32 rows);
 //   * per-workgroup fp32 slabs G [N][K+1], summed in fixed order (reduce_batch.h; behind a LayerNorm the finish kernel forms
 //     dW = gamma G + beta db^T, d(gamma), d(beta) from the summed G).
 // Where (W gamma)^T hi + lo and the G tiles do not fit the register file together (norm1 + qkv at C = 120: 736 + 768 registers
@@ -26,7 +28,7 @@
 #include "wattn_hd.h"
 
 #ifndef LBX_ABL
-#define LBX_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no weight-gradient MFMAs, 2 no data-gradient MFMAs, 4 no dX stores, 8 no slab dump
+#define LBX_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no weight-gradient MFMAs, 2 no data-gradient MFMAs, 4 no dX stores, 8 no slab dump, 16 no conversion pass, 32 no tile DMA (zero pieces)
 #endif
 
 namespace {
@@ -65,9 +67,16 @@ struct LBX {
   static constexpr int RAW_X = TPY * 1024, RAW_S = RAW_X + TPX * 1024, RAWB = RAW_S + TPS * 1024;
   static constexpr int CP = 32 * NCT;
   static constexpr int LDX = lbx_ld(CP), LDY = lbx_ld(32 * NW);
-  static constexpr int OFF_XL = 32 * LDX, OFF_YH = 64 * LDX, OFF_YL = OFF_YH + 32 * LDY, PLB = OFF_YL + 32 * LDY;   // the planes (one set)
+  static constexpr int OFF_XL = 32 * LDX, OFF_YH = 64 * LDX, OFF_YL = OFF_YH + 32 * LDY, OFF_SM = OFF_YL + 32 * LDY, PLB = OFF_SM + 128;   // the planes (one set) + rstd per row
   static constexpr int OFF_RED = (PLB + 15) / 16 * 16;
-  static constexpr int OFF_RAW = (OFF_RED + 2 * NCT * 256 + 1023) / 1024 * 1024;
+  // a data-gradient wave's bounce image: BR token rows x 32 floats (+ pad): dA leaves the registers (channel / lane = token) through it
+  // and is finished ROW-WISE — 8 lanes on the 128 contiguous bytes of a row: the addend loads and the dX stores of an instruction
+  // touch 8 rows, not 64 16-byte pieces in 32 rows (stored from the registers dX cost 27 of 72 us at C = 120 proj).  As many rows as fit
+  static constexpr int BSTR = 144;
+  static constexpr int OFF_BNC = OFF_RED + 2 * NCT * 256;
+  static constexpr int bnc_fit(int br) { return (OFF_BNC + NDG * br * BSTR + 1023) / 1024 * 1024 + 2 * RAWB <= 160 * 1024; }
+  static constexpr int BR = bnc_fit(32) ? 32 : bnc_fit(16) ? 16 : 8;
+  static constexpr int OFF_RAW = (OFF_BNC + NDG * BR * BSTR + 1023) / 1024 * 1024;
   static constexpr int SMEM = OFF_RAW + 2 * RAWB;
   static constexpr int WPS = (NWV + 3) / 4;
   static_assert(SMEM <= 160 * 1024, "LDS");
@@ -136,7 +145,7 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
                  : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
   };
   auto issue_tile = [&](int64_t tile, int b) {
-    const bool tin = tile < t1;
+    const bool tin = tile < t1 && !(LBX_ABL & 32);
 #pragma unroll
     for (int i = 0; i < CF::CNT; ++i) {
       int pc = wave + CF::NWV * i;
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
   // ---- the conversion pass of one tile, all waves: raw chunk of 4 floats -> (x-hat | GELU | as it is) -> hi / lo into the planes ----
   auto convert = [&](int b) {
     const char* raw = smem + CF::OFF_RAW + b * CF::RAWB;
-    for (int idx = tid; idx < CF::NYC + CF::NXC; idx += NT) {
+    for (int idx = tid; idx < ((LBX_ABL & 16) ? 0 : CF::NYC + CF::NXC); idx += NT) {
       const bool isy = idx < CF::NYC;
       const int li = isy ? idx : idx - CF::NYC;
       const int per = isy ? CF::CKY : CF::CKX, width = isy ? N : K;
@@ -183,6 +192,8 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
           const float2 st2 = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
 #pragma unroll
           for (int e = 0; e < 4; ++e) f[e] = (f[e] - st2.x) * st2.y;
+          // (kept beside the planes: the raw buffer is the next-but-one tile's DMA target as soon as the fastest wave gets there)
+          if (c0 == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[row] = st2.y;
         } else if (MODE == BX_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) f[e] = gelu_fast(f[e]);
@@ -284,99 +295,78 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
     }
   }
   constexpr float invK = 1.0f / (float)K;
+  constexpr int BR = CF::BR, BSTR = CF::BSTR;
   float* red = reinterpret_cast<float*>(smem + CF::OFF_RED);
+  char* bnc = smem + CF::OFF_BNC + dwv * (BR * BSTR);
   const bool has_acc = p.Acc != nullptr, has_acc2 = p.Acc2 != nullptr;
-  // the lane's runs of a row-wise operand (dX_add, dX_add2, fc2's pre-activation) in the layout the stores have: [cb, cb + 8),
-  // cb = 32 ct + 8 (2 gp + hh), 4 x 16 bytes per channel tile, read straight from HBM beside the products
-  auto load_runs = [&](const float* base, int64_t ldb, int64_t row, int ct, u32x4_a4 (&o)[4]) {
-    const int64_t rr = row < p.M ? row : p.M - 1;
+  // row-wise layout of a 32 x 32 (token x channel) block: lane -> (row 8 k + lane / 8, k = 0..3; 4-channel chunk lane % 8)
+  const int crow = lane >> 3, cch = lane & 7;
+  auto load4 = [&](const float* base, int64_t ldb, int64_t grow, int col) {   // 4 floats of a row from HBM: ONE unconditional load
+    // (a branch per chunk made the compiler wait for each of a tile's loads in turn).  Chunks past K re-read [K - 4, K) and are
+    // dropped; with K % 4 == 2 the chunk at K - 2 is that read shifted by two
+    static_assert(K % 4 == 0 || K % 4 == 2, "ragged chunk");
+    const int64_t rr = grow < p.M ? grow : p.M - 1;
+    const int c0 = col + 4 <= K ? col : K - 4;
+    u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(base + rr * ldb + c0);
+    if (K % 4 == 2 && col == K - 2) { v.x = v.z; v.y = v.w; }
+    return v;
+  };
+  // the row-wise operands of one channel tile: dX_add (+ dX_add2), or fc2's pre-activation; issued ahead of the products
+  auto load_addends = [&](int64_t row0, int ct, u32x4_a4 (&o)[4]) {
+    const int col = 32 * ct + 4 * cch;
 #pragma unroll
-    for (int gp = 0; gp < 2; ++gp) {
-      const int cb = 32 * ct + 8 * (2 * gp + hh);
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        int c0 = cb + 4 * qq;
-        c0 = c0 + 4 <= K ? c0 : K - 4;   // (clamped: the values of columns past K are never stored)
-        o[2 * gp + qq] = *reinterpret_cast<const u32x4_a4*>(base + rr * ldb + c0);
+    for (int k = 0; k < 4; ++k) {
+      const int64_t grow = row0 + 8 * k + crow;
+      if (MODE == BX_GELU) o[k] = load4(p.X, p.ldx, grow, col);
+      else if (has_acc) o[k] = load4(p.Acc, p.ldacc, grow, col);
+      else if (has_acc2) o[k] = load4(p.Acc2, p.ldacc2, grow, col);
+      if (MODE != BX_GELU && has_acc && has_acc2) {
+        const u32x4_a4 a2 = load4(p.Acc2, p.ldacc2, grow, col);
+        o[k].x = __float_as_uint(__uint_as_float(o[k].x) + __uint_as_float(a2.x));
+        o[k].y = __float_as_uint(__uint_as_float(o[k].y) + __uint_as_float(a2.y));
+        o[k].z = __float_as_uint(__uint_as_float(o[k].z) + __uint_as_float(a2.z));
+        o[k].w = __float_as_uint(__uint_as_float(o[k].w) + __uint_as_float(a2.w));
       }
     }
   };
-  auto load_addends = [&](int64_t row, int ct, u32x4_a4 (&o)[4]) {
-    if (MODE == BX_GELU) load_runs(p.X, p.ldx, row, ct, o);
-    else if (has_acc) load_runs(p.Acc, p.ldacc, row, ct, o);
-    else if (has_acc2) load_runs(p.Acc2, p.ldacc2, row, ct, o);
-    if (MODE != BX_GELU && has_acc && has_acc2) {
-      u32x4_a4 a2[4];
-      load_runs(p.Acc2, p.ldacc2, row, ct, a2);
+  // one channel tile of one token tile: values in the accumulator layout (registers: channel, lane: token) -> bounce -> row-wise:
+  // + addends / x GELU'(pre-activation) -> dX rows
+  auto finish = [&](const float (&o)[16], const u32x4_a4 (&adv)[4], int ct, int64_t row0) {
+    const int col = 32 * ct + 4 * cch;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[i].x = __float_as_uint(__uint_as_float(o[i].x) + __uint_as_float(a2[i].x));
-        o[i].y = __float_as_uint(__uint_as_float(o[i].y) + __uint_as_float(a2[i].y));
-        o[i].z = __float_as_uint(__uint_as_float(o[i].z) + __uint_as_float(a2[i].z));
-        o[i].w = __float_as_uint(__uint_as_float(o[i].w) + __uint_as_float(a2[i].w));
+    for (int ps = 0; ps < 32 / BR; ++ps) {
+      if (BR == 32 || (r / BR) == ps) {   // the tokens of this pass: their lanes (both halves) write their 16 values
+        char* orow = bnc + (r % BR) * BSTR + 16 * hh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(orow + 32 * g4) = make_float4(o[4 * g4], o[4 * g4 + 1], o[4 * g4 + 2], o[4 * g4 + 3]);
       }
-    }
-  };
-  // one channel tile of one token tile: dA (registers: channel, lane: token) -> dX rows.  LayerNorm: the row sums of ALL channel
-  // tiles come from `red` (slot pb), x-hat and rstd of the lane's elements waited in registers
-  auto finish = [&](const f32x16& dxv, const u32x4_a4 (&adv)[4], const float* xs, float rstd, int ct, int64_t row, int pb) {
-    float o[16];
-    if (LN) {
-      float s1 = 0.f, s2 = 0.f;
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int w = 0; w < NCT; ++w) {
-        const float2 v = *reinterpret_cast<const float2*>(red + ((pb * NCT + w) * 32 + r) * 2);
-        s1 += v.x; s2 += v.y;
-      }
-      s1 *= invK; s2 *= invK;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) o[v] = rstd * (dxv[v] - s1 - xs[LN ? v : 0] * s2);
-    } else {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) o[v] = dxv[v];
-    }
-    if (row >= p.M) return;
-    float* drow = p.dX + row * p.lddx;
-#pragma unroll
-    for (int gp2 = 0; gp2 < 2; ++gp2) {
-      float c8[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * gp2 + e]), __float_as_uint(o[8 * gp2 + 4 + e]), false, false);
-        c8[e] = __uint_as_float(sw[0]);
-        c8[4 + e] = __uint_as_float(sw[1]);
-      }
-      const int cb = 32 * ct + 8 * (2 * gp2 + hh);
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const int c0 = cb + 4 * qq;
-        if (c0 >= K) continue;
-        const u32x4_a4 a4 = adv[2 * gp2 + qq];
-        const float a[4] = {__uint_as_float(a4.x), __uint_as_float(a4.y), __uint_as_float(a4.z), __uint_as_float(a4.w)};
-        if (LBX_ABL & 4) continue;
-        if (c0 + 4 <= K) {
-          float y[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (MODE == BX_GELU) y[e] = c8[4 * qq + e] * gelu_grad_fast(a[e]);
-            else y[e] = (has_acc || has_acc2) ? c8[4 * qq + e] + a[e] : c8[4 * qq + e];
+      for (int kk = 0; kk < BR / 8; ++kk) {
+        const int k = ps * (BR / 8) + kk, trow = 8 * k + crow;
+        const int64_t grow = row0 + trow;
+        float4 v = *reinterpret_cast<const float4*>(bnc + (8 * kk + crow) * BSTR + cch * 16);
+        const float a[4] = {__uint_as_float(adv[k].x), __uint_as_float(adv[k].y), __uint_as_float(adv[k].z), __uint_as_float(adv[k].w)};
+        if (MODE == BX_GELU) {
+          v.x *= gelu_grad_fast(a[0]); v.y *= gelu_grad_fast(a[1]); v.z *= gelu_grad_fast(a[2]); v.w *= gelu_grad_fast(a[3]);
+        } else if (has_acc || has_acc2) {
+          v.x += a[0]; v.y += a[1]; v.z += a[2]; v.w += a[3];
+        }
+        if (grow < p.M && col < K && !(LBX_ABL & 4)) {
+          float* dst = p.dX + grow * p.lddx + col;
+          if (col + 4 <= K) {
+            u32x4_a4 u;
+            u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+            *reinterpret_cast<u32x4_a4*>(dst) = u;
+          } else {
+            dst[0] = v.x;
+            if (col + 1 < K) dst[1] = v.y;
+            if (col + 2 < K) dst[2] = v.z;
           }
-          u32x4_a4 u;
-          u.x = __float_as_uint(y[0]); u.y = __float_as_uint(y[1]); u.z = __float_as_uint(y[2]); u.w = __float_as_uint(y[3]);
-          *reinterpret_cast<u32x4_a4*>(drow + c0) = u;
-        } else {   // K % 4 != 0: the addend run was clamped to [K - 4, K): realign per element
-          const int sh = c0 + 4 - K;   // the loaded run starts sh columns early
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c0 + e < K) {
-              float ae = 0.f;
-#pragma unroll
-              for (int e2 = 0; e2 < 4; ++e2) ae = (e2 == e + sh) ? a[e2] : ae;
-              const float v0 = c8[4 * qq + e];
-              drow[c0 + e] = MODE == BX_GELU ? v0 * gelu_grad_fast(ae) : ((has_acc || has_acc2) ? v0 + ae : v0);
-            }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
   };
   auto product = [&](const char* buf, int dt, f32x16& dxv) {
@@ -396,11 +386,75 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
 #endif
     }
   };
-  // LayerNorm: state of the unfinished tile (finished after the next tile's first barrier): dA, x-hat, rstd, the addend runs, the row
+  // LayerNorm: state of the unfinished tile — dA, x-hat and rstd of the lane's own elements, the addend chunks, the first row —
+  // finished behind the NEXT tile's first barrier, when every channel tile's partial row sums are in `red` (two barriers per tile)
   f32x16 dxp;
   u32x4_a4 adp[4];
   float xsp[LN ? 16 : 1], rstdp = 0.f;
-  int64_t prow = -1;
+  int64_t prow0 = -1;
+  // (LayerNorm shapes keep the accumulator-layout finish: through the bounce image they measured 1.15x slower — their
+  // data-gradient waves are the workgroup's critical path — although the same change took 10-25 % off the shapes without one.)
+  // The lane's 8-channel runs [cb, cb + 8), cb = 32 ct + 8 (2 gp + hh), of the addends: the layout the registers have after one
+  // v_permlane32_swap per pair; runs past K re-read [K - 4, K) and are dropped or realigned (K % 4 == 2)
+  auto load_runs = [&](int64_t row, u32x4_a4 (&o)[4]) {
+    const int64_t rr = row < p.M ? row : p.M - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = 32 * dwv + 8 * (2 * (i >> 1) + hh) + 4 * (i & 1);
+      const int c0 = col + 4 <= K ? col : K - 4;
+      u32x4_a4 v = {0u, 0u, 0u, 0u};
+      if (has_acc) v = *reinterpret_cast<const u32x4_a4*>(p.Acc + rr * p.ldacc + c0);
+      if (has_acc2) {
+        const u32x4_a4 a2 = *reinterpret_cast<const u32x4_a4*>(p.Acc2 + rr * p.ldacc2 + c0);
+        v.x = __float_as_uint(__uint_as_float(v.x) + __uint_as_float(a2.x)); v.y = __float_as_uint(__uint_as_float(v.y) + __uint_as_float(a2.y));
+        v.z = __float_as_uint(__uint_as_float(v.z) + __uint_as_float(a2.z)); v.w = __float_as_uint(__uint_as_float(v.w) + __uint_as_float(a2.w));
+      }
+      if (K % 4 == 2 && col == K - 2) { v.x = v.z; v.y = v.w; }
+      o[i] = v;
+    }
+  };
+  auto finish_ln = [&](int pb) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NCT; ++w) {
+      const float2 v = *reinterpret_cast<const float2*>(red + ((pb * NCT + w) * 32 + r) * 2);
+      s1 += v.x; s2 += v.y;
+    }
+    s1 *= invK; s2 *= invK;
+    float o[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[v] = rstdp * (dxp[v] - s1 - xsp[LN ? v : 0] * s2);
+    const int64_t row = prow0 + r;
+    if (row >= p.M) return;
+    float* drow = p.dX + row * p.lddx;
+#pragma unroll
+    for (int gp2 = 0; gp2 < 2; ++gp2) {
+      float c8[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[8 * gp2 + e]), __float_as_uint(o[8 * gp2 + 4 + e]), false, false);
+        c8[e] = __uint_as_float(sw[0]);
+        c8[4 + e] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int c0 = 32 * dwv + 8 * (2 * gp2 + hh) + 4 * qq;
+        if (c0 >= K || (LBX_ABL & 4)) continue;
+        const u32x4_a4 a4 = adp[2 * gp2 + qq];
+        float y[4] = {c8[4 * qq] + __uint_as_float(a4.x), c8[4 * qq + 1] + __uint_as_float(a4.y), c8[4 * qq + 2] + __uint_as_float(a4.z),
+                      c8[4 * qq + 3] + __uint_as_float(a4.w)};
+        if (c0 + 4 <= K) {
+          u32x4_a4 u;
+          u.x = __float_as_uint(y[0]); u.y = __float_as_uint(y[1]); u.z = __float_as_uint(y[2]); u.w = __float_as_uint(y[3]);
+          *reinterpret_cast<u32x4_a4*>(drow + c0) = u;
+        } else {
+          drow[c0] = y[0];
+          if (c0 + 1 < K) drow[c0 + 1] = y[1];
+          if (c0 + 2 < K) drow[c0 + 2] = y[2];
+        }
+      }
+    }
+  };
   int b = 0;
   for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
     const char* buf = smem;
@@ -408,18 +462,18 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::CNT) : "memory");
     __syncthreads();
     if constexpr (LN) {
-      if (prow >= 0) finish(dxp, adp, xsp, rstdp, dwv, prow, b ^ 1);
+      if (prow0 >= 0) finish_ln(b ^ 1);   // the previous tile's rows: every channel tile's partial sums are in `red` now
     }
     convert(b);
     __syncthreads();
-    const int64_t nrow = tile * 32 + r;
+    const int64_t row0 = tile * 32;
     if constexpr (LN) {
-      load_addends(nrow, dwv, adp);   // consumed one barrier later
+      load_runs(row0 + r, adp);   // consumed one tile later
       product(buf, 0, dxp);
-      prow = nrow;
+      prow0 = row0;
       // x-hat of the lane's own (token, channel) elements = hi + lo of the planes; partial row sums of this channel tile
       const lds_cp xrow = (lds_cp)(buf + r * LDX) + (32 * dwv + 4 * hh) * 2;
-      rstdp = reinterpret_cast<const float2*>(smem + CF::OFF_RAW + b * CF::RAWB + CF::RAW_S)[r].y;
+      rstdp = reinterpret_cast<const float*>(buf + CF::OFF_SM)[r];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -438,20 +492,22 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
       if (hh == 0) *reinterpret_cast<float2*>(red + ((b * NCT + dwv) * 32 + r) * 2) = make_float2(s1, s2);
     } else {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {   // one channel tile at a time: one accumulator and one set of addend runs alive
+      for (int dt = 0; dt < DT; ++dt) {   // one channel tile at a time: one accumulator and one set of addend chunks alive
         const int ct = DT * dwv + dt;
         f32x16 dxv;
         u32x4_a4 adv[4];
-        float xdummy[1] = {0.f};
-        load_addends(nrow, ct, adv);
+        load_addends(row0, ct, adv);
         product(buf, dt, dxv);
-        finish(dxv, adv, xdummy, 0.f, ct, nrow, b);
+        float o[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[v] = dxv[v];
+        finish(o, adv, ct, row0);
       }
     }
   }
   if constexpr (LN) {
     __syncthreads();   // (the last tile's partial sums)
-    if (prow >= 0) finish(dxp, adp, xsp, rstdp, dwv, prow, b ^ 1);
+    if (prow0 >= 0) finish_ln(b ^ 1);
   }
 }
 
