@@ -260,6 +260,8 @@ int rdst_swin_attn_fwd(const void* X, int64_t ld_x, const float* ln_w, const flo
 #define RDST_PACK_LINEAR_X3 3     /* the RDST_F32X3 image of a Linear: hi / lo bf16 fragment pairs + b' (what rdst_ln_linear_fwd reads with
                                      dtype = RDST_F32X3 on the shapes rdst_ln_linear_fwd_packable reports; `out` needs
                                      rdst_ln_linear_fwd_workspace2(K, N, RDST_F32X3) bytes) */
+#define RDST_PACK_CONV3_FWD_X3 4  /* the RDST_F32X3 image of a 3x3 convolution's forward weights (rdst_conv_fwd with dtype = RDST_F32X3 on the
+                                     shapes rdst_conv_fwd_packable reports; `out` needs rdst_conv_fwd_workspace2(Cin, Cout, 3, RDST_F32X3)) */
 typedef struct rdst_pack_job {
   int kind;
   const float* W; const float* gamma; const float* beta; const float* bias;
@@ -270,6 +272,7 @@ typedef struct rdst_pack_job {
 int rdst_pack_batch(const rdst_pack_job* jobs, int njobs, void* stream);
 /* 1 if a call of that shape reads a packed image (so prepacking it is useful), else 0 */
 int rdst_ln_linear_fwd_packable(int K, int N, int has_ln, int has_residual, int in_act, int dtype);
+size_t rdst_conv_fwd_workspace2(int Cin, int Cout, int ksize, int dtype);   /* rdst_conv_fwd_workspace per compute mode (ABI 11) */
 int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_r, int has_residual, int in_act, int dtype);
 
 /* ---- batched fixed-order reductions -------------------------------------------------------------------

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rdst_swin_attn_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _l, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i,
                                 _f, _i, _p]),
     "rdst_conv_fwd_workspace": (_z, [_i, _i, _i]),
+    "rdst_conv_fwd_workspace2": (_z, [_i, _i, _i, _i]),
     "rdst_conv_fwd": (_i, [_p, _l, _i, _p, _p, _p, _l, _p, _l, _p, _z, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "rdst_conv_bwd_workspace": (_z, [_i, _i, _i, _i, _i, _i]),
     "rdst_conv_bwd": (_i, [_p, _l, _i, _p, _p, _l, _p, _l, _p, _l, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i,

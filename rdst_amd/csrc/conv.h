@@ -72,3 +72,11 @@ int conv3_dgrad_bf16(const float* Wc, const bf16* dY, int64_t lddy, bf16* dX, in
 size_t conv3_wgrad_slab_bytes(int Cin, int Cout);
 int conv3_wgrad_bf16(const bf16* X, int64_t ldx, int in_act, const bf16* dY, int64_t lddy, float* dW, float* dbias, float* slab,
                      const ConvGeom& g, float s, hipStream_t st);
+
+// the same register-stationary kernels on fp32 rows in the RDST_F32X3 arithmetic (conv3x_mfma.hip); wpack: conv3x_pack_bytes bytes
+size_t conv3x_pack_bytes(int Cin, int Cout);
+int conv3x_fwd_shape(int Cin, int Cout, int ks, int r, bool has_res, int in_act);   // 0 = not covered
+int conv3x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const float* R, int64_t ldr,
+                   float* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, bool prepacked, hipStream_t st);
+int conv3x_dgrad_f32(const float* Wc, const float* dY, int64_t lddy, float* dX, int64_t lddx, const float* acc, int64_t ldacc,
+                     int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st);

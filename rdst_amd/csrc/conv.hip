@@ -135,6 +135,10 @@ int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bia
     if (int rc = conv_in1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
     if (int rc = conv3_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, prepacked, st); rc != RDST_ENOTSUP) return rc;
   }
+  if constexpr (sizeof(T) == 4) {   // RDST_F32X3: the register-stationary kernels on prepacked hi / lo fragments (conv3x_mfma.hip)
+    if (rdst_split())
+      if (int rc = conv3x_fwd_f32(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, prepacked, st); rc != RDST_ENOTSUP) return rc;
+  }
   if (int rc = conv_fwd_mfma<T>(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
   ConvA<T> la{X, ldx, g, in_act};
   ConvB lb{Wc, g};
@@ -148,7 +152,7 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
   const int64_t wtotal = (int64_t)g.Cout * g.Cin * g.ks * g.ks;
   // workspace carve: [packed dgrad weights][generic split-K slab][small][MFMA scratch: un-shuffled dY, wgrad slab]
   void* wpack = wsp;
-  wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + conv3_pack_bytes(g.Cin, g.Cout));
+  wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + conv3x_pack_bytes(g.Cin, g.Cout));   // (room for the hi / lo image: twice the bf16 one)
   float* w3slab = wsp;
   wsp = reinterpret_cast<float*>(reinterpret_cast<char*>(wsp) + (g.ks == 3 ? conv3_wgrad_slab_bytes(g.Cin, g.Cout) : 0));
   float* slab = wsp;
@@ -172,6 +176,14 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
     if (dW || dbias) {
       const int rc = conv3_wgrad_bf16(X, ldx, in_act, dY, lddy, dW, dbias, w3slab, g, s, st);
       if (rc == 0) { dW = nullptr; dbias = nullptr; }
+      else if (rc != RDST_ENOTSUP) return rc;
+    }
+    if ((dxdone || !dX) && !dW && !dbias) return 0;
+  }
+  if constexpr (sizeof(T) == 4) {   // RDST_F32X3: the register-stationary dgrad (conv3x_mfma.hip)
+    if (dX && rdst_split()) {
+      const int rc = conv3x_dgrad_f32(Wc, dY, lddy, dX, lddx, acc, ldacc, in_act, g, s, wpack, st);
+      if (rc == 0) dxdone = true;
       else if (rc != RDST_ENOTSUP) return rc;
     }
     if ((dxdone || !dX) && !dW && !dbias) return 0;
@@ -247,6 +259,7 @@ __global__ void __launch_bounds__(256) rows_to_nchw_kernel(const T* __restrict__
 
 extern "C" int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_r, int has_residual, int in_act, int dtype) {
   SplitScope split_scope(dtype);   // RDST_F32X3: fp32 rows, split-bf16 GEMMs where a kernel has the form (common.h)
+  if (dtype == RDST_F32 && rdst_split()) return conv3x_fwd_shape(Cin, Cout, ksize, shuffle_r, has_residual != 0, in_act) != 0;
   if (dtype != RDST_BF16 || ksize != 3 || in_act) return 0;
   return (Cin == 150 && Cout == 60 && shuffle_r == 1) || (Cin == 60 && Cout == 60 && shuffle_r == 1) ||
          (Cin == 60 && Cout == 240 && shuffle_r == 2 && !has_residual);
@@ -255,6 +268,12 @@ extern "C" int rdst_conv_fwd_packable(int Cin, int Cout, int ksize, int shuffle_
 extern "C" size_t rdst_conv_fwd_workspace(int Cin, int Cout, int ksize) {
   if (Cin <= 0 || Cout <= 0 || ksize != 3) return 16;
   return conv3_pack_bytes(Cin, Cout);
+}
+
+// ... per compute mode: RDST_F32X3 reads hi / lo fragment pairs (RDST_PACK_CONV3_FWD_X3), twice the bf16 image
+extern "C" size_t rdst_conv_fwd_workspace2(int Cin, int Cout, int ksize, int dtype) {
+  if (Cin <= 0 || Cout <= 0 || ksize != 3) return 16;
+  return dtype == RDST_F32X3 ? conv3x_pack_bytes(Cin, Cout) : conv3_pack_bytes(Cin, Cout);
 }
 
 extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const float* Wc, const float* bias, const void* R,
@@ -269,8 +288,11 @@ extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const floa
   if (dtype != RDST_F32 && dtype != RDST_BF16) return rdst_fail(RDST_EINVAL, "rdst_conv_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
   void* wpack = (workspace && workspace_bytes >= rdst_conv_fwd_workspace(Cin, Cout, ksize)) ? workspace : nullptr;
-  if (dtype == RDST_F32)
-    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, wpack, false, st);
+  if (dtype == RDST_F32) {
+    void* wpx = (rdst_split() && workspace && workspace_bytes >= conv3x_pack_bytes(Cin, Cout)) ? workspace : nullptr;
+    return fwd_t<float>((const float*)X, ld_x, in_act, Wc, bias, (const float*)R, ld_r, (float*)Y, ld_y, g, out_scale, wpx,
+                        workspace_bytes == RDST_PREPACKED, st);
+  }
   return fwd_t<bf16>((const bf16*)X, ld_x, in_act, Wc, bias, (const bf16*)R, ld_r, (bf16*)Y, ld_y, g, out_scale, wpack,
                      workspace_bytes == RDST_PREPACKED, st);
 }
@@ -278,7 +300,7 @@ extern "C" int rdst_conv_fwd(const void* X, int64_t ld_x, int in_act, const floa
 extern "C" size_t rdst_conv_bwd_workspace(int B, int H, int W, int Cin, int Cout, int ksize) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0) return 0;
   ConvGeom g{B, H, W, Cin, Cout, ksize, ksize / 2, 2};  // r = 2 reserves room for an un-shuffled dY
-  return conv3_pack_bytes(Cin, Cout) + (ksize == 3 ? conv3_wgrad_slab_bytes(Cin, Cout) : 0) + sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
+  return conv3x_pack_bytes(Cin, Cout) + (ksize == 3 ? conv3_wgrad_slab_bytes(Cin, Cout) : 0) + sizeof(float) * ((size_t)kMaxSplits * Cout * Cin * ksize * ksize + (size_t)kSmallBlocks * Cout + 64) +
          conv_mfma_scratch_bytes(g) + sizeof(float) * (Cin == 1 ? conv_in1_slab_floats(Cout) : conv_c1_slab_floats(Cin));
 }
 

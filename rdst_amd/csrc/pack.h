@@ -222,3 +222,42 @@ static __host__ __device__ inline size_t lin3x_pack_bytes(int K, int N) {
   const int nt = (N + 31) / 32, ks = (K + 15) / 16;
   return (size_t)nt * ks * 2048 + (size_t)nt * 32 * 4 + 256;
 }
+
+
+// ---- RDST_F32X3 image of a 3x3 convolution (conv3x_mfma.hip): fragment (ct, tap, ks) = [hi: 64 lanes x 8 bf16][lo: 64 lanes x 8 bf16];
+// lane (r, h): output channel n = 32 ct + r, contraction k = 16 ks + 8 h + e; same PK_ modes as conv3_pack_block
+__device__ __forceinline__ void conv3x_pack_block(int bid, const float* __restrict__ Wc, uint32_t* __restrict__ out, int Cin, int Cout,
+                                                  int K, int N, int ksteps, int ctiles, int mode, float s) {
+  const int i = bid * 256 + threadIdx.x;          // one thread per (fragment, lane): 16 B of hi and 16 B of lo
+  const int total = ctiles * 9 * ksteps * 64;
+  if (i >= total) return;
+  const int lane = i & 63, f = i >> 6;
+  const int ks = f % ksteps, tap = (f / ksteps) % 9, ct = f / (ksteps * 9);
+  const int n = ct * 32 + (lane & 31);
+  u32x4_a4 hi, lo;
+  uint32_t* ph = reinterpret_cast<uint32_t*>(&hi);
+  uint32_t* pl = reinterpret_cast<uint32_t*>(&lo);
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2) {
+    float v[2];
+#pragma unroll
+    for (int e1 = 0; e1 < 2; ++e1) {
+      const int k = ks * 16 + (lane >> 5) * 8 + 2 * e2 + e1;
+      float x = 0.f;
+      if (n < N && k < K) {
+        if (mode == PK_FWD) x = Wc[((int64_t)n * Cin + k) * 9 + tap];
+        else x = Wc[((int64_t)k * Cin + n) * 9 + (8 - tap)];   // PK_DGRAD: contraction over co, mirrored tap
+      }
+      v[e1] = x * s;
+    }
+    ph[e2] = pack_bf16x2(v[0], v[1]);
+    pl[e2] = pack_bf16x2(v[0] - bf16lo(ph[e2]), v[1] - bf16hi(ph[e2]));
+  }
+  uint32_t* dst = out + ((int64_t)f * 128 + lane) * 4;
+  *reinterpret_cast<u32x4_a4*>(dst) = hi;
+  *reinterpret_cast<u32x4_a4*>(dst + 256) = lo;
+}
+static inline int conv3x_pack_blocks(int K, int N) {
+  const int ks = (K + 15) / 16, ct = (N + 31) / 32;
+  return (ct * 9 * ks * 64 + 255) / 256;
+}

@@ -25,6 +25,8 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const PackBatch bt) {
     uint32_t* wp = reinterpret_cast<uint32_t*>(J.out);
     float* bp = reinterpret_cast<float*>(reinterpret_cast<char*>(J.out) + (size_t)nt * ks * 2048);
     lin3x_pack_block(bid, J.W, J.gamma, J.beta, J.bias, wp, bp, J.N, J.K, ks, nt, J.s);
+  } else if (J.kind == RDST_PACK_CONV3_FWD_X3) {
+    conv3x_pack_block(bid, J.W, reinterpret_cast<uint32_t*>(J.out), J.K, J.N, J.K, J.N, (J.K + 15) / 16, (J.N + 31) / 32, PK_FWD, J.s);
   } else if (J.kind == RDST_PACK_LINEAR_SEC3) {
     const int nt = lin3sec_tiles(J.K, J.N, 3), ks = (J.K + 15) / 16;
     bf16* wp = reinterpret_cast<bf16*>(J.out);
@@ -48,13 +50,15 @@ extern "C" int rdst_pack_batch(const rdst_pack_job* jobs, int njobs, void* strea
     for (int q = 0; q < bt.n; ++q) {
       const rdst_pack_job& J = jobs[base + q];
       if (!J.W || !J.out || J.N <= 0 || J.K <= 0 || ((uintptr_t)J.out & 15) ||
-          (J.kind != RDST_PACK_LINEAR && J.kind != RDST_PACK_CONV3_FWD && J.kind != RDST_PACK_LINEAR_SEC3 && J.kind != RDST_PACK_LINEAR_X3) ||
+          (J.kind != RDST_PACK_LINEAR && J.kind != RDST_PACK_CONV3_FWD && J.kind != RDST_PACK_LINEAR_SEC3 && J.kind != RDST_PACK_LINEAR_X3 &&
+           J.kind != RDST_PACK_CONV3_FWD_X3) ||
           (J.kind == RDST_PACK_LINEAR_SEC3 && J.N % 3))
         return rdst_fail(RDST_EINVAL, "rdst_pack_batch: job %d is malformed", base + q);
       bt.j[q] = J;
       bt.first[q] = blocks;
       blocks += J.kind == RDST_PACK_LINEAR ? lin3_pack_blocks(J.K, J.N)
                 : J.kind == RDST_PACK_LINEAR_X3 ? lin3x_pack_blocks(J.K, J.N)
+                : J.kind == RDST_PACK_CONV3_FWD_X3 ? conv3x_pack_blocks(J.K, J.N)
                 : J.kind == RDST_PACK_LINEAR_SEC3 ? lin3sec_pack_blocks(J.K, J.N, 3) : conv3_pack_blocks(J.K, J.N);
     }
     bt.first[bt.n] = blocks;

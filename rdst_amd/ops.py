@@ -272,7 +272,7 @@ _PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # owner modu
 
 def pack_plan_of(owner) -> Optional[PackPlan]:
     return _PLANS.get(owner)
-PACK_LINEAR, PACK_CONV3_FWD, PACK_LINEAR_SEC3, PACK_LINEAR_X3 = 0, 1, 2, 3
+PACK_LINEAR, PACK_CONV3_FWD, PACK_LINEAR_SEC3, PACK_LINEAR_X3, PACK_CONV3_FWD_X3 = 0, 1, 2, 3, 4
 
 
 def _linear_pack_kind(code: int) -> int:
@@ -1001,9 +1001,9 @@ class _ConvRows(torch.autograd.Function):
                 raise ValueError("rdst_amd.conv_rows: residual must match the output shape/dtype")
             r_r, ldr = _rows(residual)
         code = _dtype_code(x)
-        if lib.rdst_conv_fwd_packable(Cin, Cout, k, r, int(r_r is not None), int(in_act), code):
-            _wsp, wptr, nws = _packed_workspace(PACK_CONV3_FWD, w, None, None, None, Cout, Cin, out_scale,
-                                                lib.rdst_conv_fwd_workspace(Cin, Cout, k), x.device)
+        if (X3_STREAM or code != F32X3) and lib.rdst_conv_fwd_packable(Cin, Cout, k, r, int(r_r is not None), int(in_act), code):
+            _wsp, wptr, nws = _packed_workspace(PACK_CONV3_FWD_X3 if code == F32X3 else PACK_CONV3_FWD, w, None, None, None, Cout, Cin,
+                                                out_scale, lib.rdst_conv_fwd_workspace2(Cin, Cout, k, code), x.device)
         else:
             _wsp, wptr, nws = None, None, 0
         _lib.check(lib.rdst_conv_fwd(x_r.data_ptr(), ldx, int(in_act), w.data_ptr(), _ptr(b), _ptr(r_r), ldr,

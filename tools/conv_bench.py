@@ -4,7 +4,10 @@ of REPS back-to-back calls on rotating buffers, and the fraction of the bf16 MFM
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rdst_amd import ops
-dev = torch.device("cuda:0"); dt = torch.bfloat16
+dev = torch.device("cuda:0")
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"     # python tools/conv_bench.py [bf16 | fp32 | fp32x3]
+dt = torch.bfloat16 if mode == "bf16" else torch.float32
+ops.set_f32_split(mode == "fp32x3")
 SHAPES = [(32, 64, 64, 150, 60, 1, True), (32, 64, 64, 60, 60, 1, False), (32, 64, 64, 60, 240, 2, False),
           (32, 128, 128, 60, 240, 2, False)]
 REPS = 8
