@@ -79,6 +79,9 @@ struct LBX {
   static constexpr int OFF_RAW = (OFF_BNC + NDG * BR * BSTR + 1023) / 1024 * 1024;
   static constexpr int SMEM = OFF_RAW + 2 * RAWB;
   static constexpr int WPS = (NWV + 3) / 4;
+  // conversion pass: all of a thread's chunks in flight at once — except where a wave already holds >= 128 registers of accumulators or
+  // fragments (there the batch spills into the tile loop: 1.2x slower, measured)
+  static constexpr bool CVB = TN * TC * 16 < 128 && DT * KN * 8 < 128;
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(TPT >= NWV && CNT < 64, "every wave owns at least one piece of a tile");
   static_assert(MODE != BX_LN || DT == 1, "LayerNorm backward: one channel tile per data-gradient wave");
@@ -171,39 +174,94 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
   // ---- the conversion pass of one tile, all waves: raw chunk of 4 floats -> (x-hat | GELU | as it is) -> hi / lo into the planes ----
   auto convert = [&](int b) {
     const char* raw = smem + CF::OFF_RAW + b * CF::RAWB;
-    for (int idx = tid; idx < ((LBX_ABL & 16) ? 0 : CF::NYC + CF::NXC); idx += NT) {
+    // every thread's chunks of the tile: all LDS reads first (one chunk at a time the pass was a chain of LDS round trips: 29 of 96 us
+    // at norm1 + qkv, C = 60), then the arithmetic, then the writes
+    if constexpr (!CF::CVB) {
+      for (int idx = tid; idx < ((LBX_ABL & 16) ? 0 : CF::NYC + CF::NXC); idx += NT) {
+        const bool isy = idx < CF::NYC;
+        const int li = isy ? idx : idx - CF::NYC;
+        const int per = isy ? CF::CKY : CF::CKX, width = isy ? N : K;
+        const int row = li / per, chk = li - row * per;
+        int c0 = chk * 4;
+        c0 = c0 + 4 <= width ? c0 : width - 4;
+        const char* src = raw + (isy ? row * CF::RSY : CF::RAW_X + row * CF::RSX) + c0 * 4;
+        float f[4];
+        if ((c0 & 3) == 0) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+          const float2 v0 = *reinterpret_cast<const float2*>(src), v1 = *reinterpret_cast<const float2*>(src + 8);
+          f[0] = v0.x; f[1] = v0.y; f[2] = v1.x; f[3] = v1.y;
+        }
+        if (!isy) {
+          if (MODE == BX_LN) {
+            const float2 s2 = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = (f[e] - s2.x) * s2.y;
+            if (c0 == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[row] = s2.y;
+          } else if (MODE == BX_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = gelu_fast(f[e]);
+          }
+        }
+        u32x2_t hi, lo;
+        split4(f, hi, lo);
+        char* dst = smem + (isy ? CF::OFF_YH + row * LDY : row * LDX) + c0 * 2;
+        put8(dst, hi);
+        put8(dst + (isy ? 32 * LDY : CF::OFF_XL), lo);
+      }
+      return;
+    }
+    constexpr int NPT = (CF::NYC + CF::NXC + NT - 1) / NT;
+    {
+    constexpr int ub = 0;
+    float f[NPT][4];
+    float2 st2[NPT];
+    int dsto[NPT];
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+      const int idx = tid + NT * (ub + u);
+      const bool on = idx < ((LBX_ABL & 16) ? 0 : CF::NYC + CF::NXC);
       const bool isy = idx < CF::NYC;
-      const int li = isy ? idx : idx - CF::NYC;
+      const int li = on ? (isy ? idx : idx - CF::NYC) : 0;
       const int per = isy ? CF::CKY : CF::CKX, width = isy ? N : K;
       const int row = li / per, chk = li - row * per;
       int c0 = chk * 4;
       c0 = c0 + 4 <= width ? c0 : width - 4;   // (a ragged last chunk overlaps its neighbour and rewrites the same values)
       const char* src = raw + (isy ? row * CF::RSY : CF::RAW_X + row * CF::RSX) + c0 * 4;
-      float f[4];
       if ((c0 & 3) == 0) {
         const float4 v = *reinterpret_cast<const float4*>(src);
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        f[u][0] = v.x; f[u][1] = v.y; f[u][2] = v.z; f[u][3] = v.w;
       } else {
         const float2 v0 = *reinterpret_cast<const float2*>(src), v1 = *reinterpret_cast<const float2*>(src + 8);
-        f[0] = v0.x; f[1] = v0.y; f[2] = v1.x; f[3] = v1.y;
+        f[u][0] = v0.x; f[u][1] = v0.y; f[u][2] = v1.x; f[u][3] = v1.y;
       }
-      if (!isy) {
-        if (MODE == BX_LN) {
-          const float2 st2 = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
+      st2[u] = make_float2(0.f, 1.f);
+      if (MODE == BX_LN && !isy) st2[u] = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
+      // plane offset of the chunk's hi half | lo-plane distance in the top bits; < 0: no chunk
+      dsto[u] = on ? ((isy ? CF::OFF_YH + row * LDY : row * LDX) + c0 * 2) | (isy ? 0 : 1 << 30) : -1;
+      if (MODE == BX_LN && !isy && on && c0 == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[row] = st2[u].y;   // (kept beside the planes:
+      // the raw buffer is the next-but-one tile's DMA target as soon as the fastest wave gets there)
+    }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) f[e] = (f[e] - st2.x) * st2.y;
-          // (kept beside the planes: the raw buffer is the next-but-one tile's DMA target as soon as the fastest wave gets there)
-          if (c0 == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[row] = st2.y;
+    for (int u = 0; u < NPT; ++u) {
+      if (dsto[u] < 0) continue;
+      const bool isx = (dsto[u] >> 30) & 1;
+      if (isx) {
+        if (MODE == BX_LN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[u][e] = (f[u][e] - st2[u].x) * st2[u].y;
         } else if (MODE == BX_GELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) f[e] = gelu_fast(f[e]);
+          for (int e = 0; e < 4; ++e) f[u][e] = gelu_fast(f[u][e]);
         }
       }
       u32x2_t hi, lo;
-      split4(f, hi, lo);
-      char* dst = smem + (isy ? CF::OFF_YH + row * LDY : row * LDX) + c0 * 2;
+      split4(f[u], hi, lo);
+      char* dst = smem + (dsto[u] & 0x3fffffff);
       put8(dst, hi);
-      put8(dst + (isy ? 32 * LDY : CF::OFF_XL), lo);
+      put8(dst + (isx ? CF::OFF_XL : 32 * LDY), lo);
+    }
     }
   };
   if (t0 < t1) issue_tile(t0, 0);
