@@ -80,3 +80,5 @@ int conv3x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, con
                    float* Y, int64_t ldy, const ConvGeom& g, float s, void* wpack, bool prepacked, hipStream_t st);
 int conv3x_dgrad_f32(const float* Wc, const float* dY, int64_t lddy, float* dX, int64_t lddx, const float* acc, int64_t ldacc,
                      int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st);
+int conv3x_wgrad_f32(const float* X, int64_t ldx, int in_act, const float* dY, int64_t lddy, float* dW, float* dbias, float* slab,
+                     const ConvGeom& g, float s, hipStream_t st);   // conv3x_wgrad.hip; slab: conv3_wgrad_slab_bytes(Cin, Cout)

@@ -186,6 +186,11 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
       if (rc == 0) dxdone = true;
       else if (rc != RDST_ENOTSUP) return rc;
     }
+    if ((dW || dbias) && rdst_split()) {   // ... and weight gradient (conv3x_wgrad.hip): the shuffled dY as it lies
+      const int rc = conv3x_wgrad_f32(X, ldx, in_act, dY, lddy, dW, dbias, w3slab, g, s, st);
+      if (rc == 0) { dW = nullptr; dbias = nullptr; }
+      else if (rc != RDST_ENOTSUP) return rc;
+    }
     if ((dxdone || !dX) && !dW && !dbias) return 0;
   }
   // MFMA fast paths want dY as plain (B*H*W, Cout) rows
