@@ -82,3 +82,13 @@ int conv3x_dgrad_f32(const float* Wc, const float* dY, int64_t lddy, float* dX, 
                      int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st);
 int conv3x_wgrad_f32(const float* X, int64_t ldx, int in_act, const float* dY, int64_t lddy, float* dW, float* dbias, float* slab,
                      const ConvGeom& g, float s, hipStream_t st);   // conv3x_wgrad.hip; slab: conv3_wgrad_slab_bytes(Cin, Cout)
+// the one-channel 3x3 convolutions on fp32 rows (conv_c1x.hip: plain fp32 FMAs, both fp32 modes): tail conv wide -> 1 and head conv 1 -> wide
+size_t conv_c1x_slab_floats(int C);
+int conv_c1x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const float* R, int64_t ldr, float* Y,
+                     int64_t ldy, const ConvGeom& g, float s, hipStream_t st);
+int conv_in1x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const float* R, int64_t ldr, float* Y,
+                      int64_t ldy, const ConvGeom& g, float s, hipStream_t st);
+int conv_c1x_bwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, const float* dY, int64_t lddy, float* dX, int64_t lddx,
+                     const float* acc, int64_t ldacc, float* dW, float* dbias, float* slab, const ConvGeom& g, float s, hipStream_t st);
+int conv_in1x_wgrad_f32(const float* X, int64_t ldx, int in_act, const float* dY, int64_t lddy, float* dW, float* dbias, float* slab,
+                        const ConvGeom& g, float s, hipStream_t st);

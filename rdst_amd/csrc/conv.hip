@@ -135,6 +135,10 @@ int fwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const float* bia
     if (int rc = conv_in1_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
     if (int rc = conv3_fwd_bf16(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, prepacked, st); rc != RDST_ENOTSUP) return rc;
   }
+  if constexpr (sizeof(T) == 4) {   // the one-channel convs: fp32 vector kernels (conv_c1x.hip), both fp32 modes
+    if (int rc = conv_c1x_fwd_f32(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+    if (int rc = conv_in1x_fwd_f32(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, st); rc != RDST_ENOTSUP) return rc;
+  }
   if constexpr (sizeof(T) == 4) {   // RDST_F32X3: the register-stationary kernels on prepacked hi / lo fragments (conv3x_mfma.hip)
     if (rdst_split())
       if (int rc = conv3x_fwd_f32(X, ldx, in_act, Wc, bias, R, ldr, Y, ldy, g, s, wpack, prepacked, st); rc != RDST_ENOTSUP) return rc;
@@ -164,6 +168,14 @@ int bwd_t(const T* X, int64_t ldx, int in_act, const float* Wc, const T* dY, int
       return rc;
     if (!dX && (dW || dbias) && g.r == 1) {   // one input channel (the head conv: no data gradient, the input is the image)
       if (int rc = conv_in1_wgrad_bf16(X, ldx, in_act, dY, lddy, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP) return rc;
+    }
+  }
+  if constexpr (sizeof(T) == 4) {   // the one-channel convs on fp32 rows (conv_c1x.hip)
+    float* c1slab = reinterpret_cast<float*>(mscr + conv_mfma_scratch_bytes(ConvGeom{g.B, g.H, g.W, g.Cin, g.Cout, g.ks, g.pad, 2}));
+    if (int rc = conv_c1x_bwd_f32(X, ldx, in_act, Wc, dY, lddy, dX, lddx, acc, ldacc, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP)
+      return rc;
+    if (!dX && (dW || dbias) && g.r == 1) {
+      if (int rc = conv_in1x_wgrad_f32(X, ldx, in_act, dY, lddy, dW, dbias, c1slab, g, s, st); rc != RDST_ENOTSUP) return rc;
     }
   }
   bool dxdone = false;

@@ -24,13 +24,15 @@ namespace {
 
 
 __global__ void __launch_bounds__(256) conv3x_pack_kernel(const float* __restrict__ Wc, uint32_t* __restrict__ out, int Cin,
-                                                          int Cout, int K, int N, int ksteps, int ctiles, int mode, float s) {
-  conv3x_pack_block((int)blockIdx.x, Wc, out, Cin, Cout, K, N, ksteps, ctiles, mode, s);
+                                                          int Cout, int K, int N, int ksteps, int ctiles, int mode, float s, int cmul,
+                                                          int coff) {
+  conv3x_pack_block((int)blockIdx.x, Wc, out, Cin, Cout, K, N, ksteps, ctiles, mode, s, cmul, coff);
 }
 
 struct C3Args {
   const float* A; int64_t lda;    // input rows
   int a_bytes;                    // extent of A in bytes (< 2^31): the buffer descriptor's range
+  int ymul, yoff, xmul, xoff;     // pixel (y, x) of the conv's grid = memory pixel (y ymul + yoff, x xmul + xoff) of A (a sub-pixel view)
   const uint32_t* Wp;             // packed hi / lo weight fragments of this launch's channel tiles (tile 0 = channel n0)
   const float* bias;              // (N) or null
   const float* R; int64_t ldr;    // forward residual / dgrad dX_add, output geometry; or null
@@ -122,13 +124,13 @@ __global__ void __launch_bounds__(256, 1) conv3x_kernel(const C3Args p) {
     const int x = sp.x0 - 1 + px;
     const bool ok = x >= 0 && x < W && px < 34 && sl < CF::DSLOTS;
     int off;
-    off = x * ((int)p.lda * 4) + sl * 16;
+    off = (x * p.xmul + p.xoff) * ((int)p.lda * 4) + sl * 16;
     return ok ? off : -1;
   };
   auto dma = [&](const Strip& sp, int rel, int pi, int loff) {
     const int y = sp.y0 - 1 + rel;
     const bool rowok = y >= 0 && y < H;
-    const int rowbase = (int)((((int64_t)sp.b * H + y) * W) * (p.lda * 4));
+    const int rowbase = (int)((((int64_t)sp.b * (H * p.ymul) + (int64_t)y * p.ymul + p.yoff) * ((int64_t)W * p.xmul)) * (p.lda * 4));
     const int off = (rowok && loff >= 0) ? rowbase + loff : p.a_bytes;   // out of range -> the DMA writes zeros
     // Inline asm, not the builtin: the compiler orders every later ds_read behind a builtin LDS-DMA with s_waitcnt
     // vmcnt(0) (it cannot tell that the slots differ), which exposes the whole HBM latency in every step.  The waits are
@@ -459,9 +461,9 @@ int launch_c3(C3Args& p, int ctile0, hipStream_t st, const char* what) {
   return rdst_launch_status(what);
 }
 
-int pack(const float* Wc, uint32_t* out, int Cin, int Cout, int K, int N, int mode, float s, hipStream_t st) {
+int pack(const float* Wc, uint32_t* out, int Cin, int Cout, int K, int N, int mode, float s, hipStream_t st, int cmul = 1, int coff = 0) {
   hipLaunchKernelGGL(conv3x_pack_kernel, dim3((unsigned)conv3x_pack_blocks(K, N)), dim3(256), 0, st, Wc, out, Cin, Cout, K, N,
-                     (K + 15) / 16, (N + 31) / 32, mode, s);
+                     (K + 15) / 16, (N + 31) / 32, mode, s, cmul, coff);
   return rdst_launch_status("conv3x_pack");
 }
 
@@ -499,7 +501,7 @@ int conv3x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, con
   if (abytes >= (1ll << 31) || opix * ldy * 4 >= (1ll << 31) || (R && opix * ldr * 4 >= (1ll << 31))) return RDST_ENOTSUP;
   C3Args p{};
   p.A = X; p.lda = ldx; p.a_bytes = (int)abytes; p.Wp = wp; p.bias = bias; p.R = R; p.ldr = ldr; p.Y = Y; p.ldy = ldy;
-  p.B = g.B; p.H = g.H; p.W = g.W; p.N = g.Cout; p.s = s;
+  p.B = g.B; p.H = g.H; p.W = g.W; p.N = g.Cout; p.s = s; p.ymul = 1; p.xmul = 1;
   if (shape == 1) return launch_c3<150, 2, 1, 2, 1, 2, false, false>(p, 0, st, "conv3x_fwd_150_60");
   if (shape == 2) return launch_c3<60, 2, 1, 1, 2, 2, false, false>(p, 0, st, "conv3x_fwd_60_60");
   C3Args pa = p;
@@ -507,22 +509,37 @@ int conv3x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, con
   return launch_c3<60, 4, 1, 1, 1, 2, false, true>(p, 4, st, "conv3x_fwd_60_240_ps_b");
 }
 
-// dgrad: dX = dX_add + s * conv^T(dY), dY in plain (not pixel-shuffled) geometry.
+// dgrad: dX = dX_add + s * conv^T(dY).  dY is in the OUTPUT geometry: for conv + PixelShuffle(2) the shuffled tensor as it lies — four
+// launches of the 60 -> 60 form, one per sub-pixel q = 2 i + j (dY through a stride-2 pixel view, the weights of conv channels
+// 4 c' + q), each accumulating onto the last.
 int conv3x_dgrad_f32(const float* Wc, const float* dY, int64_t lddy, float* dX, int64_t lddx, const float* acc, int64_t ldacc,
                      int in_act, const ConvGeom& g, float s, void* wpack, hipStream_t st) {
-  if (!wpack || g.ks != 3 || g.pad != 1 || in_act || g.W % 32 || g.r != 1 || ((uintptr_t)wpack & 15)) return RDST_ENOTSUP;
+  if (!wpack || g.ks != 3 || g.pad != 1 || in_act || g.W % 32 || ((uintptr_t)wpack & 15)) return RDST_ENOTSUP;
   if (!rows_aligned(dY) || !rows_aligned(dX) || (acc && !rows_aligned(acc))) return RDST_ENOTSUP;
   int shape = 0;
-  if (g.Cin == 150 && g.Cout == 60) shape = 1;
-  else if (g.Cin == 60 && g.Cout == 60) shape = 2;
+  if (g.Cin == 150 && g.Cout == 60 && g.r == 1) shape = 1;
+  else if (g.Cin == 60 && g.Cout == 60 && g.r == 1) shape = 2;
+  else if (g.Cin == 60 && g.Cout == 240 && g.r == 2) shape = 3;
   if (!shape) return RDST_ENOTSUP;
-  const int64_t abytes = ((g.pixels() - 1) * lddy + g.Cout) * 4;
+  const int64_t abytes = ((g.pixels() * g.r * g.r - 1) * lddy + g.Cout / (g.r * g.r)) * 4;
   if (abytes >= (1ll << 31) || g.pixels() * lddx * 4 >= (1ll << 31) || (acc && g.pixels() * ldacc * 4 >= (1ll << 31))) return RDST_ENOTSUP;
   uint32_t* wp = reinterpret_cast<uint32_t*>(wpack);
-  if (int rc = pack(Wc, wp, g.Cin, g.Cout, g.Cout, g.Cin, PK_DGRAD, s, st)) return rc;
   C3Args p{};
   p.A = dY; p.lda = lddy; p.a_bytes = (int)abytes; p.Wp = wp; p.bias = nullptr; p.R = acc; p.ldr = ldacc; p.Y = dX; p.ldy = lddx;
-  p.B = g.B; p.H = g.H; p.W = g.W; p.N = g.Cin; p.s = s;
+  p.B = g.B; p.H = g.H; p.W = g.W; p.N = g.Cin; p.s = s; p.ymul = 1; p.xmul = 1;
+  if (shape == 3) {
+    constexpr int IMG = 2 * 9 * 4 * 512;   // uint32 per sub-pixel image: 2 channel tiles x 9 taps x 4 k-steps x 2 KB
+    for (int q = 0; q < 4; ++q)
+      if (int rc = pack(Wc, wp + (size_t)q * IMG, g.Cin, g.Cout, 60, g.Cin, PK_DGRAD, s, st, 4, q)) return rc;
+    for (int q = 0; q < 4; ++q) {
+      C3Args pq = p;
+      pq.Wp = wp + (size_t)q * IMG; pq.ymul = 2; pq.yoff = q >> 1; pq.xmul = 2; pq.xoff = q & 1;
+      if (q > 0) { pq.R = dX; pq.ldr = lddx; }
+      if (int rc = launch_c3<60, 2, 1, 1, 2, 2, false, false>(pq, 0, st, "conv3x_dgrad_240_60_q")) return rc;
+    }
+    return 0;
+  }
+  if (int rc = pack(Wc, wp, g.Cin, g.Cout, g.Cout, g.Cin, PK_DGRAD, s, st)) return rc;
   if (shape == 1) {
     C3Args pa = p;
     if (int rc = launch_c3<60, 4, 1, 1, 1, 2, false, false>(pa, 0, st, "conv3x_dgrad_60_150a")) return rc;

@@ -226,8 +226,9 @@ static __host__ __device__ inline size_t lin3x_pack_bytes(int K, int N) {
 
 // ---- RDST_F32X3 image of a 3x3 convolution (conv3x_mfma.hip): fragment (ct, tap, ks) = [hi: 64 lanes x 8 bf16][lo: 64 lanes x 8 bf16];
 // lane (r, h): output channel n = 32 ct + r, contraction k = 16 ks + 8 h + e; same PK_ modes as conv3_pack_block
+// (cmul, coff): contraction index k of a PK_DGRAD image is conv output channel cmul k + coff (the sub-pixel slices of conv + PixelShuffle)
 __device__ __forceinline__ void conv3x_pack_block(int bid, const float* __restrict__ Wc, uint32_t* __restrict__ out, int Cin, int Cout,
-                                                  int K, int N, int ksteps, int ctiles, int mode, float s) {
+                                                  int K, int N, int ksteps, int ctiles, int mode, float s, int cmul = 1, int coff = 0) {
   const int i = bid * 256 + threadIdx.x;          // one thread per (fragment, lane): 16 B of hi and 16 B of lo
   const int total = ctiles * 9 * ksteps * 64;
   if (i >= total) return;
@@ -246,7 +247,7 @@ __device__ __forceinline__ void conv3x_pack_block(int bid, const float* __restri
       float x = 0.f;
       if (n < N && k < K) {
         if (mode == PK_FWD) x = Wc[((int64_t)n * Cin + k) * 9 + tap];
-        else x = Wc[((int64_t)k * Cin + n) * 9 + (8 - tap)];   // PK_DGRAD: contraction over co, mirrored tap
+        else x = Wc[((int64_t)(cmul * k + coff) * Cin + n) * 9 + (8 - tap)];   // PK_DGRAD: contraction over co, mirrored tap
       }
       v[e1] = x * s;
     }
