@@ -119,6 +119,10 @@ def load() -> C.CDLL:
     return lib
 
 
+def loaded() -> bool:
+    return _lib is not None
+
+
 def _missing(name):
     def raiser(*_a, **_k):
         raise RuntimeError(f"rdst_amd: {LIB_PATH} does not export {name}; rebuild with `python -m rdst_amd.build --force`")

@@ -31,6 +31,17 @@
 #define LBX_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no weight-gradient MFMAs, 2 no data-gradient MFMAs, 4 no dX stores, 8 no slab dump, 16 no conversion pass, 32 no tile DMA (zero pieces)
 #endif
 
+// -DLBX_STAMPS: workgroup 0 prints, per wave, the clock64() ticks it spent in each phase of the tile loop (tools/abl_build.sh)
+#ifdef LBX_STAMPS
+#define LBX_T0 long long tk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#define LBX_T(i) { const long long n_ = clock64(); tk_[i] += n_ - tl_; tl_ = n_; }
+#define LBX_TP(role) if (blockIdx.x == 0 && lane == 0) printf("wave %d %s: issue+wait %lld  barrierA %lld  finish_ln %lld  convert %lld  barrierB %lld  compute %lld (product %lld, rest %lld)\n", wave, role, tk_[0], tk_[1], tk_[2], tk_[3], tk_[4], tk_[5] + tk_[6] + tk_[7], tk_[6], tk_[7]);
+#else
+#define LBX_T0
+#define LBX_T(i)
+#define LBX_TP(role)
+#endif
+
 namespace {
 using namespace wahd;
 constexpr int BX_PLAIN = 0, BX_LN = 1, BX_GELU = 2;
@@ -63,7 +74,10 @@ struct LBX {
   // raw rows in LDS: 16-byte slots, a region = whole 1 KB DMA pieces
   static constexpr int RSX = (4 * K + 15) / 16 * 16, RSY = (4 * N + 15) / 16 * 16;
   static constexpr int TPX = (32 * RSX + 1023) / 1024, TPY = (32 * RSY + 1023) / 1024, TPS = MODE == BX_LN ? 1 : 0;
-  static constexpr int TPT = TPY + TPX + TPS, CNT = (TPT + NWV - 1) / NWV;   // pieces per tile / per wave
+  static constexpr int TPT = TPY + TPX + TPS, CNT = (TPT + NWG - 1) / NWG;   // pieces per tile / per weight-gradient wave (they issue the DMA)
+  // the conversion pass belongs to the weight-gradient waves too (the data-gradient waves are the workgroup's critical path): TPR threads
+  // on one token row, thread t of a row takes its 4-float chunks t, t + TPR, ... (dY's CKY chunks first, then x's CKX)
+  static constexpr int NCV = 64 * NWG, TPR = NCV / 32, CKR = CKY + CKX, NJ = (CKR + TPR - 1) / TPR;
   static constexpr int RAW_X = TPY * 1024, RAW_S = RAW_X + TPX * 1024, RAWB = RAW_S + TPS * 1024;
   static constexpr int CP = 32 * NCT;
   static constexpr int LDX = lbx_ld(CP), LDY = lbx_ld(32 * NW);
@@ -79,11 +93,10 @@ struct LBX {
   static constexpr int OFF_RAW = (OFF_BNC + NDG * BR * BSTR + 1023) / 1024 * 1024;
   static constexpr int SMEM = OFF_RAW + 2 * RAWB;
   static constexpr int WPS = (NWV + 3) / 4;
-  // conversion pass: all of a thread's chunks in flight at once — except where a wave already holds >= 128 registers of accumulators or
-  // fragments (there the batch spills into the tile loop: 1.2x slower, measured)
-  static constexpr bool CVB = TN * TC * 16 < 128 && DT * KN * 8 < 128;
+  static constexpr int CVB = TN * TC * 16 < 128 ? 8 : 4;   // chunks of the conversion pass in flight per thread
   static_assert(SMEM <= 160 * 1024, "LDS");
-  static_assert(TPT >= NWV && CNT < 64, "every wave owns at least one piece of a tile");
+  static_assert(CNT < 64, "pieces per wave");
+  static_assert((K % 4 == 0 || K % 4 == 2) && (N % 4 == 0 || N % 4 == 2), "a row's last chunk holds 4 or 2 floats");
   static_assert(MODE != BX_LN || DT == 1, "LayerNorm backward: one channel tile per data-gradient wave");
 };
 
@@ -127,9 +140,8 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
   const int64_t t0 = (int64_t)blockIdx.x * p.tiles_per_wg;
   const int64_t t1 = t0 + p.tiles_per_wg < p.ntiles ? t0 + p.tiles_per_wg : p.ntiles;
 
-  // ---- raw rows by LDS-DMA: every wave issues exactly CNT 1 KB pieces per tile (a wave whose share is one short repeats its last
-  // piece; rows past M and the tail of a region arrive as zeros), so "the tile issued one iteration ago has landed" is vmcnt(CNT)
-  // behind the next tile's issue.  (The addend loads and dX stores are the compiler's: its waits can only wait for more.)
+  // ---- raw rows by LDS-DMA, issued by the weight-gradient waves (CNT 1 KB pieces of a tile each; rows past M and the tail of a region
+  // arrive as zeros or are never read).  A lane's offset inside a tile is the same for every tile: computed once.
   typedef uint32_t u32x4s_t __attribute__((ext_vector_type(4)));
   auto make_rsrc = [&](const void* ptr, uint32_t bytes) {
     u32x4s_t v;
@@ -147,124 +159,113 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
   };
-  auto issue_tile = [&](int64_t tile, int b) {
-    const bool tin = tile < t1 && !(LBX_ABL & 32);
+  int dmo[CF::CNT];
+  if (is_wg) {
 #pragma unroll
     for (int i = 0; i < CF::CNT; ++i) {
-      int pc = wave + CF::NWV * i;
-      pc = pc < CF::TPT ? pc : pc - CF::NWV;                  // wave-uniform
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(CF::OFF_RAW + b * CF::RAWB + pc * 1024));
+      const int pc = wave + NWG * i;   // wave-uniform
+      int o = 0x40000000;              // (lanes past the 32 rows: the region's tail, never read)
       if (pc < CF::TPY) {
         const int sidx = pc * 64 + lane, row = sidx / (CF::RSY / 16), sl = sidx - row * (CF::RSY / 16);
-        const int64_t grow = tile * 32 + row;
-        const bool ok = tin && row < 32 && grow < p.M;
-        dma(rsy, dst, ok ? (int)(grow * (p.lddy * 4)) + sl * 16 : p.y_bytes);
+        if (row < 32) o = row * (int)(p.lddy * 4) + sl * 16;
       } else if (pc < CF::TPY + CF::TPX) {
         const int sidx = (pc - CF::TPY) * 64 + lane, row = sidx / (CF::RSX / 16), sl = sidx - row * (CF::RSX / 16);
-        const int64_t grow = tile * 32 + row;
-        const bool ok = tin && row < 32 && grow < p.M;
-        dma(rsx, dst, ok ? (int)(grow * (p.ldx * 4)) + sl * 16 : p.x_bytes);
-      } else {   // the tile's 32 (mean, rstd) pairs: 16 lanes of one piece
-        const int64_t grow = tile * 32 + 2 * lane;
-        const bool ok = tin && lane < 16 && grow < p.M;
-        dma(rss, dst, ok ? (int)(grow * 8) : (int)(p.M * 8));
+        if (row < 32) o = row * (int)(p.ldx * 4) + sl * 16;
+      } else if (lane < 16) {
+        o = lane * 16;                 // the tile's 32 (mean, rstd) pairs: two per lane
       }
+      dmo[i] = o;
+    }
+  }
+  auto issue_tile = [&](int64_t tile, int b) {
+    if (tile >= t1 || (LBX_ABL & 32)) return;
+    const int ty = (int)(tile * 32 * (p.lddy * 4)), tx = (int)(tile * 32 * (p.ldx * 4)), ts = (int)(tile * 256);
+#pragma unroll
+    for (int i = 0; i < CF::CNT; ++i) {
+      const int pc = wave + NWG * i;
+      if (pc >= CF::TPT) break;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(CF::OFF_RAW + b * CF::RAWB + pc * 1024));
+      if (pc < CF::TPY) dma(rsy, dst, dmo[i] + ty);
+      else if (pc < CF::TPY + CF::TPX) dma(rsx, dst, dmo[i] + tx);
+      else dma(rss, dst, dmo[i] + ts);
     }
   };
-  // ---- the conversion pass of one tile, all waves: raw chunk of 4 floats -> (x-hat | GELU | as it is) -> hi / lo into the planes ----
+  // ---- the conversion pass of one tile (weight-gradient waves): raw chunk of 4 floats -> (x-hat | GELU | as it is) -> hi / lo into the
+  // planes.  Every address is a per-thread base + a compile-time distance; CVB chunks in flight (one at a time the pass is a chain of
+  // LDS round trips).  A row's last chunk may hold only 2 floats: the other two are forced to the planes' pad values (zeros; the ones
+  // column of X' where it falls into that chunk) — what the raw slot holds there is somebody else's data.
+  const int cvrow = tid / CF::TPR, cvt = tid - cvrow * CF::TPR;
   auto convert = [&](int b) {
+    if (LBX_ABL & 16) return;
+    constexpr int TPR = CF::TPR, CKY = CF::CKY, CKR = CF::CKR, NJ = CF::NJ, CB = CF::CVB;
     const char* raw = smem + CF::OFF_RAW + b * CF::RAWB;
-    // every thread's chunks of the tile: all LDS reads first (one chunk at a time the pass was a chain of LDS round trips: 29 of 96 us
-    // at norm1 + qkv, C = 60), then the arithmetic, then the writes
-    if constexpr (!CF::CVB) {
-      for (int idx = tid; idx < ((LBX_ABL & 16) ? 0 : CF::NYC + CF::NXC); idx += NT) {
-        const bool isy = idx < CF::NYC;
-        const int li = isy ? idx : idx - CF::NYC;
-        const int per = isy ? CF::CKY : CF::CKX, width = isy ? N : K;
-        const int row = li / per, chk = li - row * per;
-        int c0 = chk * 4;
-        c0 = c0 + 4 <= width ? c0 : width - 4;
-        const char* src = raw + (isy ? row * CF::RSY : CF::RAW_X + row * CF::RSX) + c0 * 4;
-        float f[4];
-        if ((c0 & 3) == 0) {
-          const float4 v = *reinterpret_cast<const float4*>(src);
-          f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-        } else {
-          const float2 v0 = *reinterpret_cast<const float2*>(src), v1 = *reinterpret_cast<const float2*>(src + 8);
-          f[0] = v0.x; f[1] = v0.y; f[2] = v1.x; f[3] = v1.y;
-        }
-        if (!isy) {
-          if (MODE == BX_LN) {
-            const float2 s2 = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
+    const char* sy = raw + cvrow * CF::RSY + 16 * cvt;
+    const char* sx = raw + CF::RAW_X + cvrow * CF::RSX + 16 * (cvt - CKY);
+    char* dy = smem + CF::OFF_YH + cvrow * LDY + 8 * cvt;
+    char* dx = smem + cvrow * LDX + 8 * (cvt - CKY);
+    float rs = 1.f, nm = 0.f;
+    if (MODE == BX_LN) {
+      const float2 s2 = *reinterpret_cast<const float2*>(raw + CF::RAW_S + cvrow * 8);
+      rs = s2.y; nm = -s2.x * s2.y;
+      if (cvt == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[cvrow] = s2.y;   // (kept beside the planes: the raw buffer is the
+      // next-but-one tile's DMA target before the data-gradient waves read it)
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] = (f[e] - s2.x) * s2.y;
-            if (c0 == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[row] = s2.y;
+    for (int j0 = 0; j0 < NJ; j0 += CB) {
+      float4 v[CB];
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const int j = j0 + u;
+        if (j >= NJ) continue;
+        const bool ally = TPR * (j + 1) <= CKY, allx = TPR * j >= CKY;
+        const int cidx = cvt + TPR * j;
+        const bool isy = ally ? true : allx ? false : cidx < CKY;
+        const bool on = TPR * (j + 1) <= CKR ? true : cidx < CKR;
+        const char* src = (isy ? sy : sx) + 16 * TPR * j;
+        if (TPR * (j + 1) > CKR) src = on ? src : sy;   // (a thread without a chunk in the last round reads something valid)
+        v[u] = *reinterpret_cast<const float4*>(src);
+      }
+#pragma unroll
+      for (int u = 0; u < CB; ++u) {
+        const int j = j0 + u;
+        if (j >= NJ) continue;
+        const bool ally = TPR * (j + 1) <= CKY, allx = TPR * j >= CKY;
+        const int cidx = cvt + TPR * j;
+        const bool isy = ally ? true : allx ? false : cidx < CKY;
+        const bool on = TPR * (j + 1) <= CKR ? true : cidx < CKR;
+        float f[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        if (!ally) {
+          float g[4];
+          if (MODE == BX_LN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(f[e], rs, nm);
           } else if (MODE == BX_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[e] = gelu_fast(f[e]);
+            for (int e = 0; e < 4; ++e) g[e] = gelu_fast(f[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = f[e];
           }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = isy ? f[e] : g[e];
+        }
+        if (N % 4 == 2 && TPR * j <= CKY - 1 && CKY - 1 < TPR * (j + 1)) {
+          if (cidx == CKY - 1) { f[2] = 0.f; f[3] = 0.f; }
+        }
+        if (K % 4 == 2 && TPR * j <= CKR - 1 && CKR - 1 < TPR * (j + 1)) {
+          if (cidx == CKR - 1) { f[2] = 1.f; f[3] = 0.f; }
         }
         u32x2_t hi, lo;
         split4(f, hi, lo);
-        char* dst = smem + (isy ? CF::OFF_YH + row * LDY : row * LDX) + c0 * 2;
-        put8(dst, hi);
-        put8(dst + (isy ? 32 * LDY : CF::OFF_XL), lo);
-      }
-      return;
-    }
-    constexpr int NPT = (CF::NYC + CF::NXC + NT - 1) / NT;
-    {
-    constexpr int ub = 0;
-    float f[NPT][4];
-    float2 st2[NPT];
-    int dsto[NPT];
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-      const int idx = tid + NT * (ub + u);
-      const bool on = idx < ((LBX_ABL & 16) ? 0 : CF::NYC + CF::NXC);
-      const bool isy = idx < CF::NYC;
-      const int li = on ? (isy ? idx : idx - CF::NYC) : 0;
-      const int per = isy ? CF::CKY : CF::CKX, width = isy ? N : K;
-      const int row = li / per, chk = li - row * per;
-      int c0 = chk * 4;
-      c0 = c0 + 4 <= width ? c0 : width - 4;   // (a ragged last chunk overlaps its neighbour and rewrites the same values)
-      const char* src = raw + (isy ? row * CF::RSY : CF::RAW_X + row * CF::RSX) + c0 * 4;
-      if ((c0 & 3) == 0) {
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        f[u][0] = v.x; f[u][1] = v.y; f[u][2] = v.z; f[u][3] = v.w;
-      } else {
-        const float2 v0 = *reinterpret_cast<const float2*>(src), v1 = *reinterpret_cast<const float2*>(src + 8);
-        f[u][0] = v0.x; f[u][1] = v0.y; f[u][2] = v1.x; f[u][3] = v1.y;
-      }
-      st2[u] = make_float2(0.f, 1.f);
-      if (MODE == BX_LN && !isy) st2[u] = *reinterpret_cast<const float2*>(raw + CF::RAW_S + row * 8);
-      // plane offset of the chunk's hi half | lo-plane distance in the top bits; < 0: no chunk
-      dsto[u] = on ? ((isy ? CF::OFF_YH + row * LDY : row * LDX) + c0 * 2) | (isy ? 0 : 1 << 30) : -1;
-      if (MODE == BX_LN && !isy && on && c0 == 0) reinterpret_cast<float*>(smem + CF::OFF_SM)[row] = st2[u].y;   // (kept beside the planes:
-      // the raw buffer is the next-but-one tile's DMA target as soon as the fastest wave gets there)
-    }
-#pragma unroll
-    for (int u = 0; u < NPT; ++u) {
-      if (dsto[u] < 0) continue;
-      const bool isx = (dsto[u] >> 30) & 1;
-      if (isx) {
-        if (MODE == BX_LN) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) f[u][e] = (f[u][e] - st2[u].x) * st2[u].y;
-        } else if (MODE == BX_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) f[u][e] = gelu_fast(f[u][e]);
+        if (on) {
+          char* dst = (isy ? dy : dx) + 8 * TPR * j;
+          *reinterpret_cast<u32x2_t*>(dst) = hi;
+          *reinterpret_cast<u32x2_t*>(dst + (isy ? 32 * LDY : CF::OFF_XL)) = lo;
         }
       }
-      u32x2_t hi, lo;
-      split4(f[u], hi, lo);
-      char* dst = smem + (dsto[u] & 0x3fffffff);
-      put8(dst, hi);
-      put8(dst + (isx ? CF::OFF_XL : 32 * LDY), lo);
-    }
     }
   };
-  if (t0 < t1) issue_tile(t0, 0);
+  if (is_wg) issue_tile(t0, 0);
 
   // The two roles run SEPARATE copies of the tile loop (same barrier count): in one loop body the register allocator would have
   // to keep the G tiles and the W fragments alive side by side in every wave.
@@ -277,13 +278,18 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
 #pragma unroll
         for (int v = 0; v < 16; ++v) G[i][j][v] = 0.f;
     int b = 0;
+    LBX_T0
     for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
       const char* buf = smem;
-      issue_tile(tile + 1, b ^ 1);   // (raw buffer b ^ 1: converted one iteration ago)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::CNT) : "memory");
-      __syncthreads();   // raw tile landed (every wave's pieces); everybody is done with the planes
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LBX_T(0)
+      __syncthreads();   // raw tile landed (every wave's pieces); everybody is done with the planes and with raw buffer b ^ 1
+      LBX_T(1)
+      issue_tile(tile + 1, b ^ 1);
       convert(b);
+      LBX_T(3)
       __syncthreads();   // planes staged
+      LBX_T(4)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         Pack16 yh[TN], yl[TN];
@@ -311,7 +317,9 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
           }
         }
       }
+      LBX_T(5)
     }
+    LBX_TP("wgrad")
     if (LN) __syncthreads();   // (the data-gradient waves' closing barrier)
     // fp32 slab G [N][K+1] of this workgroup: consecutive lanes = consecutive channels of one row
     float* my = p.slab + (int64_t)blockIdx.x * p.slab_stride;
@@ -375,8 +383,7 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t grow = row0 + 8 * k + crow;
-      if (MODE == BX_GELU) o[k] = load4(p.X, p.ldx, grow, col);
-      else if (has_acc) o[k] = load4(p.Acc, p.ldacc, grow, col);
+      if (has_acc) o[k] = load4(p.Acc, p.ldacc, grow, col);
       else if (has_acc2) o[k] = load4(p.Acc2, p.ldacc2, grow, col);
       if (MODE != BX_GELU && has_acc && has_acc2) {
         const u32x4_a4 a2 = load4(p.Acc2, p.ldacc2, grow, col);
@@ -407,7 +414,7 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
         float4 v = *reinterpret_cast<const float4*>(bnc + (8 * kk + crow) * BSTR + cch * 16);
         const float a[4] = {__uint_as_float(adv[k].x), __uint_as_float(adv[k].y), __uint_as_float(adv[k].z), __uint_as_float(adv[k].w)};
         if (MODE == BX_GELU) {
-          v.x *= gelu_grad_fast(a[0]); v.y *= gelu_grad_fast(a[1]); v.z *= gelu_grad_fast(a[2]); v.w *= gelu_grad_fast(a[3]);
+          v.x *= a[0]; v.y *= a[1]; v.z *= a[2]; v.w *= a[3];
         } else if (has_acc || has_acc2) {
           v.x += a[0]; v.y += a[1]; v.z += a[2]; v.w += a[3];
         }
@@ -431,17 +438,26 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
     const lds_cp yrow = (lds_cp)(buf + CF::OFF_YH + r * LDY + hh * 16);
 #pragma unroll
     for (int v = 0; v < 16; ++v) dxv[v] = 0.f;
+    // the dY packs PD k-steps ahead of the products (read just in time every k-step was an LDS round trip + three MFMAs in a row:
+    // 75-80 cycles per MFMA, measured); sched_barrier pins the order
+    constexpr int PD = KN < 3 ? KN : 3;
+    Pack16 yh[PD], yl[PD];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) { yh[i] = lds_pack(yrow + 32 * i); yl[i] = lds_pack(yrow + 32 * LDY + 32 * i); }
 #pragma unroll
     for (int ks = 0; ks < KN; ++ks) {
-      const Pack16 yh = lds_pack(yrow + 32 * ks), yl = lds_pack(yrow + 32 * LDY + 32 * ks);
+      const Pack16 ch = yh[ks % PD], cl = yl[ks % PD];
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + PD < KN) { yh[ks % PD] = lds_pack(yrow + 32 * (ks + PD)); yl[ks % PD] = lds_pack(yrow + 32 * LDY + 32 * (ks + PD)); }
 #if !(LBX_ABL & 2)
       // rows = channels, columns = tokens
-      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfl[dt][ks]), __builtin_bit_cast(bf16x8_t, yh), dxv, 0, 0, 0);
-      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfh[dt][ks]), __builtin_bit_cast(bf16x8_t, yl), dxv, 0, 0, 0);
-      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfh[dt][ks]), __builtin_bit_cast(bf16x8_t, yh), dxv, 0, 0, 0);
+      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfl[dt][ks]), __builtin_bit_cast(bf16x8_t, ch), dxv, 0, 0, 0);
+      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfh[dt][ks]), __builtin_bit_cast(bf16x8_t, cl), dxv, 0, 0, 0);
+      dxv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfh[dt][ks]), __builtin_bit_cast(bf16x8_t, ch), dxv, 0, 0, 0);
 #else
-      dxv[0] += __uint_as_float(yh.w[0] ^ yl.w[1] ^ wfh[dt][ks].w[0] ^ wfl[dt][ks].w[1]);
+      dxv[0] += __uint_as_float(ch.w[0] ^ cl.w[1] ^ wfh[dt][ks].w[0] ^ wfl[dt][ks].w[1]);
 #endif
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // LayerNorm: state of the unfinished tile — dA, x-hat and rstd of the lane's own elements, the addend chunks, the first row —
@@ -514,20 +530,42 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
     }
   };
   int b = 0;
+  LBX_T0
   for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
     const char* buf = smem;
-    issue_tile(tile + 1, b ^ 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CF::CNT) : "memory");
+    LBX_T(0)
     __syncthreads();
+    LBX_T(1)
     if constexpr (LN) {
       if (prow0 >= 0) finish_ln(b ^ 1);   // the previous tile's rows: every channel tile's partial sums are in `red` now
     }
-    convert(b);
+    LBX_T(2)
+    // fc2: GELU'(pre-activation) of the wave's own channel tiles from the raw x tile, in the finish's row-wise layout — while the
+    // weight-gradient waves convert (in the finish it was 5.8 of the 8.8 k cycles the data-gradient waves spent per tile)
+    u32x4_a4 gp[MODE == BX_GELU ? DT : 1][4];
+    if constexpr (MODE == BX_GELU) {
+      const char* rawx = smem + CF::OFF_RAW + b * CF::RAWB + CF::RAW_X;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int col = 32 * (DT * dwv + dt) + 4 * cch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 pa = *reinterpret_cast<const float4*>(rawx + (8 * k + crow) * CF::RSX + (col < K ? col : 0) * 4);
+          gp[dt][k].x = __float_as_uint(gelu_grad_fast(pa.x)); gp[dt][k].y = __float_as_uint(gelu_grad_fast(pa.y));
+          gp[dt][k].z = __float_as_uint(gelu_grad_fast(pa.z)); gp[dt][k].w = __float_as_uint(gelu_grad_fast(pa.w));
+          // (pinned here: left alone the compiler sinks the arithmetic behind the barrier, to its use)
+          asm volatile("" : "+v"(gp[dt][k].x), "+v"(gp[dt][k].y), "+v"(gp[dt][k].z), "+v"(gp[dt][k].w));
+        }
+      }
+    }
+    LBX_T(3)
     __syncthreads();
+    LBX_T(4)
     const int64_t row0 = tile * 32;
     if constexpr (LN) {
       load_runs(row0 + r, adp);   // consumed one tile later
       product(buf, 0, dxp);
+      LBX_T(6)
       prow0 = row0;
       // x-hat of the lane's own (token, channel) elements = hi + lo of the planes; partial row sums of this channel tile
       const lds_cp xrow = (lds_cp)(buf + r * LDX) + (32 * dwv + 4 * hh) * 2;
@@ -554,15 +592,24 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
         const int ct = DT * dwv + dt;
         f32x16 dxv;
         u32x4_a4 adv[4];
-        load_addends(row0, ct, adv);
+        if constexpr (MODE == BX_GELU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) adv[k] = gp[dt][k];
+        } else {
+          load_addends(row0, ct, adv);
+        }
         product(buf, dt, dxv);
+        LBX_T(6)
         float o[16];
 #pragma unroll
         for (int v = 0; v < 16; ++v) o[v] = dxv[v];
         finish(o, adv, ct, row0);
+        LBX_T(7)
       }
     }
+    LBX_T(7)
   }
+  LBX_TP("dgrad")
   if constexpr (LN) {
     __syncthreads();   // (the last tile's partial sums)
     if (prow0 >= 0) finish_ln(b ^ 1);

@@ -579,8 +579,12 @@ class _ReduceBatchState(type):
     def _state(cls):
         st = cls._tls.__dict__
         if "depth" not in st:
-            st.update(depth=0, keep=[], fresh=0, owner=-1, mixed=False)
+            st.update(depth=0, keep=[], fresh=0, owner=-1, mixed=False, epoch=cls.EPOCH)
         return st
+
+    # bumped by reset_backward_state(): a thread whose open batch was begun in an older epoch drops it (abort) before it
+    # queues, flushes or nests anything - how the main thread reaches the autograd device thread's batch after a failed pass
+    EPOCH = 0
 
     depth = property(lambda cls: cls._state()["depth"], lambda cls, v: cls._state().__setitem__("depth", v))
     keep = property(lambda cls: cls._state()["keep"], lambda cls, v: cls._state().__setitem__("keep", v))
@@ -589,6 +593,7 @@ class _ReduceBatchState(type):
     # device thread serves every concurrent backward() of that device, so nodes of two passes can interleave
     owner = property(lambda cls: cls._state()["owner"], lambda cls, v: cls._state().__setitem__("owner", v))
     mixed = property(lambda cls: cls._state()["mixed"], lambda cls, v: cls._state().__setitem__("mixed", v))
+    epoch = property(lambda cls: cls._state()["epoch"], lambda cls, v: cls._state().__setitem__("epoch", v))
 
 
 class _ReduceBatch(metaclass=_ReduceBatchState):
@@ -619,12 +624,34 @@ class _ReduceBatch(metaclass=_ReduceBatchState):
         return _ReduceBatch.mixed
 
     @staticmethod
+    def _drop_stale(lib):
+        """This thread's batch was opened before the last reset_backward_state(): the pass it belonged to is dead."""
+        if _ReduceBatch.epoch != type(_ReduceBatch).EPOCH:
+            _ReduceBatch.abandon(lib)
+            _ReduceBatch.epoch = type(_ReduceBatch).EPOCH
+
+    @staticmethod
     def begin(lib):
+        _ReduceBatch._drop_stale(lib)
         if _ReduceBatch.depth == 0:
             _lib.check(lib.rdst_reduce_batch_begin(), "rdst_reduce_batch_begin")
             _ReduceBatch.owner = _ReduceBatch._task()
             _ReduceBatch.mixed = False
         _ReduceBatch.depth += 1
+
+    @staticmethod
+    def begin_layer(lib):
+        """The dense join's outer batch (first node of a DenseSTLayer's backward).  Inside ONE pass no batch is open here,
+        so an open one is either a leftover of this pass's task (a node raised and the pass was re-entered: drop it) or the
+        batch of ANOTHER live pass served by the same device thread: that one keeps its queued reductions - this pass
+        nests inside it and from here on every node flushes before it returns (`mixed`)."""
+        _ReduceBatch._drop_stale(lib)
+        if _ReduceBatch.depth > 0:
+            if _ReduceBatch.owner == _ReduceBatch._task():
+                _ReduceBatch.abandon(lib)
+            else:
+                _ReduceBatch.mixed = True
+        _ReduceBatch.begin(lib)
 
     @staticmethod
     def end(lib, keep=None):
@@ -642,6 +669,7 @@ class _ReduceBatch(metaclass=_ReduceBatchState):
     def settle(lib):
         """Last statement of a node's backward: if a batch is still open around this node and the node handed out a
         gradient destination that autograd may read on return, run what is queued now (and keep the batch open)."""
+        _ReduceBatch._drop_stale(lib)
         if _ReduceBatch.depth > 0 and (_ReduceBatch.fresh or _ReduceBatch._foreign()):
             try:
                 _lib.check(lib.rdst_reduce_batch_end(_stream()), "rdst_reduce_batch_end")
@@ -662,6 +690,15 @@ class _ReduceBatch(metaclass=_ReduceBatchState):
         _ReduceBatch.keep = []
         _ReduceBatch.fresh = 0
         _ReduceBatch.mixed = False
+
+
+def reset_backward_state() -> None:
+    """After a backward pass that did not run to its end (an exception inside a node, a failed HIP-graph capture): every
+    thread drops the reduction batch it still holds open - its queued jobs name workspaces of the dead pass - the next
+    time it touches one.  The calling thread's is dropped at once."""
+    type(_ReduceBatch).EPOCH += 1
+    if _lib.loaded():
+        _ReduceBatch._drop_stale(_lib.load())
 
 
 class GradSink:
@@ -698,8 +735,7 @@ class _DenseJoin(torch.autograd.Function):
             ctx.sink.extra = g[..., :ctx.c]
             if g.is_cuda and not TWO_STREAM_BACKWARD:
                 lib = _lib.load()
-                _ReduceBatch.abandon(lib)   # (only after a backward that did not run to its end)
-                _ReduceBatch.begin(lib)
+                _ReduceBatch.begin_layer(lib)
                 ctx.sink.batch_open = True
             return None, g[..., ctx.c:], None, None
         return g[..., :ctx.c], g[..., ctx.c:], None, None

@@ -155,8 +155,9 @@ class DPTrainStep:
             torch.cuda.synchronize()
             # a backward that died half way leaves a reduction batch open and bucket views on offer: drop both (the
             # queued reductions name workspaces of the failed capture; running them later would write through freed memory)
-            from . import _lib, ops
-            ops._ReduceBatch.abandon(_lib.load())
+            # (the batch lives on autograd's device thread: reset_backward_state() reaches it through an epoch counter)
+            from . import ops
+            ops.reset_backward_state()
             dp._OFFERED = {}
             self.bucket.gather()
             self.use_graph, self.graph, self._static, self._graph_report = False, None, None, None

@@ -182,5 +182,51 @@ def test_two_threads_backward_at_once_vs_oracle():
         assert not errs, errs
         for net in nets:
             _check(net, g, 1.0)
+    # the counters live on autograd's DEVICE thread: read them there, from a hook on the last node of one more (solo) pass.
+    # A batch the mixed passes left open would make this pass nest inside it and end one level up.
     from rdst_amd import ops
-    assert ops._ReduceBatch.depth == 0
+    seen = []
+    net = nets[0]
+    net.zero_grad(set_to_none=True)
+    first = next(p for p in net.parameters() if p.requires_grad)
+    h = first.register_hook(lambda g_: seen.append((ops._ReduceBatch.depth, ops._ReduceBatch.mixed)))
+    F.l1_loss(net(x), tgt).backward()
+    torch.cuda.synchronize()
+    h.remove()
+    assert seen and seen[-1] == (0, False), seen
+    _check(net, g, 1.0)
+
+
+def test_backward_that_raises_then_clean_pass_vs_oracle():
+    """A hook raises in the middle of a backward: the dense join's reduction batch of that pass stays open on autograd's
+    device thread.  The next pass must not run those queued jobs as its own and must not lose its own: without a reset it
+    nests inside the dead batch and flushes at every node; ``ops.reset_backward_state()`` (what the trainer calls after a
+    failed capture) makes the device thread drop the dead batch, and the counters return to zero."""
+    from rdst_amd import ops
+    net, g, x, tgt = _tiny()
+    mid = [p for n, p in net.named_parameters() if n.endswith("attn.proj.weight")][0]   # a block inside the first layer
+
+    def boom(_g):
+        raise RuntimeError("boom")
+    h = mid.register_hook(boom)
+    try:
+        F.l1_loss(net(x), tgt).backward()
+        raised = False
+    except RuntimeError:
+        raised = True
+    h.remove()
+    assert raised
+    torch.cuda.synchronize()
+    for reset in (False, True):
+        if reset:
+            ops.reset_backward_state()
+        net.zero_grad(set_to_none=True)
+        seen = []
+        first = next(p for p in net.parameters() if p.requires_grad)
+        hk = first.register_hook(lambda g_: seen.append(ops._ReduceBatch.depth))
+        F.l1_loss(net(x), tgt).backward()
+        torch.cuda.synchronize()
+        hk.remove()
+        _check(net, g, 1.0)
+        if reset:
+            assert seen[-1] == 0, seen

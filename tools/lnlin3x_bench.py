@@ -12,7 +12,11 @@ SH = [(60, 180, 1, 0, 1, "qkv60"), (90, 270, 1, 0, 1, "qkv90"), (120, 360, 1, 0,
       (60, 120, 1, 0, 1, "fc1_60"), (90, 180, 1, 0, 1, "fc1_90"), (120, 240, 1, 0, 1, "fc1_120"), (120, 60, 0, 1, 0, "fc2_60"),
       (180, 90, 0, 1, 0, "fc2_90"), (240, 120, 0, 1, 0, "fc2_120")]
 tot = 0.0
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]   # shape names; --once: a single call each (the -DLBX_STAMPS build prints)
+ONCE = "--once" in sys.argv
 for K, N, ln, act, add, name in SH:
+    if ONLY and name not in ONLY:
+        continue
     NB = 3
     xs = [torch.randn(M, K, device=dev) for _ in range(NB)]
     dys = [torch.randn(M, N, device=dev) for _ in range(NB)]
@@ -33,6 +37,10 @@ for K, N, ln, act, add, name in SH:
                                     P(dlw), P(dlb), wsp.data_ptr(), nws, M, K, N, 1.0, _lib.F32X3, st)
         assert rc == 0, (rc, lib.rdst_last_error())
 
+    if ONCE:
+        print(name, flush=True)
+        call(0); torch.cuda.synchronize()
+        continue
     for i in range(3):
         call(i)
     torch.cuda.synchronize()
