@@ -154,8 +154,11 @@ __global__ void __launch_bounds__((CF::NT), (CF::WPS)) lnlin3x_bwd_kernel(const 
   const u32x4s_t rsy = make_rsrc(p.dY, (uint32_t)p.y_bytes), rsx = make_rsrc(p.X, (uint32_t)p.x_bytes),
                  rss = make_rsrc(MODE == BX_LN ? (const void*)p.stats : (const void*)p.X, MODE == BX_LN ? (uint32_t)(p.M * 8) : 0u);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  auto dma = [&](const u32x4s_t& rs, uint32_t ldst, int off) {   // inline asm: see conv3_mfma.hip
+  auto dma = [&](const u32x4s_t& rs0, uint32_t ldst, int off) {   // inline asm: see conv3_mfma.hip
     uint32_t keep;
+    u32x4s_t rs;   // (scalar again at the point of use: under SGPR pressure the descriptor otherwise arrives in vector registers)
+    rs.x = __builtin_amdgcn_readfirstlane(rs0.x); rs.y = __builtin_amdgcn_readfirstlane(rs0.y);
+    rs.z = __builtin_amdgcn_readfirstlane(rs0.z); rs.w = __builtin_amdgcn_readfirstlane(rs0.w);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(off), "s"(ldst), "s"(rs) : "memory");
   };
