@@ -743,22 +743,32 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         ms = _replay_calls(lib, sub, reps)
         bts = _alg(sub[0][0], sub[0][1], elt)[0]
         per_c[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
-    # inside the step: the forward pass as a HIP graph with its 48 K1 launches and with those launches left out
-    # (Recorder.skip: the library call is not made, its output buffer keeps the previous replay's values)
+    # inside the step: the forward pass as a HIP graph with these launches and with them left out.  Both graphs are captured
+    # into ONE memory pool: the allocation sequence is the same, so they use the same buffers, and a left-out launch's outputs keep what the
+    # full graph's replay wrote there last (finite, valid data for everything downstream: LayerNorm / GELU never see uninitialised
+    # memory).  The output pointers of the two captures are compared; if they differ the figure is not reported.
     in_step = None
     try:
-        def fwd_graph(skip):
+        def fwd_graph(skip, pool=None):
             with torch.no_grad():
                 net(x)
                 torch.cuda.synchronize()
                 gph = torch.cuda.CUDAGraph()
                 with Recorder(lib) as r2:
                     r2.skip = skip
-                    with torch.cuda.graph(gph):
+                    with torch.cuda.graph(gph, pool=pool):
                         net(x)
-            return gph
-        g_full, g_skip = fwd_graph(None), fwd_graph(fa)
-        diffs = sorted(_timed_replay(g_full, 15) - _timed_replay(g_skip, 15) for _ in range(4))   # interleaved
+            ptrs = [tuple(v for v in a if isinstance(v, int) and v > (1 << 32)) for n, a in r2.calls if _op_key(n) == fa]
+            return gph, ptrs
+        g_full, p_full = fwd_graph(None)
+        g_skip, p_skip = fwd_graph(fa, g_full.pool())
+        if p_full != p_skip:
+            raise RuntimeError("the two captures did not get the same buffers")
+        diffs = []
+        for _ in range(4):   # interleaved; every replay of the graph without the launches follows one with them
+            t_full = _timed_replay(g_full, 15)
+            diffs.append(t_full - _timed_replay(g_skip, 15))
+        diffs.sort()
         in_step = 0.5 * (diffs[1] + diffs[2]) / len(k1)
         del g_full, g_skip
     except Exception as e:  # noqa: BLE001 - measurement aid only
@@ -791,7 +801,7 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
                               "launch; algorithmic bytes 6 C elt + 8 per token: x in; qkv, attention output, x1, statistics out)")
                              if fused else "rdst_wattn_fwd (K1, window attention forward)"), None
     ach = k1_bytes / (k1_ms * 1e-3) / 1e9
-    out["roofline"] = {"kernel": kname, "bound": "hbm",
+    out["roofline"] = {"kernel": kname, "id": "K8" if fused else ("K1-ws16" if ws16 else "K1"), "bound": "hbm",
                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                        "launches": len(k1), "avg_launch_us": round(1e3 * k1_ms, 2),

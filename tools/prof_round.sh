@@ -11,7 +11,8 @@ python3 bench.py --config ws16 > $O/ws16_bench.json 2>> $O/bench.err
 bash tools/prof_cfg.sh $T/e1 > /dev/null 2>&1
 bash tools/prof_cfg.sh $T/hrl --config e1_hrl > /dev/null 2>&1
 bash tools/prof_cfg.sh $T/ws16 --config ws16 > /dev/null 2>&1
-python3 -m pytest tests/test_fullsize_gpu.py tests/test_segunet_gpu.py tests/test_config5_gpu.py tests/test_modules_gpu.py tests/test_grad_accum_gpu.py -m gpu -q -s > $O/parity.log 2>&1
+bash tools/prof_cfg.sh $T/x3 --dtype fp32x3 > /dev/null 2>&1    # (round 6: the parity mode's own kernel family)
+python3 -m pytest tests/test_fullsize_gpu.py tests/test_segunet_gpu.py tests/test_config5_gpu.py tests/test_modules_gpu.py tests/test_grad_accum_gpu.py tests/test_fp32x3_gpu.py -m gpu -q -s > $O/parity.log 2>&1
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-line > $O/bench_traced.json 2> $O/trace.err
 cd $R
 f=$(find $O/trace -name '*kernel_trace.csv' | head -1)
