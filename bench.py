@@ -743,32 +743,42 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
         ms = _replay_calls(lib, sub, reps)
         bts = _alg(sub[0][0], sub[0][1], elt)[0]
         per_c[f"C{C}"] = {"avg_launch_us": round(1e3 * ms, 2), "frac": round(bts / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
-    # inside the step: the forward pass as a HIP graph with these launches and with them left out.  Both graphs are captured
-    # into ONE memory pool: the allocation sequence is the same, so they use the same buffers, and a left-out launch's outputs keep what the
-    # full graph's replay wrote there last (finite, valid data for everything downstream: LayerNorm / GELU never see uninitialised
-    # memory).  The output pointers of the two captures are compared; if they differ the figure is not reported.
+    # inside the step: the forward pass as a HIP graph with these launches and with them left out.  The outputs of a left-out launch
+    # (buffers of the graph's own pool, never written by anybody else first) are zero-filled ONCE after the capture, so everything
+    # downstream — LayerNorm, GELU, the next blocks — runs on finite data in every replay (an uninitialised buffer could hold NaNs).
     in_step = None
     try:
-        def fwd_graph(skip, pool=None):
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemset2D.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t]
+
+        def outputs(n, a):   # (pointer, pitch, row bytes, rows) of everything the call writes (rows of a wider buffer: only the call's columns)
+            if n == "rdst_swin_attn_fwd":
+                M, C = a[18] * a[19] * a[20], a[21]
+                return [(a[9], a[10] * elt, 3 * C * elt, M), (a[11], a[12] * elt, C * elt, M), (a[13], a[14] * elt, C * elt, M), (a[15], 8, 8, M)]
+            M, C = a[7] * a[8] * a[9], a[10]
+            return [(a[5], a[6] * elt, C * elt, M)]
+
+        def fwd_graph(skip):
             with torch.no_grad():
                 net(x)
                 torch.cuda.synchronize()
                 gph = torch.cuda.CUDAGraph()
                 with Recorder(lib) as r2:
                     r2.skip = skip
-                    with torch.cuda.graph(gph, pool=pool):
+                    with torch.cuda.graph(gph):
                         net(x)
-            ptrs = [tuple(v for v in a if isinstance(v, int) and v > (1 << 32)) for n, a in r2.calls if _op_key(n) == fa]
-            return gph, ptrs
-        g_full, p_full = fwd_graph(None)
-        g_skip, p_skip = fwd_graph(fa, g_full.pool())
-        if p_full != p_skip:
-            raise RuntimeError("the two captures did not get the same buffers")
-        diffs = []
-        for _ in range(4):   # interleaved; every replay of the graph without the launches follows one with them
-            t_full = _timed_replay(g_full, 15)
-            diffs.append(t_full - _timed_replay(g_skip, 15))
-        diffs.sort()
+            if skip is not None:
+                torch.cuda.synchronize()
+                for n, a in r2.calls:
+                    if _op_key(n) == skip:
+                        for ptr, pitch, wb, rows in outputs(n, a):
+                            if ptr and hip.hipMemset2D(ptr, pitch, 0, wb, rows) != 0:
+                                raise RuntimeError("hipMemset2D failed")
+                torch.cuda.synchronize()
+            return gph
+        g_full, g_skip = fwd_graph(None), fwd_graph(fa)
+        diffs = sorted(_timed_replay(g_full, 15) - _timed_replay(g_skip, 15) for _ in range(4))   # interleaved
         in_step = 0.5 * (diffs[1] + diffs[2]) / len(k1)
         del g_full, g_skip
     except Exception as e:  # noqa: BLE001 - measurement aid only
@@ -807,7 +817,7 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
                        "launches": len(k1), "avg_launch_us": round(1e3 * k1_ms, 2),
                        "how": "COLD: the step's launches of this kernel (every width, shifted and not) replayed back to back on "
                               "the step's own buffers, HIP events on the launch stream; in_step = (forward graph with them) - "
-                              "(forward graph without) / launches",
+                              "(forward graph without: their outputs zero-filled once after the capture) / launches",
                        "per_shape": per_c, "algorithmic_bytes_per_launch_avg": int(k1_bytes)}
     if bound_note:
         out["roofline"]["note"] = bound_note

@@ -15,8 +15,16 @@
  *   - `dtype` selects the activation element type: RDST_F32 (parity mode, fp32 I/O and math),
  *     RDST_BF16 (throughput mode: bf16 I/O, fp32 accumulation) or RDST_F32X3 (fast parity mode: fp32
  *     I/O exactly as RDST_F32, but every GEMM-shaped product takes its operands as TWO bf16 terms —
- *     16 mantissa bits — on the bf16 matrix cores with fp32 accumulation; LayerNorm, softmax, GELU and
- *     every sum stay fp32; entry points without GEMMs treat it as RDST_F32).  Parameters and parameter
+ *     16 mantissa bits — on the bf16 matrix cores with fp32 accumulation; LayerNorm statistics, the
+ *     softmax sums and every reduction stay fp32; entry points without GEMMs treat it as RDST_F32).
+ *     What RDST_F32X3 changes BESIDES the operand split (so its error model is not "2^-17 per operand"
+ *     alone): GELU and GELU' are evaluated as gelu_fast / gelu_grad_fast (erf by Abramowitz-Stegun
+ *     7.1.26 on the hardware exp2 / rcp, |error| <= 1.5e-7 absolute) instead of erff; the softmax of
+ *     rdst_wattn_* runs in the log2 domain on v_exp_f32 (logits pre-multiplied by log2 e) instead of
+ *     expf.  What it does NOT cover and silently runs in exact fp32 (same results as RDST_F32):
+ *     rdst_wattn_* with 16x16 windows or an explicit mask, rdst_mlp_fwd / rdst_mlp_bwd (a fused Mlp
+ *     call in RDST_F32X3 is refused with RDST_ENOTSUP: the host runs fc1 / fc2 as two rdst_ln_linear_*
+ *     calls), LayerNorm-only rows, the one-channel convolutions, rdst_adam.  Parameters and parameter
  *     gradients are ALWAYS fp32;
  *   - return value: 0 on success, a negative hipError_t from the launch, or RDST_EINVAL /
  *     RDST_ENOTSUP for bad or unsupported arguments.  Never throws.  rdst_last_error() returns a
@@ -34,9 +42,10 @@ extern "C" {
 
 #define RDST_F32 0
 #define RDST_BF16 1
-#define RDST_F32X3 2   /* fp32 rows, split-bf16 products (~4e-6 relative per product): the network entry points (rdst_ln_linear_*,
-                          rdst_wattn_* with 8x8 windows, rdst_conv_*) run all four partial products of (a_hi + a_lo)(b_hi + b_lo) in two
-                          v_mfma_f32_32x32x16_bf16; rdst_u_conv runs three (hi.hi + hi.lo + lo.hi, ~1e-5); everything else = RDST_F32 */
+#define RDST_F32X3 2   /* fp32 rows, split-bf16 products (~4e-6 .. 1e-5 relative per product).  The E1 shapes of rdst_ln_linear_* and
+                          rdst_conv_* (ABI 11: lin3x / lnlin3x / conv3x kernels) and rdst_u_conv run three partial products
+                          (hi.hi + hi.lo + lo.hi; the dropped lo.lo is <= 2^-18 relative); rdst_wattn_* with 8x8 windows and the other
+                          shapes run all four in two v_mfma_f32_32x32x16_bf16; everything else = RDST_F32 (see the conventions above) */
 
 #define RDST_EINVAL (-10001)
 #define RDST_ENOTSUP (-10002)

@@ -272,15 +272,30 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
                 }
                 __builtin_memcpy(&v, w, GRAN);
               }
+              if constexpr (SP && GRAN == 16) {   // a 16-byte chunk IS a pack of 4 channels: split on the way in (no second pass over the LDS)
+                float f[4];
+                __builtin_memcpy(f, &v, 16);
+                const Pack16 pk = MM::pack_op(f);
+                __builtin_memcpy(&v, &pk, 16);
+              }
               *reinterpret_cast<CH*>(smw + sec * (secsz - secb) + row * ldt + off) = v;
             }
           }
-          if (lane < cps) *reinterpret_cast<CH*>(Os + row * ldt + lane * GRAN) = rego[i];
+          if (lane < cps) {
+            CH v = rego[i];
+            if constexpr (SP && GRAN == 16) {
+              float f[4];
+              __builtin_memcpy(f, &v, 16);
+              const Pack16 pk = MM::pack_op(f);
+              __builtin_memcpy(&v, &pk, 16);
+            }
+            *reinterpret_cast<CH*>(Os + row * ldt + lane * GRAN) = v;
+          }
         }
       }
     }
     __syncthreads();
-    if constexpr (SP) {
+    if constexpr (SP && GRAN != 16) {   // (C = 90: 8-byte chunks, packs straddle them)
       const int ppr = (C + 3) / 4;   // packs per row; the channels past C inside the last one are zeroed (they held lo halves)
       for (int i = tid; i < 4 * 64 * ppr; i += NTHREADS) {
         const int row = i / ppr, pk = i - row * ppr;

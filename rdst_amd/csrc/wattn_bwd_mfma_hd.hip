@@ -141,6 +141,21 @@ __device__ __forceinline__ void bw_phase_a(const BwCtx& c, Pack16 (&pP)[2][2], P
     for (int kt = 0; kt < 2; ++kt)
       Mma<bf16>::mma(X[kt], onehot(2 * ((c.mrow && kt * 4 + (c.yi & 3) >= c.thr) ? 1 : 0) + rx, 0x3f80u), mQ);
   }
+#if defined(K2_ABL) && (K2_ABL & 16)
+  // ablation (r05 verdict item 2a, upper bound): what phase A would cost with the forward's log-sum-exp and delta = rowsum(dO o O) handed
+  // in per (token, head) — no row maximum, no row sum, no normalisation, no delta reduction (numerically meaningless: timing only)
+  {
+    const float nl = -c.scale2 * X[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(X[kt][v], c.scale2, nl));
+        Y[kt][v] = pv * (Y[kt][v] - 0.125f);
+        X[kt][v] = pv;
+      }
+  }
+#else
   float m = X[0][0];
 #pragma unroll
   for (int v = 1; v < 16; ++v) m = __builtin_fmaxf(m, X[0][v]);
@@ -176,6 +191,7 @@ __device__ __forceinline__ void bw_phase_a(const BwCtx& c, Pack16 (&pP)[2][2], P
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int v = 0; v < 16; ++v) Y[kt][v] = X[kt][v] * (Y[kt][v] - delta);   // dS (gradient of the logits)
+#endif
   // element jj of lane half h of pack (kt, s) is key kt*32 + 16s + 8(jj>>2) + 4h + (jj&3)
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)

@@ -164,13 +164,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? (sizeof(T) == 2 ? 3 : 2) : 
               }
               __builtin_memcpy(&v, w, GRAN);
             }
+            if constexpr (SP && GRAN == 16) {   // K / V: a 16-byte chunk is a pack of 4 channels, split on the way in
+              if (sec != 0) {
+                float f[4];
+                __builtin_memcpy(f, &v, 16);
+                const Pack16 pk = MM::pack_op(f);
+                __builtin_memcpy(&v, &pk, 16);
+              }
+            }
             *reinterpret_cast<CH*>(smem + sec * (64 * ldt - secb) + row * ldt + off) = v;
           }
         }
       }
     }
     __syncthreads();
-    if constexpr (SP) {
+    if constexpr (SP && GRAN != 16) {
       const int ppr = (C + 3) / 4;   // packs per row; the channels past C inside the last one are zeroed (they held lo halves)
       for (int i = tid; i < 2 * 64 * ppr; i += NT) {
         const int row = i / ppr, pk = i - row * ppr;

@@ -39,8 +39,10 @@ def _e1_step(mode, B=4, seed=11):
 def test_e1_fp32x3_bench_shape_psnr_equal_to_4_decimals():
     """RDST-E1 x4 on 1x64x64 LR patches (B = 4 of BASELINE configs[1]'s 32: the oracle is a CPU pass), forward + L1 + backward in the
     fp32x3 mode against the oracle: |dPSNR| < 5e-5 dB (border 4 as trans_sr_tester.py:155 passes it; measured 3e-6), loss to 2e-6,
-    every gradient to 4e-3 relative L2 (measured worst 1.6e-3: the first block's relative-position table, a 225 x 6 tensor whose
-    gradient is a difference of large sums; the exact mode has 1e-3 there) and the total gradient to 2e-4 (measured 9e-5)."""
+    every gradient to SURVEY 8(d)'s 1e-3 relative L2 — with ONE named exception: the relative-position bias tables
+    (`...attn.relative_position_bias_table`, 225 x 6: each entry is the sum of dS over up to 64 (query, key) pairs of every window, a
+    difference of large terms of both signs) are gated at 2.5e-3 (measured 1.2e-3 .. 1.6e-3 on the first blocks; the exact mode's
+    worst gradient is 1.1e-5) — and the total gradient to 2e-4 (measured 6e-5 .. 9e-5)."""
     cfg, sd, net, x, tgt, yc, loss = _e1_step("fp32x3")
     assert net.compute_code == ops.F32X3 and not ops.F32_SPLIT      # the mode is the module's, the process default untouched
     params = dict(net.named_parameters())
@@ -52,15 +54,19 @@ def test_e1_fp32x3_bench_shape_psnr_equal_to_4_decimals():
     rels = [((p.grad.cpu() - osd[k].grad).norm().item() / max(osd[k].grad.norm().item(), 1e-12), k)
             for k, p in params.items() if p.requires_grad]
     worst = max(rels)
+    is_table = lambda k: k.endswith("relative_position_bias_table")
+    worst_tab = max(r for r in rels if is_table(r[1]))
+    worst_rest = max(r for r in rels if not is_table(r[1]))
     num = sum((p.grad.cpu() - osd[k].grad).double().pow(2).sum().item() for k, p in params.items() if p.requires_grad)
     den = sum(osd[k].grad.double().pow(2).sum().item() for k, p in params.items() if p.requires_grad)
     total = (num / den) ** 0.5
     print(f"\nE1 fp32x3 B=4 64x64: PSNR {p_hip:.6f} vs {p_ref:.6f} dB (|d| {abs(p_hip - p_ref):.2e})  out max|d| "
           f"{(yc - oy.detach()).abs().max().item():.2e}  loss {loss:.7f} vs {oloss.item():.7f}  worst gradient {worst[0]:.2e} "
-          f"({worst[1]})  total gradient {total:.2e}")
+          f"({worst[1]})  worst that is not a bias table {worst_rest[0]:.2e} ({worst_rest[1]})  total gradient {total:.2e}")
     assert abs(p_hip - p_ref) < 5e-5
     assert abs(loss - oloss.item()) <= 2e-6
-    assert worst[0] <= 4e-3, worst
+    assert worst_rest[0] <= 1e-3, worst_rest
+    assert worst_tab[0] <= 2.5e-3, worst_tab
     assert total <= 2e-4
 
 
