@@ -151,9 +151,9 @@ int rdst_ln_linear_bwd(const void* X, int64_t ld_x, const float* ln_w, const flo
 /* The same with a SECOND addend of dX, dX = dX_add + dX_add2 + f'(...): the gradient slice a dense concatenation
  * hands back for its prefix (rdst_variations.py:339-340, `torch.cat((x, new), 2)`: x feeds both the DenseSTLayer's
  * body and the concatenation, so autograd would sum the body's dX and a strided slice of the concatenation's gradient
- * in a separate add kernel).  dX_add2 NULL = rdst_ln_linear_bwd.  Taken only by the one-pass bf16 kernel of the E1
- * shapes (LayerNorm + Linear, every gradient requested); RDST_ENOTSUP otherwise, with nothing launched - the caller
- * then adds the slice itself. */
+ * in a separate add kernel).  dX_add2 NULL = rdst_ln_linear_bwd.  Taken only by the one-pass kernels of the E1 shapes
+ * (RDST_BF16: lnlin3_mfma.hip; RDST_F32X3: lnlin3x_mfma.hip; every gradient requested); RDST_ENOTSUP otherwise, with
+ * nothing launched - the caller then adds the slice itself. */
 int rdst_ln_linear_bwd2(const void* X, int64_t ld_x, const float* ln_w, const float* ln_b,
                         const float* stats, int in_act, const float* Wt, const void* dY,
                         int64_t ld_dy, void* dX, int64_t ld_dx, const void* dX_add, int64_t ld_dx_add,

@@ -176,6 +176,9 @@ def test_ln_linear_fp32x3_vs_torch(K, N, ln, act, res):
     (1, 32, 32, 60, 1, 3, 0, 0, 1),       # the 60 -> 1 tail: dY rows shorter than a pack (single elements into the hi / lo planes)
     (1, 128, 128, 60, 1, 3, 0, 0, 1),     # ... with 128-pixel stripes
     (2, 16, 16, 90, 30, 1, 0, 0, 1),      # 1x1
+    (3, 64, 64, 150, 60, 3, 0, 1, 1),     # conv3x at the E1 image size, several images (the DMA row ring wraps across images)
+    (1, 128, 128, 60, 240, 3, 0, 0, 2),   # the second upsampler stage: 128 x 128 -> 256 x 256 (four sub-pixel data-gradient launches)
+    (2, 64, 64, 1, 60, 3, 0, 0, 1),       # the head conv 1 -> 60 (conv_c1x.hip)
 ])
 def test_conv_fp32x3_vs_torch(B, H, W, Cin, Cout, k, act, res, r):
     """k x k convolution (+ LeakyReLU in front, residual, PixelShuffle) forward and every gradient with split-bf16 operands against
@@ -298,3 +301,101 @@ def test_two_networks_in_different_modes_interleave_bit_for_bit():
     # and the two modes' gradients are NOT each other's (a mode leak would make them equal)
     assert any(not torch.equal(g3_ref[k], g1_ref[k]) for k in g3_ref)
     assert not ops.F32_SPLIT
+
+
+@pytest.mark.parametrize("K,N,ln,act,nadd", [(120, 360, 1, 0, 2),   # norm1 + qkv at C = 120: two launches over halves of N, the second onto the first's dX
+                                             (90, 270, 1, 0, 2), (60, 120, 1, 0, 1), (120, 30, 1, 0, 0),
+                                             (120, 120, 0, 0, 1), (90, 90, 0, 0, 0), (240, 120, 0, 1, 0), (180, 90, 0, 1, 0)])
+def test_lnlin3x_many_tiles_strided_operands_two_addends_vs_float64(K, N, ln, act, nadd):
+    """The one-pass Linear backward of the fp32x3 family (lnlin3x_mfma.hip) straight through the C ABI at a size where every
+    workgroup walks several 32-token tiles (M = 40003: 1251 tiles, the last one with 3 rows — double-buffered DMA, the LayerNorm
+    rows finished one tile late), with every operand a column slice of a wider buffer (the dense buffer of an RDSTB addresses its
+    tensors that way: rdst_variations.py:339-340) and both addends of dX (rdst_ln_linear_bwd2): dX, dW, dbias, d(gamma), d(beta)
+    against the formulas of nn.LayerNorm / nn.GELU / nn.Linear in float64 on the CPU: relative L2 <= 3e-5."""
+    from rdst_amd import _lib
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    M = 40003
+    ldx, lddy, lddx, lda = K + 8, N + 4, K + 12, K + 16
+    xw, dyw = _rand((M, ldx), 1), _rand((M, lddy), 2)
+    x, dy = xw[:, 4:4 + K], dyw[:, 4:4 + N]
+    w = _rand((N, K), 3, K ** -0.5)
+    lw = (1 + _rand((K,), 4, 0.1)) if ln else None
+    lb = _rand((K,), 5, 0.1) if ln else None
+    a1w = _rand((M, lda), 6) if nadd >= 1 else None
+    a2 = _rand((M, K), 7) if nadd >= 2 else None
+    # float64 reference
+    x64 = x.double().clone().requires_grad_(True)
+    p64 = [t.double().clone().requires_grad_(True) if t is not None else None for t in (w, lw, lb)]
+    b64 = torch.zeros(N, dtype=torch.float64, requires_grad=True)
+    h = F.layer_norm(x64, (K,), p64[1], p64[2], 1e-5) if ln else x64
+    h = F.gelu(h) if act == 1 else h
+    F.linear(h, p64[0], b64).backward(dy.double())
+    want = [x64.grad + (a1w[:, 8:8 + K].double() if nadd >= 1 else 0) + (a2.double() if nadd >= 2 else 0), p64[0].grad, b64.grad]
+    if ln:
+        want += [p64[1].grad, p64[2].grad]
+    # the HIP call
+    g = lambda t: t.to(dev) if t is not None else None
+    xg, dyg, wg, lwg, lbg, a1g, a2g = g(xw), g(dyw), g(w), g(lw), g(lb), g(a1w), g(a2)
+    dxg = torch.full((M, lddx), 7.0, device=dev)
+    stats = None
+    if ln:
+        xs = xg[:, 4:4 + K]
+        stats = torch.stack([xs.mean(1), torch.rsqrt(xs.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    dw, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    dlw, dlb = (torch.empty(K, device=dev), torch.empty(K, device=dev)) if ln else (None, None)
+    nws = lib.rdst_ln_linear_bwd_workspace(M, K, N)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    P = lambda t, off=0: (t.data_ptr() + 4 * off) if t is not None else None
+    rc = lib.rdst_ln_linear_bwd2(P(xg, 4), ldx, P(lwg), P(lbg), P(stats), act, wg.data_ptr(), P(dyg, 4), lddy, P(dxg, 4), lddx,
+                                 P(a1g, 8), lda, dw.data_ptr(), db.data_ptr(), P(dlw), P(dlb), ws.data_ptr(), nws, M, K, N, 1.0,
+                                 _lib.F32X3, torch.cuda.current_stream().cuda_stream, P(a2g), K)
+    assert rc == 0, (rc, lib.rdst_last_error())
+    torch.cuda.synchronize()
+    got = [dxg[:, 4:4 + K].cpu().double(), dw.cpu().double(), db.cpu().double()] + ([dlw.cpu().double(), dlb.cpu().double()] if ln else [])
+    rels = [(a - b).norm().item() / max(b.norm().item(), 1e-12) for a, b in zip(got, want)]
+    print(f"\nlnlin3x K={K} N={N} M={M} strided, {nadd} addend(s): rel L2 (dx, dW, db[, dgamma, dbeta]) " + " ".join(f"{v:.1e}" for v in rels))
+    assert max(rels) <= 3e-5, rels
+    assert rels[0] > 0
+    # the columns of the wider dX buffer beside the slice are untouched
+    assert torch.all(dxg[:, :4] == 7.0) and torch.all(dxg[:, 4 + K:] == 7.0)
+
+
+@pytest.mark.parametrize("K,N,ln,act,res", [(120, 360, 1, 0, 0), (90, 270, 1, 0, 0), (60, 60, 0, 0, 1), (120, 120, 0, 0, 1),
+                                            (90, 30, 1, 0, 0), (120, 240, 1, 0, 0), (240, 120, 0, 1, 1), (120, 60, 0, 1, 1)])
+def test_lin3x_many_tiles_strided_operands_vs_float64(K, N, ln, act, res):
+    """The forward of the fp32x3 family (lin3x_mfma.hip) through the C ABI, several tiles per workgroup (M = 70003), x / residual / y
+    as column slices of wider buffers, the weight image self-packed by the call: y and the LayerNorm statistics against float64."""
+    from rdst_amd import _lib
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    M = 70003
+    ldx, ldr, ldy = K + 8, N + 12, N + 4
+    xw, rw = _rand((M, ldx), 1), (_rand((M, ldr), 2) if res else None)
+    x = xw[:, 4:4 + K]
+    w, b = _rand((N, K), 3, K ** -0.5), _rand((N,), 4, 0.1)
+    lw = (1 + _rand((K,), 5, 0.1)) if ln else None
+    lb = _rand((K,), 6, 0.1) if ln else None
+    h = F.layer_norm(x.double(), (K,), lw.double(), lb.double(), 1e-5) if ln else x.double()
+    h = F.gelu(h) if act == 1 else h
+    want = F.linear(h, w.double(), b.double()) + (rw[:, 8:8 + N].double() if res else 0)
+    g = lambda t: t.to(dev) if t is not None else None
+    xg, rg, wg, bg, lwg, lbg = g(xw), g(rw), g(w), g(b), g(lw), g(lb)
+    yg = torch.full((M, ldy), 7.0, device=dev)
+    stats = torch.empty(M, 2, device=dev) if ln else None
+    nws = lib.rdst_ln_linear_fwd_workspace2(K, N, _lib.F32X3)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+    P = lambda t, off=0: (t.data_ptr() + 4 * off) if t is not None else None
+    rc = lib.rdst_ln_linear_fwd(P(xg, 4), ldx, P(lwg), P(lbg), act, wg.data_ptr(), bg.data_ptr(), P(rg, 8), ldr, P(yg, 4), ldy, P(stats),
+                                ws.data_ptr(), nws, M, K, N, 1.0, _lib.F32X3, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, (rc, lib.rdst_last_error())
+    torch.cuda.synchronize()
+    got = yg[:, 4:4 + N].cpu().double()
+    rel = (got - want).norm().item() / want.norm().item()
+    print(f"\nlin3x K={K} N={N} M={M} strided: y rel L2 {rel:.1e}")
+    assert 0 < rel <= 3e-5
+    assert torch.all(yg[:, :4] == 7.0) and torch.all(yg[:, 4 + N:] == 7.0)
+    if ln:
+        xs = x.double()
+        ref = torch.stack([xs.mean(1), torch.rsqrt(xs.var(1, unbiased=False) + 1e-5)], 1)
+        assert (stats.cpu().double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
