@@ -47,10 +47,17 @@ KERNELS = {
     "wattn16_bwd_kernel": ("wattn16_bwd_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "wattn16_bwd3_kernel": ("wattn16_bwd3_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
     "wattn16_bwd1_kernel": ("wattn16_bwd1_kernel", ["wattn16_mfma.hip", "wattn_hd.h"]),
+    "lin3x_kernel": ("lin3x_kernel", ["lin3x_mfma.hip"]),
+    "lnlin3x_bwd_kernel": ("lnlin3x_bwd_kernel", ["lnlin3x_mfma.hip"]),
+    "conv3x_kernel": ("conv3x_kernel", ["conv3x_mfma.hip"]),
+    "conv3x_wgrad_kernel": ("conv3x_wgrad_kernel", ["conv3x_wgrad.hip"]),
+    "wattn_fwd_mfma_kernel": ("wattn_fwd_mfma_kernel", ["wattn_mfma.hip"]),
+    "wattn_bwd_mfma_kernel": ("wattn_bwd_mfma_kernel", ["wattn_bwd_mfma.hip"]),
+    "batched_sum_kernel": ("batched_sum_kernel", ["reduce_batch.hip"]),
     "uconv_halo_kernel": ("uconv_halo_kernel", ["uconv_mfma.hip"]),
     "uconv_kernel": ("uconv_kernel", ["uconv_mfma.hip"]),
 }
-CONFIG = sys.argv[2] if len(sys.argv) > 2 else "e1"   # bench.py --config (ws16: the window-16 kernels)
+CONFIG = sys.argv[2] if len(sys.argv) > 2 else "e1"   # bench.py --config (ws16: the window-16 kernels); "x3": e1 in --dtype fp32x3
 
 
 def source_hash(files):
@@ -66,7 +73,7 @@ def run_pass(counters, outdir):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", outdir, "-o", "p", "--",
            "python3", os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--graph", "0", "--no-roofline",
-           "--no-cpu-baseline", "--config", CONFIG]
+           "--no-cpu-baseline", *(["--config", "e1", "--dtype", "fp32x3"] if CONFIG == "x3" else ["--config", CONFIG])]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=1500)
     if r.returncode != 0:
         print(r.stderr[-2000:], file=sys.stderr)
@@ -87,7 +94,7 @@ def main():
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
                 for sub, (key, _) in KERNELS.items():
-                    if sub in name and (sub != "conv3_kernel" or "wgrad" not in name):
+                    if sub in name and (sub not in ("conv3_kernel", "conv3x_kernel") or "wgrad" not in name):
                         short = re.sub(r"\(anonymous namespace\)::|void ", "", name).split("(")[0]
                         agg.setdefault(key, {}).setdefault(short, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     out = {"command": "rocprofv3 --kernel-trace --pmc <one set per run> -- python3 bench.py --steps 1 --warmup 0 --graph 0 "
