@@ -18,10 +18,26 @@
 #include "wattn_hd.h"
 #include <stdlib.h>
 
+#ifndef LB3_LOADW_SHAPE
+#define LB3_LOADW_SHAPE(K, N) (((K) == 60 && (N) == 180) || ((K) == 90 && (N) == 270) || ((K) == 120 && (N) == 120))   // which shapes let the
+// weight-gradient waves do all the staging (see LB3::LOADW).  A/B on one box, cold, us per call: norm1 + qkv 40.7 -> 37.1 (C = 60), 53.5 -> 51.8 (90),
+// proj 38.0 -> 33.5 (C = 120); the other shapes are equal or slower (the dense tails' single weight-gradient wave spills: 41 -> 154 us)
+#endif
 #ifndef LB3_ABL
 #define LB3_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no weight-gradient MFMAs, 2 no data-gradient MFMAs (the wide chain), 4 no W gather, 8 no slab dump, 16 no LDS zeroing.
                     // Round 4: with BOTH removed the K = 120, N = 360 launch goes from 53.7 to 50.9 us: the kernel is bound by its
                     // load -> stash -> barrier skeleton (one tile of loads in flight per workgroup), not by its arithmetic
+#endif
+
+// -DLB3_STAMPS: workgroup 0 prints, per wave, the clock64() ticks it spent in each phase of the tile loop (tools/abl_build.sh)
+#ifdef LB3_STAMPS
+#define LB3_T0 long long tk_[5] = {0, 0, 0, 0, 0}, tl_ = clock64();
+#define LB3_T(i) { const long long n_ = clock64(); tk_[i] += n_ - tl_; tl_ = n_; }
+#define LB3_TP(role) if (blockIdx.x == 0 && lane == 0) printf("wave %d %s: stash %lld  fetch %lld  barrier %lld  compute %lld  finish %lld\n", wave, role, tk_[0], tk_[1], tk_[2], tk_[3], tk_[4]);
+#else
+#define LB3_T0
+#define LB3_T(i)
+#define LB3_TP(role)
 #endif
 
 namespace {
@@ -56,11 +72,16 @@ struct LB3 {
   static constexpr int NY = 32 * PKY, NX = 32 * PKX;
   // loader: WIDE shapes split the kinds between the roles (weight-gradient waves stage dY and x, data-gradient waves
   // dX_add: the registers of either role are full); the narrow shapes let every thread take its share of every kind
-  static constexpr int NTW = WIDE ? 64 * NWG : NT, NTD = WIDE ? 64 * NDG : NT;
+  // LOADW (round 6, after the per-wave phase stamps of this kernel and of lnlin3x_mfma.hip: the data-gradient waves are the workgroup's
+  // critical path — staging, products, LayerNorm finish — while the weight-gradient waves wait at the barrier half of the time): the
+  // weight-gradient waves stage EVERYTHING, the data-gradient waves nothing
+  static constexpr bool LOADW = LB3_LOADW_SHAPE(K_, N_);
+  static constexpr bool SPLITR = WIDE || LOADW;   // the roles load with separate thread sets
+  static constexpr int NTW = SPLITR ? 64 * NWG : NT, NTD = SPLITR ? 64 * NDG : NT;
   static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
   static constexpr bool ACC_BY_W = K == 120 && N == 360;   // 92 registers of W fragments: these data-gradient waves stage nothing
-  static constexpr int W_SY = cdiv(NY, NTW), W_SX = cdiv(NX, NTW), W_SA = (WIDE && !ACC_BY_W) ? 0 : cdiv(NX, NTW);
-  static constexpr int D_SY = WIDE ? 0 : W_SY, D_SX = WIDE ? 0 : W_SX, D_SA = ACC_BY_W ? 0 : cdiv(NX, NTD);
+  static constexpr int W_SY = cdiv(NY, NTW), W_SX = cdiv(NX, NTW), W_SA = (WIDE && !ACC_BY_W && !LOADW) ? 0 : cdiv(NX, NTW);
+  static constexpr int D_SY = SPLITR ? 0 : W_SY, D_SX = SPLITR ? 0 : W_SX, D_SA = (ACC_BY_W || LOADW) ? 0 : cdiv(NX, NTD);
   static constexpr int CP = 32 * NCT;
   // (strides of 64 / 192 (mod 256) bytes — the four rows of a transposed read on disjoint bank quarters — were measured:
   // qkv / proj unchanged within noise, the tails 1-3 us slower (the 8-byte slice reads of the epilogue collide): not the limit)
@@ -206,11 +227,15 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
 #pragma unroll
         for (int v = 0; v < 16; ++v) G[i][j][v] = 0.f;
     int b = 0;
+    LB3_T0
     for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
       char* buf = smem + b * CF::BUF;
       ld.stash(p, tile, buf);
+      LB3_T(0)
       ld.fetch(p, tile + 1 < t1 ? tile + 1 : tile);   // every iteration defines the whole prefetch set
+      LB3_T(1)
       __syncthreads();   // the one barrier of the tile: buffer b staged; everybody is done with buffer b^1 and red[b]
+      LB3_T(2)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         Pack16 ya[TN], xb[TC];
@@ -235,7 +260,9 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
 #endif
           }
       }
+      LB3_T(3)
     }
+    LB3_TP("wgrad")
     if (LN) __syncthreads();
     // bf16 slab in groups of 4 rows (reduce_batch.h, "G4"): G [N][K+1]; p.slab_stride counts 8-byte groups
     uint2* my = reinterpret_cast<uint2*>(p.slab) + (int64_t)blockIdx.x * p.slab_stride;
@@ -257,7 +284,7 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
 
   // ---- data-gradient wave: (W gamma)^T fragments, lane (r, hh) of k-step ks holds W[16 ks + 8 hh + e][32 dct + r] gamma
   LB3Loader<CF, LN, CF::D_SY, CF::D_SX, CF::D_SA> ld;
-  ld.setup(CF::WIDE ? tid - 64 * NWG : tid, CF::NTD, has_acc);
+  ld.setup(CF::SPLITR ? tid - 64 * NWG : tid, CF::NTD, has_acc);
   if (t0 < t1) ld.fetch(p, t0);
   Pack16 wf[KN];
   {
@@ -331,12 +358,17 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
     }
   };
   int b = 0;
+  LB3_T0
   for (int64_t tile = t0; tile < t1; ++tile, b ^= 1) {
     char* buf = smem + b * CF::BUF;
     ld.stash(p, tile, buf);
+    LB3_T(0)
     ld.fetch(p, tile + 1 < t1 ? tile + 1 : tile);
+    LB3_T(1)
     __syncthreads();
+    LB3_T(2)
     if (LN && prow >= 0) finish(b ^ 1);
+    LB3_T(4)
     const lds_cp yrow = (lds_cp)(buf + CF::OFF_DY + r * LDY + hh * 16);
 #pragma unroll
     for (int v = 0; v < 16; ++v) dx[v] = 0.f;
@@ -385,9 +417,13 @@ __global__ void __launch_bounds__((LB3<K, N>::NT), (LB3<K, N>::WPS)) lnlin3_bwd_
       s2 = half_swap_sum(s2);
       if (hh == 0) *reinterpret_cast<float2*>(red + ((b * NCT + dct) * 32 + r) * 2) = make_float2(s1, s2);
     } else {
+      LB3_T(3)
       finish(b);
+      LB3_T(4)
     }
+    LB3_T(3)
   }
+  LB3_TP("dgrad")
   if (LN) {
     __syncthreads();
     if (prow >= 0) finish(b ^ 1);
