@@ -216,7 +216,20 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
   for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
     const int b = win / nW, wi = win - b * nW;
     const int wr = wi / g.nWw, wc = wi - wr * g.nWw;
-    auto out_row = [&](int row) { return p.dqkv + win_token8(b, wr, wc, row, g) * p.ldq; };   // dqkv row of window token `row`
+    // dqkv rows of the lane's 16 accumulator rows of tile t (token (y, x) = (4 t + (v >> 2), 4 h + (v & 3)) of the window): the image row
+    // part is WAVE-UNIFORM (scalar registers), the column part one offset per (v & 3) — computed once per unit instead of a 64-bit
+    // token-index product in front of every one of the 16 x 3 (x 2) stores (64 v_mad_u64_u32 + 64 v_mul_lo_u32 per pass in the ISA)
+    auto out_rows = [&](int t, T* (&rowp)[4], int (&cofs)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int ry = wr * 8 + t * 4 + j + g.shift;
+        ry = ry >= g.H ? ry - g.H : ry;
+        rowp[j] = p.dqkv + ((int64_t)b * g.H + ry) * g.W * p.ldq;
+        int cx = wc * 8 + j + 4 * h + g.shift;
+        cx = cx >= g.W ? cx - g.W : cx;
+        cofs[j] = cx * (int)p.ldq;
+      }
+    };
     // the lane index is made opaque per window: the ~200 LDS positions of a unit are window-invariant, and hipcc
     // otherwise computes each of them (section + row x stride + lane part as its own register, not as an instruction
     // offset) in front of the window loop and spills them; recomputed per window they are base + immediate
@@ -402,9 +415,12 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
         const bool colin = col >= c_lo && col < c_hi;
         acc_xt_b<T, SP>(acc, D, Ks, ldt, col0, colin, lane);
         if (colin) {
+          T* rowp[4];
+          int cofs[4];
+          out_rows(t, rowp, cofs);
 #pragma unroll
           for (int v = 0; v < 16; ++v)
-            out_row(t * 32 + acc_row(v, h))[col] = from_f32<T>(acc[v] * p.scale);
+            rowp[v >> 2][cofs[v & 3] + col] = from_f32<T>(acc[v] * p.scale);
         }
       }
     }
@@ -467,9 +483,12 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
           for (int v = 0; v < 16; ++v) av[v] = 0.f;
           acc_xt_b<T, SP>(av, Y, Os, ldt, col0, colin, lane);   // dV_h = P^T dO_h
           if (colin) {
+            T* rowp[4];
+            int cofs[4];
+            out_rows(t, rowp, cofs);
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-              out_row(t * 32 + acc_row(v, h))[2 * C + col] = from_f32<T>(av[v]);
+              rowp[v >> 2][cofs[v & 3] + 2 * C + col] = from_f32<T>(av[v]);
           }
         }
         {
@@ -478,9 +497,12 @@ __global__ void __launch_bounds__(64 * NWAVES) wattn_bwd_mfma_kernel(const WbArg
           for (int v = 0; v < 16; ++v) ak[v] = 0.f;
           acc_xt_b<T, SP>(ak, E, Qs, ldt, col0, colin, lane);   // dK_h = dS^T Qs_h (Qs carries scale [* log2 e])
           if (colin) {
+            T* rowp[4];
+            int cofs[4];
+            out_rows(t, rowp, cofs);
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-              out_row(t * 32 + acc_row(v, h))[C + col] = from_f32<T>(ak[v] * kfix);
+              rowp[v >> 2][cofs[v & 3] + C + col] = from_f32<T>(ak[v] * kfix);
           }
         }
       }
