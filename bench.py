@@ -756,8 +756,13 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
             if n == "rdst_swin_attn_fwd":
                 M, C = a[18] * a[19] * a[20], a[21]
                 return [(a[9], a[10] * elt, 3 * C * elt, M), (a[11], a[12] * elt, C * elt, M), (a[13], a[14] * elt, C * elt, M), (a[15], 8, 8, M)]
-            M, C = a[7] * a[8] * a[9], a[10]
-            return [(a[5], a[6] * elt, C * elt, M)]
+            if n == "rdst_wattn_fwd_lse":   # (qkv, ld, table, out, ld_out, nlse, B, H, W, C, heads, ...)
+                M, C = a[6] * a[7] * a[8], a[9]
+                return [(a[3], a[4] * elt, C * elt, M), (a[5], 4 * a[10], 4 * a[10], M)]
+            if n == "rdst_wattn_fwd":       # (qkv, ld, table, mask, mask_nw, out, ld_out, B, H, W, C, ...)
+                M, C = a[7] * a[8] * a[9], a[10]
+                return [(a[5], a[6] * elt, C * elt, M)]
+            raise RuntimeError(f"no output map for {n}")
 
         def fwd_graph(skip):
             with torch.no_grad():
@@ -774,6 +779,7 @@ def op_tables(lib, recorded, elt, reps, dtype_name, net, x, ws16=False):
                     if _op_key(n) == skip:
                         for ptr, pitch, wb, rows in outputs(n, a):
                             if ptr and hip.hipMemset2D(ptr, pitch, 0, wb, rows) != 0:
+                                hip.hipGetLastError()   # (not sticky: the measurements after this one go on)
                                 raise RuntimeError("hipMemset2D failed")
                 torch.cuda.synchronize()
             return gph

@@ -20,6 +20,11 @@
 #include "mfma.h"
 #include "pack.h"
 
+#ifndef L3X_TWO_SHAPE
+#define L3X_TWO_SHAPE(K, N, RES) (!(RES) && (N) == 2 * (K))   // shapes that run TWO workgroups per CU on half-size tiles (see L3X::TWO):
+// norm2 + fc1.  A/B on one box, cold us per call: 26.5 -> 25.1 (C = 60), 42.5 -> 41.0 (90), 56.7 -> 50.6 (120); norm1 + qkv at C = 60 and the
+// dense tails at C = 60 are unchanged, the tail at C = 120 is slower (22.4 -> 28.2), N > 256 would need more than 16 waves per CU
+#endif
 #ifndef L3X_ABL
 #define L3X_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no MFMAs, 2 no conversion pass, 4 no global stores, 8 no tile DMA
 #endif
@@ -41,8 +46,8 @@ constexpr int l3x_pow2floor(int v) { return v >= 16 ? 16 : v >= 8 ? 8 : v >= 4 ?
 constexpr int l3x_pow2ceil(int v) { return v > 8 ? 16 : v > 4 ? 8 : v > 2 ? 4 : v > 1 ? 2 : 1; }
 constexpr int l3x_min(int a, int b) { return a < b ? a : b; }
 // compute waves: a multiple of NT (a wave keeps ONE output tile's fragments), at most 12, dividing the items evenly where one does
-constexpr int l3x_nwc(int NT, int items) {
-  for (int m = (12 / NT) * NT; m >= NT; m -= NT)
+constexpr int l3x_nwc(int NT, int items, int cap = 12) {
+  for (int m = (cap / NT) * NT; m >= NT; m -= NT)
     if (m <= items && items % m == 0) return m;
   return NT;
 }
@@ -56,11 +61,14 @@ struct L3X {
   static constexpr int BROWS = 8, BS = 144, BNCB = BROWS * BS;                              // (no residual) a wave's bounce image: 8 rows x 32 floats
   static constexpr int tileb(int tt) { return (tt * XSLOTS + 63) / 64 * 1024 + (RES ? (tt * RSLOTS + 63) / 64 * 1024 : 0); }
   // tokens per tile: as many as two buffers fit (one tile ahead in flight = 30..68 KB per CU)
-  static constexpr int LIM = (RES ? 156 : 144) * 1024;   // (without a residual tile the waves' bounce images come on top)
+  // TWO: two workgroups per CU, each with half the LDS — the conversion pass (vector ALU) of one runs beside the products (matrix pipe)
+  // and stores of the other; inside ONE workgroup the two phases are separated by barriers and never overlap
+  static constexpr bool TWO = L3X_TWO_SHAPE(K, N, RES);
+  static constexpr int LIM = TWO ? 62 * 1024 : (RES ? 156 : 144) * 1024;   // (without a residual tile the waves' bounce images come on top)
   static constexpr int TT = NBUF * tileb(128) <= LIM ? 128 : NBUF * tileb(64) <= LIM ? 64 : 32;
   static constexpr int SUB = TT / 32, ITEMS = NT * SUB;
   // waves: NWC compute waves, filled up to 8 with helpers (conversion pass, DMA issue)
-  static constexpr int NWC = l3x_nwc(NT, ITEMS);
+  static constexpr int NWC = l3x_nwc(NT, ITEMS, TWO ? 8 : 12);
   static constexpr int NW = NWC < 8 ? 8 : NWC, NTHR = 64 * NW;
   static constexpr int NJ = (ITEMS + NWC - 1) / NWC;
   static constexpr int TP = (TT * XSLOTS + 63) / 64, TILEB = TP * 1024;
@@ -73,10 +81,10 @@ struct L3X {
   static constexpr int SMEM = B_OFF + BB;
   static constexpr int LPT = l3x_min(l3x_pow2floor(NTHR / TT), l3x_pow2ceil(KS));         // lanes per token in the conversion pass
   static constexpr int NG = (KS + LPT - 1) / LPT;                                          // 64-byte groups per lane
-  static constexpr int WPS = (NW + 3) / 4;
+  static constexpr int WPS = (NW + 3) / 4 * (TWO ? 2 : 1);
   static constexpr int NST = (N % 4 == 0 && ITEMS % NWC == 0 && CNT + 4 * NJ < 64) ? 4 * NJ : 0;   // stores per compute wave and tile, where exact
   static_assert(NWC % NT == 0 && NWC <= 12, "a wave keeps one output tile");
-  static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert(SMEM <= 160 * 1024 / (TWO ? 2 : 1), "LDS");
   static_assert(TP >= NW && (!RES || RP >= NW), "every wave owns at least one piece of a tile");
   static_assert(CNT < 64, "vmcnt is a 6-bit counter");
   static_assert(LPT >= 1 && LPT <= 16 && NTHR % LPT == 0, "lanes per token");
@@ -358,7 +366,8 @@ template <int K, int N, int MODE, bool RES>
 int launch_l3x(L3XArgs& p, hipStream_t st, const char* what) {
   using CF = L3X<K, N, MODE, RES>;
   p.ntiles = (p.M + CF::TT - 1) / CF::TT;
-  int grid = p.ntiles < 256 ? p.ntiles : 256;
+  const int cap = CF::TWO ? 512 : 256;
+  int grid = p.ntiles < cap ? p.ntiles : cap;
   auto kern = lin3x_kernel<K, N, MODE, RES>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CF::NTHR), CF::SMEM, st, p);
