@@ -276,6 +276,38 @@ int run_wgrad(C1XArgs& p, float* dW, float* dbias, int wsc, int wst, int bias_wi
   hipLaunchKernelGGL(c1x_wgrad_finish_kernel, dim3((ROW + 255) / 256), dim3(256), 0, st, red, C, p.s, wsc, wst, dW, dbias, bias_wide);
   return rdst_launch_status("c1x_wgrad_finish");
 }
+// 1x1 conv with one input and one output channel on fp32 rows (MeanShift on a single-channel image, common.py:151-167): an elementwise
+// affine map, out = in (w s) + b s (+ add); four elements per thread where the rows are contiguous.  (On the generic functor GEMM the two
+// MeanShifts of an RDST-E1 step and the data gradient of the second took 123 + 123 + 189 us: 0.43 ms of the fp32x3 step.)
+__global__ void __launch_bounds__(256) c1x_pw11_kernel(const float* __restrict__ in, int64_t ldi, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* add, int64_t lda, float* out, int64_t ldo,
+                                                       int64_t P, float s, int vec) {
+  const float w = W[0] * s, b = bias ? bias[0] * s : 0.f;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (vec) {
+    const int64_t e0 = i * 4;
+    if (e0 + 4 <= P) {
+      const float4 v = *reinterpret_cast<const float4*>(in + e0);
+      float4 o = make_float4(fmaf(v.x, w, b), fmaf(v.y, w, b), fmaf(v.z, w, b), fmaf(v.w, w, b));
+      if (add) {
+        const float4 a = *reinterpret_cast<const float4*>(add + e0);
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      *reinterpret_cast<float4*>(out + e0) = o;
+    } else {
+      for (int64_t e = e0; e < P; ++e) out[e] = fmaf(in[e], w, b) + (add ? add[e] : 0.f);
+    }
+    return;
+  }
+  if (i < P) out[i * ldo] = fmaf(in[i * ldi], w, b) + (add ? add[i * lda] : 0.f);
+}
+int pw11x_launch(const float* in, int64_t ldi, const float* W, const float* bias, const float* add, int64_t lda, float* out, int64_t ldo,
+                 int64_t P, float s, hipStream_t st, const char* what) {
+  const bool vec = ldi == 1 && ldo == 1 && (!add || lda == 1) && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)add) & 15) == 0;
+  const int64_t n = vec ? (P + 3) / 4 : P;
+  hipLaunchKernelGGL(c1x_pw11_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, ldi, W, bias, add, lda, out, ldo, P, s, vec ? 1 : 0);
+  return rdst_launch_status(what);
+}
 }  // namespace
 
 size_t conv_c1x_slab_floats(int C) { return (size_t)(256 + 1) * (10 * C + 1); }
@@ -283,7 +315,8 @@ size_t conv_c1x_slab_floats(int C) { return (size_t)(256 + 1) * (10 * C + 1); }
 // wide -> 1 forward (the tail conv).  RDST_ENOTSUP for other shapes / a residual.
 int conv_c1x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, const float* bias, const float* R, int64_t ldr, float* Y,
                      int64_t ldy, const ConvGeom& g, float s, hipStream_t st) {
-  (void)ldr;
+  if (g.Cin == 1 && g.Cout == 1 && g.ks == 1 && g.r == 1 && in_act == 0)
+    return pw11x_launch(X, ldx, Wc, bias, R, ldr, Y, ldy, g.pixels(), s, st, "conv_pw11x_fwd");
   if (g.Cout != 1 || R || !shape_ok(g, in_act, g.Cin) || ((uintptr_t)X & 3)) return RDST_ENOTSUP;
   C1XArgs p{};
   set_tiles(p, g, g.Cin);
@@ -305,6 +338,8 @@ int conv_in1x_fwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, 
 // backward of the tail conv (Cout == 1): dX (optional) = s conv^T(dY) + dX_add, dW (1, Cin, 3, 3), dbias (1); slab: conv_c1x_slab_floats(Cin)
 int conv_c1x_bwd_f32(const float* X, int64_t ldx, int in_act, const float* Wc, const float* dY, int64_t lddy, float* dX, int64_t lddx,
                      const float* acc, int64_t ldacc, float* dW, float* dbias, float* slab, const ConvGeom& g, float s, hipStream_t st) {
+  if (g.Cin == 1 && g.Cout == 1 && g.ks == 1 && g.r == 1 && in_act == 0 && !dW && !dbias && dX)   // frozen MeanShift: dX = dY w s (+ dX_add)
+    return pw11x_launch(dY, lddy, Wc, nullptr, acc, ldacc, dX, lddx, g.pixels(), s, st, "conv_pw11x_dgrad");
   if (g.Cout != 1 || !shape_ok(g, in_act, g.Cin) || ((uintptr_t)X & 3) || ((uintptr_t)dX & 3) || ((uintptr_t)acc & 3)) return RDST_ENOTSUP;
   C1XArgs p{};
   set_tiles(p, g, g.Cin);

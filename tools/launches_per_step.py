@@ -6,7 +6,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 segs, cur = [], collections.Counter()
 for r in rows:
-    cur[r["Kernel_Name"].split("(")[0][:70]] += 1
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    cur[name.split("(")[0][:70]] += 1
     if "adam_kernel" in r["Kernel_Name"]:
         segs.append(cur)
         cur = collections.Counter()
