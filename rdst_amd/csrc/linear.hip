@@ -120,6 +120,18 @@ __device__ __forceinline__ void ln8_unpack(const ln8_u32x4& v, float (&f)[8]) {
 __device__ __forceinline__ uint32_t ln8_pack2(float a, float b) {
   return (uint32_t)__builtin_bit_cast(uint16_t, __float2bfloat16(a)) | ((uint32_t)__builtin_bit_cast(uint16_t, __float2bfloat16(b)) << 16);
 }
+// a lane's 8 channels of a row: one 16-byte load (bf16) or two (fp32 rows: round 6 — the fp32 modes still ran row_stats + ln_apply and
+// scale_to_f32 + ln_bwd_rows, one wave per row: 0.24 ms of the fp32x3 step for the two LayerNorm-only layers)
+template <typename T>
+__device__ __forceinline__ void ln8_load(const T* p, float (&f)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(p), f);
+  } else {
+    const ln8_u32x4 a = *reinterpret_cast<const ln8_u32x4*>(p), b = *reinterpret_cast<const ln8_u32x4*>(p + 4);
+    f[0] = __uint_as_float(a.x); f[1] = __uint_as_float(a.y); f[2] = __uint_as_float(a.z); f[3] = __uint_as_float(a.w);
+    f[4] = __uint_as_float(b.x); f[5] = __uint_as_float(b.y); f[6] = __uint_as_float(b.z); f[7] = __uint_as_float(b.w);
+  }
+}
 struct Ln8Lane { int c0, lo; bool on; };
 __device__ __forceinline__ Ln8Lane ln8_lane(int grp, int K) {
   Ln8Lane l;
@@ -128,6 +140,20 @@ __device__ __forceinline__ Ln8Lane ln8_lane(int grp, int K) {
   l.lo = 8 * grp - l.c0;
   if (!l.on) { l.c0 = 0; l.lo = 8; }
   return l;
+}
+__device__ __forceinline__ void ln8_store(float* dst, const float (&o)[8], const Ln8Lane& l) {
+  if (!l.on) return;
+  if (l.lo == 0) {
+    ln8_u32x4 u, v;
+    u.x = __float_as_uint(o[0]); u.y = __float_as_uint(o[1]); u.z = __float_as_uint(o[2]); u.w = __float_as_uint(o[3]);
+    v.x = __float_as_uint(o[4]); v.y = __float_as_uint(o[5]); v.z = __float_as_uint(o[6]); v.w = __float_as_uint(o[7]);
+    *reinterpret_cast<ln8_u32x4*>(dst + l.c0) = u;
+    *reinterpret_cast<ln8_u32x4*>(dst + l.c0 + 4) = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e >= l.lo) dst[l.c0 + e] = o[e];
+  }
 }
 __device__ __forceinline__ void ln8_store(bf16* dst, const float (&o)[8], const Ln8Lane& l) {
   if (!l.on) return;
@@ -142,8 +168,9 @@ __device__ __forceinline__ void ln8_store(bf16* dst, const float (&o)[8], const 
   }
 }
 
-__global__ void __launch_bounds__(256) ln8_fwd_kernel(const bf16* __restrict__ X, int64_t ldx, const float* __restrict__ g,
-                                                      const float* __restrict__ b, const bf16* R, int64_t ldr, bf16* Y, int64_t ldy,
+template <typename T>
+__global__ void __launch_bounds__(256) ln8_fwd_kernel(const T* __restrict__ X, int64_t ldx, const float* __restrict__ g,
+                                                      const float* __restrict__ b, const T* R, int64_t ldr, T* Y, int64_t ldy,
                                                       float* __restrict__ stats, int64_t M, int K, float s) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ps = lane >> 3, grp = lane & 7;
   const Ln8Lane l = ln8_lane(grp, K);
@@ -155,7 +182,7 @@ __global__ void __launch_bounds__(256) ln8_fwd_kernel(const bf16* __restrict__ X
     const int64_t row = r0 + ps < M ? r0 + ps : M - 1;
     const bool valid = r0 + ps < M;
     float f[8];
-    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(X + row * ldx + l.c0), f);
+    ln8_load<T>(X + row * ldx + l.c0, f);
     float sum = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += (l.on && e >= l.lo) ? f[e] : 0.f;
@@ -172,7 +199,7 @@ __global__ void __launch_bounds__(256) ln8_fwd_kernel(const bf16* __restrict__ X
     for (int e = 0; e < 8; ++e) o[e] = (f[e] * rstd * gm[e] + bt[e]) * s;
     if (R) {
       float rr[8];
-      ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(R + row * ldr + l.c0), rr);
+      ln8_load<T>(R + row * ldr + l.c0, rr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += rr[e];
     }
@@ -184,9 +211,10 @@ __global__ void __launch_bounds__(256) ln8_fwd_kernel(const bf16* __restrict__ X
 }
 
 // dX = rstd (g - mean(g) - xhat mean(g xhat)) + acc, g = dY s gamma; per-block partial d(gamma) / d(beta) -> slab [block][2][K]
-__global__ void __launch_bounds__(256) ln8_bwd_kernel(const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
-                                                      const float* __restrict__ stats, const float* __restrict__ gamma, bf16* dX,
-                                                      int64_t lddx, const bf16* acc, int64_t ldacc, float* __restrict__ slab, int64_t M,
+template <typename T>
+__global__ void __launch_bounds__(256) ln8_bwd_kernel(const T* __restrict__ dY, int64_t lddy, const T* __restrict__ X, int64_t ldx,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma, T* dX,
+                                                      int64_t lddx, const T* acc, int64_t ldacc, float* __restrict__ slab, int64_t M,
                                                       int K, float s) {
   __shared__ float red[4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ps = lane >> 3, grp = lane & 7;
@@ -200,8 +228,8 @@ __global__ void __launch_bounds__(256) ln8_bwd_kernel(const bf16* __restrict__ d
     const bool valid = r0 + ps < M;
     const float2 st = *reinterpret_cast<const float2*>(stats + 2 * row);
     float da[8], xh[8], gg[8];
-    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(dY + row * lddy + l.c0), da);
-    ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(X + row * ldx + l.c0), xh);
+    ln8_load<T>(dY + row * lddy + l.c0, da);
+    ln8_load<T>(X + row * ldx + l.c0, xh);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -222,7 +250,7 @@ __global__ void __launch_bounds__(256) ln8_bwd_kernel(const bf16* __restrict__ d
       for (int e = 0; e < 8; ++e) o[e] = st.y * (gg[e] - s1 - xh[e] * s2);
       if (acc) {
         float a[8];
-        ln8_unpack(*reinterpret_cast<const ln8_u32x4*>(acc + row * ldacc + l.c0), a);
+        ln8_load<T>(acc + row * ldacc + l.c0, a);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] += a[e];
       }
@@ -244,8 +272,8 @@ __global__ void __launch_bounds__(256) ln8_bwd_kernel(const bf16* __restrict__ d
     slab[(int64_t)blockIdx.x * 2 * K + i] = red[0][which][k] + red[1][which][k] + red[2][which][k] + red[3][which][k];
   }
 }
-static inline bool ln8_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, int K) {
-  auto al = [](const void* q, int64_t l) { return ((uintptr_t)q & 3) == 0 && (l & 1) == 0; };
+static inline bool ln8_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, int K, int elt = 2) {
+  auto al = [elt](const void* q, int64_t l) { return ((uintptr_t)q & 3) == 0 && (elt == 4 || (l & 1) == 0); };
   return K >= 8 && K <= 64 && (K & 1) == 0 && al(a, lda) && al(b, ldb) && al(c, ldc);
 }
 
@@ -407,13 +435,11 @@ int fwd_t(const T* X, int64_t ldx, const float* ln_w, const float* ln_b, int in_
     return rdst_launch_status("row_stats");
   };
   if (!Wt) {
-    if constexpr (sizeof(T) == 2) {
-      if (ln8_ok(X, ldx, Y, ldy, R, ldr, K)) {
-        const int64_t nb = (M + 31) / 32;
-        hipLaunchKernelGGL(ln8_fwd_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, st, X, ldx, ln_w, ln_b, R, ldr, Y, ldy,
-                           stats, M, K, s);
-        return rdst_launch_status("ln8_fwd");
-      }
+    if (ln8_ok(X, ldx, Y, ldy, R, ldr, K, (int)sizeof(T))) {
+      const int64_t nb = (M + 31) / 32;
+      hipLaunchKernelGGL((ln8_fwd_kernel<T>), dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, st, X, ldx, ln_w, ln_b, R, ldr, Y, ldy,
+                         stats, M, K, s);
+      return rdst_launch_status("ln8_fwd");
     }
     if (int rc = run_stats()) return rc;
     const int64_t n = M * K;
@@ -581,14 +607,12 @@ int ln_only_bwd(const T* X, int64_t ldx, const float* ln_w, const float* stats, 
   float* dA = wsp;
   float* small = dA + M * K;
   const int64_t n = M * K;
-  if constexpr (sizeof(T) == 2) {
-    if (K <= 64 && ln8_ok(X, ldx, dY, lddy, dX, lddx, K) && ln8_ok(acc, ldacc, nullptr, 0, nullptr, 0, K)) {
-      const int64_t nb = (M + 31) / 32;
-      const int blocks = (int)(nb < kSmallBlocks ? nb : kSmallBlocks);
-      hipLaunchKernelGGL(ln8_bwd_kernel, dim3(blocks), dim3(256), 0, st, dY, lddy, X, ldx, stats, ln_w, dX, lddx, acc, ldacc, small, M, K, s);
-      if (int rc = rdst_launch_status("ln8_bwd")) return rc;
-      return slab_reduce2(small, dln_w, dln_b, blocks, K, st);
-    }
+  if (K <= 64 && ln8_ok(X, ldx, dY, lddy, dX, lddx, K, (int)sizeof(T)) && ln8_ok(acc, ldacc, nullptr, 0, nullptr, 0, K, (int)sizeof(T))) {
+    const int64_t nb = (M + 31) / 32;
+    const int blocks = (int)(nb < kSmallBlocks ? nb : kSmallBlocks);
+    hipLaunchKernelGGL((ln8_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, dY, lddy, X, ldx, stats, ln_w, dX, lddx, acc, ldacc, small, M, K, s);
+    if (int rc = rdst_launch_status("ln8_bwd")) return rc;
+    return slab_reduce2(small, dln_w, dln_b, blocks, K, st);
   }
   hipLaunchKernelGGL((scale_to_f32_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dY, lddy, dA, M, K, s);
   if (int rc = rdst_launch_status("scale_to_f32")) return rc;

@@ -30,6 +30,7 @@ LIN = [  # M, K, N, ln, act, residual, scale
     (288, 120, 30, True, 0, False, 1.0),     # dense tail as E1 runs it (one-pass backward, 1 n-tile on 8 waves)
     (160, 90, 270, True, 0, False, 1.0),     # norm1 + qkv at C = 90 (one-pass backward, 9 waves)
     (130, 48, 48, True, 0, True, 0.9),       # LayerNorm only (no weight), scale + residual
+    (4133, 60, 60, True, 0, True, 0.9),      # ... at E1's width (the last 8-channel chunk of a row overlaps its neighbour), many row groups
     (64, 33, 17, False, 2, False, 1.0),      # odd sizes, LeakyReLU input
     (384, 90, 270, True, 0, False, 1.0),     # fp32: the weights fit the LDS only as ONE chunk that ends inside a column tile (launch_lin)
     (320, 240, 120, False, 1, True, 1.0),    # GELU + fc2 at C = 120 (fp32: the same single tight chunk), + residual
