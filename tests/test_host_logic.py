@@ -339,3 +339,57 @@ def test_compute_dtype_switch_and_dtype_codes():
             ops._dtype_code(torch.zeros(1, dtype=torch.float16))
     finally:
         ops.set_f32_split(False)
+
+
+def test_reduce_batch_bookkeeping_nesting_foreign_pass_and_reset(monkeypatch):
+    """The host-side bookkeeping of the batched slab reductions (ops._ReduceBatch) against a recording stand-in for the library:
+    a DenseSTLayer's outer batch nests the blocks' own (ONE begin / end pair reaches the C side); a dense join that finds the batch of
+    ANOTHER live backward pass open nests inside it and makes every node flush (it must not drop the other pass's queued jobs); a join
+    that finds a leftover of its OWN pass drops it; ops.reset_backward_state() makes the thread drop a stale batch the next time it
+    touches one (how the trainer reaches autograd's device thread after a failed capture)."""
+    from rdst_amd import ops
+    RB = ops._ReduceBatch
+    calls = []
+
+    class Lib:
+        def __getattr__(self, name):
+            def f(*a):
+                calls.append(name)
+                return 0
+            return f
+    lib = Lib()
+    task = {"id": 7}
+    monkeypatch.setattr(RB, "_task", staticmethod(lambda: task["id"]))
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+    RB.abandon(lib)
+    calls.clear()
+    # one pass: join opens the layer's batch, two blocks nest, the first block of the layer closes it
+    RB.begin_layer(lib)
+    for _ in range(2):
+        RB.begin(lib); RB.settle(lib); RB.end(lib)
+    RB.end(lib)
+    assert calls == ["rdst_reduce_batch_begin", "rdst_reduce_batch_end"] and RB.depth == 0 and not RB.mixed
+    # a second pass's join runs while the first pass's batch is open: nest + flush at every node, nothing aborted
+    calls.clear()
+    RB.begin_layer(lib)              # pass 7
+    task["id"] = 8
+    RB.begin_layer(lib)              # pass 8 inside it
+    assert RB.depth == 2 and RB.mixed and "rdst_reduce_batch_abort" not in calls
+    RB.begin(lib); RB.settle(lib); RB.end(lib)      # a node of pass 8: flushed (end + begin) before it returns
+    assert calls.count("rdst_reduce_batch_end") == 1 and calls.count("rdst_reduce_batch_begin") == 2
+    RB.end(lib)                      # pass 8's layer closes
+    task["id"] = 7
+    RB.end(lib)                      # pass 7's layer closes: the batch ends
+    assert RB.depth == 0 and "rdst_reduce_batch_abort" not in calls
+    # a leftover of the SAME pass (a node raised, the pass re-entered): dropped
+    calls.clear()
+    RB.begin_layer(lib)
+    RB.begin_layer(lib)
+    assert calls == ["rdst_reduce_batch_begin", "rdst_reduce_batch_abort", "rdst_reduce_batch_begin"] and RB.depth == 1
+    # reset_backward_state(): the stale batch is dropped the next time this thread touches one
+    calls.clear()
+    type(RB).EPOCH += 1
+    RB.begin(lib)
+    assert calls[:2] == ["rdst_reduce_batch_abort", "rdst_reduce_batch_begin"] and RB.depth == 1
+    RB.end(lib)
+    assert RB.depth == 0
