@@ -29,6 +29,17 @@
 #define L3X_ABL 0   // compile-time ablations (tools/abl_build.sh): 1 no MFMAs, 2 no conversion pass, 4 no global stores, 8 no tile DMA
 #endif
 
+// -DL3X_STAMPS: workgroup 0 prints, per wave, the clock64() ticks it spent in each phase of the tile loop (tools/abl_build.sh)
+#ifdef L3X_STAMPS
+#define L3X_T0 long long tk_[6] = {0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#define L3X_T(i) { const long long n_ = clock64(); tk_[i] += n_ - tl_; tl_ = n_; }
+#define L3X_TP if (blockIdx.x == 0 && lane == 0) printf("wave %d: issue %lld  wait %lld  barrier1 %lld  convert %lld  barrier2 %lld  products+stores %lld\n", wave, tk_[0], tk_[1], tk_[2], tk_[3], tk_[4], tk_[5]);
+#else
+#define L3X_T0
+#define L3X_T(i)
+#define L3X_TP
+#endif
+
 namespace {
 
 constexpr int X3_PLAIN = 0, X3_LN = 1, X3_GELU = 2;
@@ -175,8 +186,10 @@ __global__ void __launch_bounds__((L3X<K, N, MODE, RES>::NTHR), (L3X<K, N, MODE,
 
   int b = 0;
   if ((int)blockIdx.x < p.ntiles) issue_tile(blockIdx.x, 0);
+  L3X_T0
   for (int tile = blockIdx.x; tile < p.ntiles; tile += grid, b ^= 1) {
     issue_tile(tile + grid, b ^ 1);   // (buffer b ^ 1: everybody left it at the barrier that ended the previous iteration)
+    L3X_T(0)
     // Wait for THIS tile (issued one iteration ago), not for what was issued since: the CNT pieces of the next tile and — the point —
     // the previous tile's output stores, which then drain beside this tile's conversion and products instead of in front of them
     // (a plain vmcnt(CNT) waits for them: memory operations complete in issue order).  The count must never exceed what really was
@@ -186,7 +199,9 @@ __global__ void __launch_bounds__((L3X<K, N, MODE, RES>::NTHR), (L3X<K, N, MODE,
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(whi[ks]), "+v"(wlo[ks]));   // every use of a fragment is behind a wait
+    L3X_T(1)
     __syncthreads();
+    L3X_T(2)
     char* tb = smem + b * CF::TILEB;
     char* rb = smem + CF::R_OFF + b * CF::RTILEB;
     // ---- conversion pass: raw fp32 row -> (LayerNorm | GELU | as it is) -> [8 hi | 8 hi | 8 lo | 8 lo] per 16 k, in place ----
@@ -262,7 +277,9 @@ __global__ void __launch_bounds__((L3X<K, N, MODE, RES>::NTHR), (L3X<K, N, MODE,
         }
       }
     }
+    L3X_T(3)
     __syncthreads();
+    L3X_T(4)
     // ---- items of this wave: output tile nt, token sub-tiles tt = (wave + NWC j) / NT ----
     if (wave < NWC) {
 #pragma unroll 1
@@ -358,8 +375,11 @@ __global__ void __launch_bounds__((L3X<K, N, MODE, RES>::NTHR), (L3X<K, N, MODE,
         }
       }
     }
+    L3X_T(5)
     __syncthreads();   // buffer b may be overwritten (the next iteration's issue targets it)
+    L3X_T(2)
   }
+  L3X_TP
 }
 
 template <int K, int N, int MODE, bool RES>

@@ -13,7 +13,11 @@ SH = [(60, 180, 1, 0, 0, "qkv60"), (90, 270, 1, 0, 0, "qkv90"), (120, 360, 1, 0,
       (60, 120, 1, 0, 0, "fc1_60"), (90, 180, 1, 0, 0, "fc1_90"), (120, 240, 1, 0, 0, "fc1_120"), (120, 60, 0, 1, 1, "fc2_60"),
       (180, 90, 0, 1, 1, "fc2_90"), (240, 120, 0, 1, 1, "fc2_120")]
 tot = 0.0
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-") and a != "old"]   # shape names; --once: a single call each (the -DL3X_STAMPS build prints)
+ONCE = "--once" in sys.argv
 for K, N, ln, act, res, name in SH:
+    if ONLY and name not in ONLY:
+        continue
     NB = 4
     xs = [torch.randn(M, K, device=dev) for _ in range(NB)]
     ys = [torch.empty(M, N, device=dev) for _ in range(NB)]
@@ -33,6 +37,9 @@ for K, N, ln, act, res, name in SH:
 
     call(0, nws)   # packs
     torch.cuda.synchronize()
+    if ONCE:
+        print(name, flush=True)
+        continue
     for i in range(4):
         call(i, _lib.PREPACKED)
     torch.cuda.synchronize()
