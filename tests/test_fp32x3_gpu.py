@@ -179,6 +179,7 @@ def test_ln_linear_fp32x3_vs_torch(K, N, ln, act, res):
     (3, 64, 64, 150, 60, 3, 0, 1, 1),     # conv3x at the E1 image size, several images (the DMA row ring wraps across images)
     (1, 128, 128, 60, 240, 3, 0, 0, 2),   # the second upsampler stage: 128 x 128 -> 256 x 256 (four sub-pixel data-gradient launches)
     (2, 64, 64, 1, 60, 3, 0, 0, 1),       # the head conv 1 -> 60 (conv_c1x.hip)
+    (2, 16, 25, 1, 1, 1, 0, 1, 1),        # MeanShift on a single-channel image: the elementwise kernel of conv_c1x.hip, + residual
 ])
 def test_conv_fp32x3_vs_torch(B, H, W, Cin, Cout, k, act, res, r):
     """k x k convolution (+ LeakyReLU in front, residual, PixelShuffle) forward and every gradient with split-bf16 operands against

@@ -100,6 +100,7 @@ CONV = [  # B, H, W, Cin, Cout, k, act, residual, scale, shuffle
     (1, 6, 6, 48, 108, 3, 0, False, 1.0, 3),   # x3 upsampler
     (2, 5, 5, 3, 3, 1, 0, False, 1.0, 1),      # MeanShift
     (2, 16, 25, 1, 1, 1, 0, True, 0.5, 1),     # MeanShift on a single-channel image (elementwise kernel), + residual, ragged tail
+    (1, 7, 9, 1, 1, 1, 0, True, 1.0, 1),       # ... 63 pixels: the last thread's chunk is cut (fp32: 4 per thread, bf16: 8)
     (1, 8, 32, 150, 60, 3, 0, True, 0.7, 1),   # fusion conv on full 32-pixel row slabs (fp32: two launches over halves of the input channels)
     (1, 4, 32, 60, 240, 3, 0, False, 1.0, 2),  # upsampler conv, 32-pixel row slabs (fp32 data gradient: two launches over halves of dY's channels)
     (1, 6, 10, 150, 60, 3, 2, True, 1.0, 1),   # the same split on the pixel-tile kernel, reading through LeakyReLU
